@@ -1,0 +1,148 @@
+/* uaps_hip.h -- C ABI of libuaps_hip.so, the MI355X (gfx950) kernels of the UAPS training step.
+ *
+ * The reference (djene-mengistu/UAPS) is pure Python on PyTorch and has no FFI of its own
+ * (SURVEY.md section 8b); each entry point below replaces a chain of PyTorch ops of the reference
+ * step, cited as file:line relative to the reference root.  The host side (the uaps_amd Python package) binds
+ * these with ctypes; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory;
+ *   - tensors are dense fp32 NCHW exactly as the reference's decoders produce them; labels and
+ *     pseudo-labels are int64 [B,H,W] as torch.argmax / the reference's data loader produce them;
+ *   - `stream` is a hipStream_t (0 = the null stream); calls only enqueue work, never synchronise,
+ *     never allocate, keep no global state and are re-entrant per stream (safe under hipGraph capture);
+ *   - return value: 0 on success, a negative UAPS_E* code for bad arguments, a positive hipError_t
+ *     if a launch failed.  Nothing throws.
+ *   - number of heads D in [1,8] (main + auxiliary decoders), classes C in [2,8].
+ */
+#ifndef UAPS_HIP_H
+#define UAPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* uaps_stream_t; /* hipStream_t */
+
+#define UAPS_MAX_HEADS 8
+#define UAPS_MAX_CLASSES 8
+
+#define UAPS_OK 0
+#define UAPS_EINVAL (-1)     /* null pointer, non-positive dimension                       */
+#define UAPS_ERANGE (-2)     /* D or C outside the supported range                         */
+#define UAPS_EWORKSPACE (-3) /* workspace smaller than uaps_loss_workspace_bytes() reports */
+
+int uaps_abi_version(void);
+const char* uaps_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loss block of the step: UAPS_train.py:186-282 (+ utilities/pytorch_losses.py:54-89 dice_loss,
+ * torch.nn.CrossEntropyLoss / KLDivLoss / LogSoftmax objects created at UAPS_train.py:73-75).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Layout of the `scalars` output of the two forward calls (float, device).  Offsets in floats. */
+/* unsupervised: */
+#define UAPS_U_CE(D, C) 0                                   /* ce[D]    CE_k vs pseudo-label (mean)       :259 */
+#define UAPS_U_DICE(D, C) (D)                               /* dice[D]  dice_loss_k vs pseudo-label       :259 */
+#define UAPS_U_S(D, C) (2 * (D))                            /* s[D]     0.5 (ce+dice)                      :259 */
+#define UAPS_U_E(D, C) (3 * (D))                            /* E[D]     mean_pix exp(-var_k)               :265 */
+#define UAPS_U_PS(D, C) (4 * (D))                           /* ps_loss                                     :277 */
+#define UAPS_U_LUN(D, C) (4 * (D) + 1)                      /* l_uncert                                    :243 */
+#define UAPS_U_LOSS(D, C) (4 * (D) + 2)                     /* cw1*ps_loss + cw2*l_uncert                  :282 */
+#define UAPS_U_A1(D, C) (4 * (D) + 4)                       /* a1[D*C] = -(2/C)/(card+eps)   (for backward) */
+#define UAPS_U_A2(D, C) (4 * (D) + 4 + (D) * (C))           /* a2[D*C] = (2/C) I/(card+eps)^2               */
+#define UAPS_U_I(D, C) (4 * (D) + 4 + 2 * (D) * (C))        /* I[D*C]    sum p_kc [y=c]    pytorch_losses.py:85 */
+#define UAPS_U_CARD(D, C) (4 * (D) + 4 + 3 * (D) * (C))     /* card[D*C] sum p_kc + [y=c]  pytorch_losses.py:86 */
+#define UAPS_U_CNT(D, C) (4 * (D) + 4 + 4 * (D) * (C))      /* cnt[C]    pixels per pseudo-label class      */
+#define UAPS_U_NSCALARS(D, C) (4 * (D) + 4 + 4 * (D) * (C) + (C))
+/* supervised: */
+#define UAPS_S_CE(D, C) 0                                   /* ce[D]                              :194-197 */
+#define UAPS_S_DICE(D, C) (D)                               /* dice[D]                            :201-204 */
+#define UAPS_S_SUP(D, C) (2 * (D))                          /* sum_k ce_coef*ce_k + dice_coef*dice_k  :218 */
+#define UAPS_S_BAD(D, C) (2 * (D) + 1)                      /* number of labels outside [0,C) (must be 0)  */
+#define UAPS_S_A1(D, C) (2 * (D) + 2)
+#define UAPS_S_A2(D, C) (2 * (D) + 2 + (D) * (C))
+#define UAPS_S_I(D, C) (2 * (D) + 2 + 2 * (D) * (C))
+#define UAPS_S_CARD(D, C) (2 * (D) + 2 + 3 * (D) * (C))
+#define UAPS_S_CNT(D, C) (2 * (D) + 2 + 4 * (D) * (C))
+#define UAPS_S_NSCALARS(D, C) (2 * (D) + 2 + 4 * (D) * (C) + (C))
+
+/* Bytes of scratch the forward calls need (block partial sums); same query serves both. */
+int uaps_loss_workspace_bytes(int D, int B, int C, int H, int W, size_t* out_host);
+
+/* Unsupervised branch, forward.  Replaces UAPS_train.py:186-189 (softmax), 223 (mean prediction),
+ * 226-236 (KL "variance" maps, exp(-var)), 241-243 (l_uncert), 251-255 (Dirichlet-mixed arg-max
+ * pseudo-label; w_host are the np.random.dirichlet weights, applied as fp32 scalars left to right),
+ * 259-277 (CE + Dice pseudo-supervision weighted by mean(exp(-var))) and the cw-weighted sum of 282.
+ *   logits_host : host array of D device pointers, each fp32 [B,C,H,W] contiguous
+ *   pseudo      : out int64 [B,H,W]
+ *   var         : out fp32 [D,B,H,W] (var_k = sum_c KL(mean || p_k)); may be NULL to skip the store
+ *   scalars     : out fp32 [UAPS_U_NSCALARS(D,C)]
+ */
+int uaps_unsup_fwd(const float* const* logits_host, const double* w_host, int D, int B, int C, int H, int W,
+                   float cw1, float cw2, float eps, int64_t* pseudo, float* var, float* scalars,
+                   void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+
+/* Unsupervised branch, backward: d(gscale * (cw1*ps_loss + cw2*l_uncert)) / d logits_k, the closed
+ * form of what autograd derives from UAPS_train.py:223-282.
+ *   gscale  : device pointer to the upstream gradient (one float), or NULL for 1
+ *   dlogits_host : host array of D device pointers, each fp32 [B,C,H,W], overwritten
+ */
+int uaps_unsup_bwd(const float* const* logits_host, const int64_t* pseudo, const float* scalars, float cw1,
+                   float cw2, const float* gscale, int D, int B, int C, int H, int W,
+                   float* const* dlogits_host, uaps_stream_t stream);
+
+/* Supervised branch: UAPS_train.py:194-218.  loss = sum_k (ce_coef * CrossEntropy_k + dice_coef * dice_loss_k);
+ * the reference's supervised_loss (mean over heads of 0.5 (CE + Dice)) is ce_coef = dice_coef = 0.5 / D.
+ * With D = 1: (1, 0) is nn.CrossEntropyLoss()(logits, labels) (UAPS_train.py:75) and (0, 1) is
+ * dice_loss(labels.unsqueeze(1), logits, eps) (utilities/pytorch_losses.py:54-89). */
+int uaps_sup_fwd(const float* const* logits_host, const int64_t* labels, int D, int B, int C, int H, int W,
+                 float ce_coef, float dice_coef, float eps, float* scalars, void* workspace,
+                 size_t workspace_bytes, uaps_stream_t stream);
+int uaps_sup_bwd(const float* const* logits_host, const int64_t* labels, const float* scalars, float ce_coef,
+                 float dice_coef, const float* gscale, int D, int B, int C, int H, int W,
+                 float* const* dlogits_host, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Feature perturbations of the auxiliary decoders: utilities/UAPS_unet.py:156-185, applied to all
+ * five encoder scales at UAPS_unet.py:227-231.  Random numbers: Philox4x32-10 keyed by `seed`,
+ * counter = element index + `offset` (the reference draws from the unseeded CPU generators, so
+ * bit parity of the draws is impossible; the *_apply forms take recorded draws for parity tests).
+ * ------------------------------------------------------------------------------------------- */
+
+/* FeatureNoise (UAPS_unet.py:172-185): y = x*n + x, n ~ U(-range, range) of shape [C,H,W] shared by
+ * the batch.  Backward = the same call on dy with the same seed.  noise_out (fp32 [C,H,W]) may be NULL. */
+int uaps_feat_noise(const float* x, float* y, int B, int C, int H, int W, uint64_t seed, uint64_t offset,
+                    float range, float* noise_out, uaps_stream_t stream);
+/* Same with a given noise tensor (fp32 [C*H*W]); chw = C*H*W. */
+int uaps_feat_noise_apply(const float* x, const float* noise, float* y, int B, long chw, uaps_stream_t stream);
+
+/* Dropout(x, p) = F.dropout(x, p, training=True) (UAPS_unet.py:156-158): y = x * keep / (1-p).
+ * Backward = the same call on dy with the same seed.  keep_out (uint8 [n]) may be NULL. */
+int uaps_feat_bernoulli(const float* x, float* y, long n, uint64_t seed, uint64_t offset, float p,
+                        uint8_t* keep_out, uaps_stream_t stream);
+int uaps_feat_mask_apply(const float* x, const uint8_t* keep, float scale, float* y, long n, uaps_stream_t stream);
+
+/* FeatureDropout (UAPS_unet.py:161-169): y = x * (mean_c x < u * max_hw mean_c x), u = the
+ * np.random.uniform(0.7, 0.9) draw.  keep [B,H,W] uint8 is written for the backward (dx = dy * keep).
+ * workspace: uaps_feat_dropout_workspace_bytes(). */
+int uaps_feat_dropout_workspace_bytes(int B, int C, int H, int W, size_t* out_host);
+int uaps_feat_dropout_fwd(const float* x, float* y, int B, int C, int H, int W, float u, uint8_t* keep,
+                          void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int B, int C, int H, int W,
+                          uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Metrics: utilities/metrics.py:8-61 (pixel_accuracy, mIoU, mDice) need only the C x C confusion
+ * matrix of arg-max(logits) against the labels: counts[t*C + p], int64, overwritten.
+ * ------------------------------------------------------------------------------------------- */
+int uaps_seg_confusion(const float* logits, const int64_t* labels, int B, int C, int H, int W,
+                       int64_t* counts, uaps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAPS_HIP_H */

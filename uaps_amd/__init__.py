@@ -1,0 +1,20 @@
+"""uaps_amd: MI355X-native training step of UAPS (uncertainty-aware, dynamically mixed pseudo-labels).
+
+Public surface (mirrors the names the reference's UAPS_train.py imports):
+  net_factory, UNet_UAPS, UNet                      (utilities/UAPS_net_factory.py, UAPS_unet.py)
+  dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_step_loss   (UAPS_train.py:186-282)
+  sigmoid_rampup, get_current_consistency_weight    (utilities/ramps.py, UAPS_train.py:81-87)
+  FeatureNoise, Dropout, FeatureDropout             (utilities/UAPS_unet.py:156-185)
+  mIoU, mDice, pixel_accuracy, seg_confusion        (utilities/metrics.py)
+  UAPSTrainer                                       (UAPS_train.py:109-450 step/optimizer/checkpoint)
+"""
+from .ramps import sigmoid_rampup, get_current_consistency_weight
+from .losses import dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_step_loss, unsup_scalars, sup_scalars
+from .perturb import FeatureNoise, Dropout, FeatureDropout, manual_seed as perturb_manual_seed
+from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, metrics_from_confusion
+from .unet import UNet, UNet_UAPS
+from .net_factory import net_factory
+from .trainer import UAPSTrainer
+from . import data, dist
+
+__all__ = [n for n in dir() if not n.startswith("_")]

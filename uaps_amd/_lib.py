@@ -1,0 +1,103 @@
+"""ctypes binding of libuaps_hip.so (C ABI: include/uaps_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent, every op that needs it
+raises.  `python -c "import __graft_entry__ as g; g.build()"` (or `make -C uaps_amd/csrc`) builds it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libuaps_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lock = threading.Lock()
+_lib = None
+
+c_float_p = C.POINTER(C.c_float)
+c_void_p = C.c_void_p
+
+# symbol -> (restype, argtypes); mirrors include/uaps_hip.h one to one
+_PTR = C.c_void_p
+SIGNATURES = {
+    "uaps_abi_version": (C.c_int, []),
+    "uaps_error_string": (C.c_char_p, [C.c_int]),
+    "uaps_loss_workspace_bytes": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_size_t)]),
+    "uaps_unsup_fwd": (C.c_int, [_PTR, _PTR] + [C.c_int] * 5 + [C.c_float] * 3 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
+    "uaps_unsup_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_float, C.c_float, _PTR] + [C.c_int] * 5 + [_PTR, _PTR]),
+    "uaps_sup_fwd": (C.c_int, [_PTR, _PTR] + [C.c_int] * 5 + [C.c_float] * 3 + [_PTR, _PTR, C.c_size_t, _PTR]),
+    "uaps_sup_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_float, C.c_float, _PTR] + [C.c_int] * 5 + [_PTR, _PTR]),
+    "uaps_feat_noise": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [C.c_uint64, C.c_uint64, C.c_float, _PTR, _PTR]),
+    "uaps_feat_noise_apply": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_long, _PTR]),
+    "uaps_feat_bernoulli": (C.c_int, [_PTR, _PTR, C.c_long, C.c_uint64, C.c_uint64, C.c_float, _PTR, _PTR]),
+    "uaps_feat_mask_apply": (C.c_int, [_PTR, _PTR, C.c_float, _PTR, C.c_long, _PTR]),
+    "uaps_feat_dropout_workspace_bytes": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_size_t)]),
+    "uaps_feat_dropout_fwd": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [C.c_float, _PTR, _PTR, C.c_size_t, _PTR]),
+    "uaps_feat_dropout_bwd": (C.c_int, [_PTR, _PTR, _PTR] + [C.c_int] * 4 + [_PTR]),
+    "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
+}
+
+
+class UapsHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False, jobs: int = 8) -> str:
+    """Compile every HIP source under uaps_amd/csrc for gfx950 into uaps_amd/lib/libuaps_hip.so."""
+    cmd = ["make", "-C", CSRC, f"-j{jobs}"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise UapsHipError("building libuaps_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library with typed entry points; raises UapsHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise UapsHipError(
+                    f"{LIB_PATH} not found: the UAPS HIP kernels are not built. Run "
+                    "`make -C uaps_amd/csrc` (needs hipcc; cross-compiles for gfx950 without a GPU). "
+                    "uaps_amd has no CPU or PyTorch fallback for these ops.")
+            l = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                try:
+                    fn = getattr(l, name)
+                except AttributeError as e:
+                    raise UapsHipError(f"libuaps_hip.so does not export {name}; rebuild it") from e
+                fn.restype, fn.argtypes = res, args
+            _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().uaps_error_string(rc).decode()
+        raise UapsHipError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (const float* const*)."""
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def current_stream(device=None) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(t, what: str):
+    """The kernels only exist for the GPU: refuse CPU tensors loudly instead of computing elsewhere."""
+    if not t.is_cuda:
+        raise UapsHipError(f"{what}: tensor is on {t.device}; uaps_amd ops run only on a ROCm device "
+                           "(hand-written HIP kernels, no CPU fallback)")

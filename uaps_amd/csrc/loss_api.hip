@@ -1,0 +1,76 @@
+// extern "C" entry points of the loss block (include/uaps_hip.h).
+#include "loss_dispatch.hpp"
+using namespace uaps;
+
+extern "C" int uaps_abi_version(void) { return 1; }
+
+extern "C" const char* uaps_error_string(int code) {
+    switch (code) {
+        case UAPS_OK: return "ok";
+        case UAPS_EINVAL: return "invalid argument (null pointer or non-positive dimension)";
+        case UAPS_ERANGE: return "number of heads or classes outside the supported range (D 1..8, C 2..8)";
+        case UAPS_EWORKSPACE: return "workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+static size_t loss_ws_bytes(int D, int C) {
+    const size_t ns = (size_t)(D + 2 * D * C + C + 2 * D);
+    return (size_t)kMaxBlocks * ns * sizeof(float);
+}
+
+extern "C" int uaps_loss_workspace_bytes(int D, int B, int C, int H, int W, size_t* out) {
+    if (!out) return UAPS_EINVAL;
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    *out = loss_ws_bytes(D, C);
+    return UAPS_OK;
+}
+
+extern "C" int uaps_unsup_fwd(const float* const* logits, const double* w, int D, int B, int C, int H, int W, float cw1,
+                              float cw2, float eps, int64_t* pseudo, float* var, float* scalars, void* ws,
+                              size_t ws_bytes, uaps_stream_t stream) {
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    if (!logits || !w || !pseudo || !scalars || !ws) return UAPS_EINVAL;
+    for (int k = 0; k < D; ++k) if (!logits[k]) return UAPS_EINVAL;
+    if (ws_bytes < loss_ws_bytes(D, C)) return UAPS_EWORKSPACE;
+    LossArgs a{}; a.logits = logits; a.w = w; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W; a.cw1 = cw1; a.cw2 = cw2;
+    a.eps = eps; a.pseudo = pseudo; a.var = var; a.scalars = scalars; a.partials = (float*)ws; a.stream = (hipStream_t)stream;
+    return launch_unsup_fwd(a);
+}
+
+extern "C" int uaps_unsup_bwd(const float* const* logits, const int64_t* pseudo, const float* scalars, float cw1, float cw2,
+                              const float* gscale, int D, int B, int C, int H, int W, float* const* dlogits,
+                              uaps_stream_t stream) {
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    if (!logits || !pseudo || !scalars || !dlogits) return UAPS_EINVAL;
+    for (int k = 0; k < D; ++k) if (!logits[k] || !dlogits[k]) return UAPS_EINVAL;
+    LossArgs a{}; a.logits = logits; a.dlogits = dlogits; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W; a.cw1 = cw1; a.cw2 = cw2;
+    a.labels = pseudo; a.cscalars = scalars; a.gscale = gscale; a.stream = (hipStream_t)stream;
+    return launch_unsup_bwd(a);
+}
+
+extern "C" int uaps_sup_fwd(const float* const* logits, const int64_t* labels, int D, int B, int C, int H, int W, float ce_coef,
+                            float dice_coef, float eps, float* scalars, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    if (!logits || !labels || !scalars || !ws) return UAPS_EINVAL;
+    for (int k = 0; k < D; ++k) if (!logits[k]) return UAPS_EINVAL;
+    if (ws_bytes < loss_ws_bytes(D, C)) return UAPS_EWORKSPACE;
+    LossArgs a{}; a.logits = logits; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W; a.eps = eps; a.labels = labels;
+    a.cw1 = ce_coef; a.cw2 = dice_coef; a.scalars = scalars; a.partials = (float*)ws; a.stream = (hipStream_t)stream;
+    return launch_sup_fwd(a);
+}
+
+extern "C" int uaps_sup_bwd(const float* const* logits, const int64_t* labels, const float* scalars, float ce_coef,
+                            float dice_coef, const float* gscale, int D, int B, int C, int H, int W, float* const* dlogits, uaps_stream_t stream) {
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    if (!logits || !labels || !scalars || !dlogits) return UAPS_EINVAL;
+    for (int k = 0; k < D; ++k) if (!logits[k] || !dlogits[k]) return UAPS_EINVAL;
+    LossArgs a{}; a.logits = logits; a.dlogits = dlogits; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W; a.labels = labels;
+    a.cw1 = ce_coef; a.cw2 = dice_coef; a.cscalars = scalars; a.gscale = gscale; a.stream = (hipStream_t)stream;
+    return launch_sup_bwd(a);
+}

@@ -1,0 +1,471 @@
+// Fused loss-block kernels of the UAPS step for gfx950 (wave64, HBM-bound streaming kernels).
+//
+// One thread owns VEC horizontally adjacent pixels and keeps all D*C logits of each in registers:
+// with the reference's NCHW fp32 logits a (head, class) plane is contiguous over pixels, so a lane
+// reads 16 B (VEC=4) from each of the D*C planes and a wave reads 1 KiB per plane, fully coalesced.
+// The class softmax is therefore register-local (no cross-lane traffic); cross-lane work is only
+// the block reduction of the per-thread partial sums (wave64 DPP/shuffle tree, then LDS across the
+// 4 waves), written as one row of partials per block and reduced in a fixed order by a one-block
+// finalize kernel (double accumulation) -- no float atomics, so results are bitwise reproducible
+// run to run.
+//
+// Reference lines restated: UAPS_train.py:186-189, 194-218, 223-277, 282; pytorch_losses.py:81-89.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uaps {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1024;
+
+template <int D> struct HeadPtrs { const float* p[D]; };
+template <int D> struct HeadOutPtrs { float* p[D]; };
+template <int D> struct HeadWeights { float w[D]; };
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC> __device__ __forceinline__ void load_vec(const float* p, float (&out)[VEC]) {
+    using V = typename VecT<VEC>::type;
+    V v = *reinterpret_cast<const V*>(p);
+    if constexpr (VEC == 1) { out[0] = v; }
+    if constexpr (VEC == 2) { out[0] = v.x; out[1] = v.y; }
+    if constexpr (VEC == 4) { out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+}
+template <int VEC> __device__ __forceinline__ void store_vec(float* p, const float (&in)[VEC]) {
+    using V = typename VecT<VEC>::type;
+    V v;
+    if constexpr (VEC == 1) { v = in[0]; }
+    if constexpr (VEC == 2) { v.x = in[0]; v.y = in[1]; }
+    if constexpr (VEC == 4) { v.x = in[0]; v.y = in[1]; v.z = in[2]; v.w = in[3]; }
+    *reinterpret_cast<V*>(p) = v;
+}
+template <int VEC> __device__ __forceinline__ void load_labels(const int64_t* p, int (&out)[VEC]) {
+    if constexpr (VEC == 1) { out[0] = (int)p[0]; }
+    if constexpr (VEC == 2) { longlong2 v = *reinterpret_cast<const longlong2*>(p); out[0] = (int)v.x; out[1] = (int)v.y; }
+    if constexpr (VEC == 4) {
+        longlong2 a = *reinterpret_cast<const longlong2*>(p), b = *reinterpret_cast<const longlong2*>(p + 2);
+        out[0] = (int)a.x; out[1] = (int)a.y; out[2] = (int)b.x; out[3] = (int)b.y;
+    }
+}
+template <int VEC> __device__ __forceinline__ void store_labels(int64_t* p, const int (&in)[VEC]) {
+    if constexpr (VEC == 1) { p[0] = in[0]; }
+    if constexpr (VEC == 2) { longlong2 v; v.x = in[0]; v.y = in[1]; *reinterpret_cast<longlong2*>(p) = v; }
+    if constexpr (VEC == 4) {
+        longlong2 a, b; a.x = in[0]; a.y = in[1]; b.x = in[2]; b.y = in[3];
+        *reinterpret_cast<longlong2*>(p) = a; *reinterpret_cast<longlong2*>(p + 2) = b;
+    }
+}
+
+// v_exp_f32 / v_log_f32 / v_rcp_f32 based forms: ~1-2 ulp, far inside the 1e-4 parity budget and
+// one quarter-rate instruction each instead of libm's ~15-instruction sequences (these kernels are
+// VALU/HBM co-limited: ~30 transcendentals per pixel at D=C=4).
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float flog(float x) { return __logf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// softmax over C register values: p, log p, all from one max/exp/sum pass.
+template <int C> __device__ __forceinline__ void softmax_regs(const float (&z)[C], float (&p)[C], float (&lp)[C]) {
+    float mx = z[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = fexp(z[c] - mx); s += p[c]; }
+    const float inv = frcp(s), lse = mx + flog(s);
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] *= inv; lp[c] = z[c] - lse; }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block reduction of NS per-thread partial sums into row `blockIdx.x` of `partials` ([gridDim.x][NS]).
+template <int NS> __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], float* partials) {
+    __shared__ float red[kThreads / 64][NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NS; i += kThreads) {
+        float s = red[0][i];
+#pragma unroll
+        for (int w = 1; w < kThreads / 64; ++w) s += red[w][i];
+        partials[(size_t)blockIdx.x * NS + i] = s;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// raw-sum layouts (floats per block row / doubles in the finalize)
+//   unsup: CE[D] | I[D*C] | P[D*C] | cnt[C] | E[D] | V[D]
+//   sup:   CE[D] | I[D*C] | P[D*C] | cnt[C] | bad
+// --------------------------------------------------------------------------------------------------
+template <int D, int C> struct UnsupLayout {
+    static constexpr int CE = 0, I = D, P = D + D * C, CNT = D + 2 * D * C, E = CNT + C, V = E + D, NS = V + D;
+};
+template <int D, int C> struct SupLayout {
+    static constexpr int CE = 0, I = D, P = D + D * C, CNT = D + 2 * D * C, BAD = CNT + C, NS = BAD + 1;
+};
+
+// --------------------------------------------------------------------------------------------------
+// F1: unsupervised forward.  Algorithmic HBM bytes per pixel: 4DC (logits) + 8 (pseudo) + 4D (var).
+// --------------------------------------------------------------------------------------------------
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void unsup_fwd_kernel(HeadPtrs<D> z, HeadWeights<D> w, int HW, long ngroups,
+                                                             long N, int64_t* __restrict__ pseudo,
+                                                             float* __restrict__ var, float* __restrict__ partials) {
+    using L = UnsupLayout<D, C>;
+    float acc[L::NS];
+#pragma unroll
+    for (int i = 0; i < L::NS; ++i) acc[i] = 0.f;
+
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+        const long n0 = g * VEC;
+        const long b = n0 / HW;
+        const long hw = n0 - b * HW;
+        const long base = b * C * (long)HW + hw;
+        float zv[D][C][VEC];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[k][c]);
+
+        int yv[VEC];
+        float varv[D][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float p[D][C], lp[D][C], m[C];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                float zz[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) zz[c] = zv[k][c][v];
+                softmax_regs<C>(zz, p[k], lp[k]);
+            }
+            // mean prediction (UAPS_train.py:223) and the mixture that feeds arg-max (:252-255):
+            // separate multiply and add roundings, left to right, like the reference's tensor ops.
+            float xm = 0.f;
+            int y = 0;
+            float best = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float s = p[0][c];
+                float mix = __fmul_rn(w.w[0], p[0][c]);
+#pragma unroll
+                for (int k = 1; k < D; ++k) { s = __fadd_rn(s, p[k][c]); mix = __fadd_rn(mix, __fmul_rn(w.w[k], p[k][c])); }
+                m[c] = s / (float)D;
+                xm += (m[c] > 0.f) ? m[c] * flog(m[c]) : 0.f;           // xlogy(m, m)
+                if (c == 0 || mix > best) { best = mix; y = c; }          // first maximum wins, as torch.argmax
+            }
+            yv[v] = y;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[L::CNT + c] += (y == c) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                float dot = 0.f, lpy = lp[k][0];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    dot += m[c] * lp[k][c];
+                    acc[L::P + k * C + c] += p[k][c];
+                    acc[L::I + k * C + c] += (y == c) ? p[k][c] : 0.f;
+                    if (c > 0) lpy = (y == c) ? lp[k][c] : lpy;
+                }
+                const float vk = xm - dot;                               // sum_c KL(m || p_k)  (:226)
+                varv[k][v] = vk;
+                acc[L::V + k] += vk;
+                acc[L::E + k] += fexp(-vk);                              // :227
+                acc[L::CE + k] -= lpy;
+            }
+        }
+        store_labels<VEC>(pseudo + n0, yv);
+        if (var != nullptr) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) store_vec<VEC>(var + (long)k * N + n0, varv[k]);
+        }
+    }
+    block_reduce_store<L::NS>(acc, partials);
+}
+
+// --------------------------------------------------------------------------------------------------
+// F3 forward: supervised branch.  Bytes per pixel: 4DC + 8.
+// --------------------------------------------------------------------------------------------------
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void sup_fwd_kernel(HeadPtrs<D> z, int HW, long ngroups,
+                                                           const int64_t* __restrict__ labels,
+                                                           float* __restrict__ partials) {
+    using L = SupLayout<D, C>;
+    float acc[L::NS];
+#pragma unroll
+    for (int i = 0; i < L::NS; ++i) acc[i] = 0.f;
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+        const long n0 = g * VEC;
+        const long b = n0 / HW;
+        const long hw = n0 - b * HW;
+        const long base = b * C * (long)HW + hw;
+        int yv[VEC];
+        load_labels<VEC>(labels + n0, yv);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float zv[C][VEC];
+#pragma unroll
+            for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[c]);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float zz[C], p[C], lp[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) zz[c] = zv[c][v];
+                softmax_regs<C>(zz, p, lp);
+                const int y = yv[v];
+                float lpy = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    acc[L::P + k * C + c] += p[c];
+                    acc[L::I + k * C + c] += (y == c) ? p[c] : 0.f;
+                    lpy = (y == c) ? lp[c] : lpy;
+                }
+                acc[L::CE + k] -= lpy;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int y = yv[v];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[L::CNT + c] += (y == c) ? 1.f : 0.f;
+            acc[L::BAD] += (y < 0 || y >= C) ? 1.f : 0.f;
+        }
+    }
+    block_reduce_store<L::NS>(acc, partials);
+}
+
+// --------------------------------------------------------------------------------------------------
+// finalize: fixed-order double reduction of the block rows, then the scalar losses and the Dice
+// gradient coefficients the backward kernels need.  One block.
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <bool UNSUP>
+__global__ __launch_bounds__(kThreads) void finalize_kernel(const float* __restrict__ partials, int nrows, int D, int C,
+                                                            long N, float cw1, float cw2, float eps,
+                                                            float* __restrict__ out) {
+    __shared__ double tot[4 * UAPS_MAX_HEADS + 2 * UAPS_MAX_HEADS * UAPS_MAX_CLASSES + UAPS_MAX_CLASSES + 1];
+    __shared__ double dice_s[UAPS_MAX_HEADS];
+    const int NS = UNSUP ? (D + 2 * D * C + C + 2 * D) : (D + 2 * D * C + C + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < NS; i += kThreads / 64) {
+        double s = 0.0;
+        for (int r = lane; r < nrows; r += 64) s += (double)partials[(size_t)r * NS + i];
+        s = wave_sum_d(s);
+        if (lane == 0) tot[i] = s;
+    }
+    __syncthreads();
+    const double *CE = tot, *I = tot + D, *P = I + D * C, *cnt = P + D * C;
+    const int oA1 = UNSUP ? UAPS_U_A1(D, C) : UAPS_S_A1(D, C);
+    const int oA2 = UNSUP ? UAPS_U_A2(D, C) : UAPS_S_A2(D, C);
+    const int oI = UNSUP ? UAPS_U_I(D, C) : UAPS_S_I(D, C);
+    const int oCard = UNSUP ? UAPS_U_CARD(D, C) : UAPS_S_CARD(D, C);
+    const int oCnt = UNSUP ? UAPS_U_CNT(D, C) : UAPS_S_CNT(D, C);
+    if ((int)threadIdx.x < D * C) {
+        const int t = threadIdx.x, c = t % C;
+        const double card = P[t] + cnt[c];
+        const double den = card + (double)eps;
+        out[oA1 + t] = (float)(-(2.0 / C) / den);
+        out[oA2 + t] = (float)((2.0 / C) * I[t] / (den * den));
+        out[oI + t] = (float)I[t];
+        out[oCard + t] = (float)card;
+    }
+    if ((int)threadIdx.x < C) out[oCnt + threadIdx.x] = (float)cnt[threadIdx.x];
+    if ((int)threadIdx.x < D) {
+        const int k = threadIdx.x;
+        double ds = 0.0;
+        for (int c = 0; c < C; ++c) ds += 2.0 * I[k * C + c] / (P[k * C + c] + cnt[c] + (double)eps);
+        dice_s[k] = 1.0 - ds / C;                                   // pytorch_losses.py:88-89
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (UNSUP) {
+            const double *E = cnt + C, *V = E + D;
+            double ps = 0.0, lu = 0.0;
+            for (int k = 0; k < D; ++k) {
+                const double ce = CE[k] / (double)N, s = 0.5 * (ce + dice_s[k]), Em = E[k] / (double)N;
+                out[UAPS_U_CE(D, C) + k] = (float)ce;
+                out[UAPS_U_DICE(D, C) + k] = (float)dice_s[k];
+                out[UAPS_U_S(D, C) + k] = (float)s;
+                out[UAPS_U_E(D, C) + k] = (float)Em;
+                ps += s * Em;                                       // UAPS_train.py:265-268
+                lu += V[k];
+            }
+            ps /= D;                                                // :277
+            lu /= ((double)N * D);                                  // :241-243
+            out[UAPS_U_PS(D, C)] = (float)ps;
+            out[UAPS_U_LUN(D, C)] = (float)lu;
+            out[UAPS_U_LOSS(D, C)] = (float)((double)cw1 * ps + (double)cw2 * lu);
+            out[UAPS_U_LOSS(D, C) + 1] = 0.f;
+        } else {
+            double sup = 0.0;
+            for (int k = 0; k < D; ++k) {
+                const double ce = CE[k] / (double)N;
+                out[UAPS_S_CE(D, C) + k] = (float)ce;
+                out[UAPS_S_DICE(D, C) + k] = (float)dice_s[k];
+                sup += (double)cw1 * ce + (double)cw2 * dice_s[k];  // UAPS_train.py:208-211 with cw1 = cw2 = 0.5/D
+            }
+            out[UAPS_S_SUP(D, C)] = (float)sup;                     // :218
+            out[UAPS_S_BAD(D, C)] = (float)cnt[C];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// F2: unsupervised backward.  Bytes per pixel: 4DC + 8 read, 4DC written.
+// --------------------------------------------------------------------------------------------------
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, HeadOutPtrs<D> dz, int HW, long ngroups, long N,
+                                                             const int64_t* __restrict__ pseudo,
+                                                             const float* __restrict__ sc, float cw1, float cw2,
+                                                             const float* __restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    const float invN = 1.f / (float)N;
+    // per-head constants: coefficient of exp(-v_k) in g_k, and of the (CE + Dice) term
+    float ge[D], cs[D];
+    const float gu = gs * cw2 * invN / (float)D;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        ge[k] = gs * (cw1 / (float)D) * sc[UAPS_U_S(D, C) + k] * invN;
+        cs[k] = gs * (cw1 / (float)D) * sc[UAPS_U_E(D, C) + k] * 0.5f;
+    }
+    const float* __restrict__ A1 = sc + UAPS_U_A1(D, C);
+    const float* __restrict__ A2 = sc + UAPS_U_A2(D, C);
+
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+        const long n0 = g * VEC;
+        const long b = n0 / HW;
+        const long hw = n0 - b * HW;
+        const long base = b * C * (long)HW + hw;
+        float zv[D][C][VEC];
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[k][c]);
+        int yv[VEC];
+        load_labels<VEC>(pseudo + n0, yv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float p[D][C], lp[D][C], m[C], lm1[C], gk[D], h[C];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                float zz[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) zz[c] = zv[k][c][v];
+                softmax_regs<C>(zz, p[k], lp[k]);
+            }
+            float xm = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float s = p[0][c];
+#pragma unroll
+                for (int k = 1; k < D; ++k) s = __fadd_rn(s, p[k][c]);
+                m[c] = s / (float)D;
+                const float lm = (m[c] > 0.f) ? flog(m[c]) : 0.f;
+                xm += m[c] * lm;
+                lm1[c] = (m[c] > 0.f) ? lm + 1.f : 0.f;       // d xlogy(m,m)/dm, 0 at m == 0 (limit; reference NaNs)
+                h[c] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                float dot = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) dot += m[c] * lp[k][c];
+                gk[k] = gu - ge[k] * fexp(dot - xm);            // dL/dv_k ; exp(-v_k) = exp(dot - xm)
+#pragma unroll
+                for (int c = 0; c < C; ++c) h[c] += (m[c] > 0.f) ? gk[k] * (lm1[c] - lp[k][c]) : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) h[c] *= (1.f / (float)D);
+            const int y = yv[v];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float a[C], pa = 0.f, ph = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    a[c] = ((y == c) ? A1[j * C + c] : 0.f) + A2[j * C + c];
+                    pa += p[j][c] * a[c];
+                    ph += p[j][c] * h[c];
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float oh = (y == c) ? 1.f : 0.f;
+                    const float gr = cs[j] * ((p[j][c] - oh) * invN + p[j][c] * (a[c] - pa))
+                                   - gk[j] * (m[c] - p[j][c])
+                                   + p[j][c] * (h[c] - ph);
+                    zv[j][c][v] = gr;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) store_vec<VEC>(dz.p[k] + base + (long)c * HW, zv[k][c]);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// F3 backward.  Bytes per pixel: 4DC + 8 read, 4DC written.
+// --------------------------------------------------------------------------------------------------
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void sup_bwd_kernel(HeadPtrs<D> z, HeadOutPtrs<D> dz, int HW, long ngroups, long N,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ sc, float ce_coef,
+                                                           float dice_coef, const float* __restrict__ gscale) {
+    const float gs0 = gscale ? gscale[0] : 1.f;
+    const float gce = gs0 * ce_coef / (float)N, gdc = gs0 * dice_coef;
+    const float* __restrict__ A1 = sc + UAPS_S_A1(D, C);
+    const float* __restrict__ A2 = sc + UAPS_S_A2(D, C);
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+        const long n0 = g * VEC;
+        const long b = n0 / HW;
+        const long hw = n0 - b * HW;
+        const long base = b * C * (long)HW + hw;
+        int yv[VEC];
+        load_labels<VEC>(labels + n0, yv);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float zv[C][VEC];
+#pragma unroll
+            for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[c]);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float zz[C], p[C], lp[C], a[C], pa = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) zz[c] = zv[c][v];
+                softmax_regs<C>(zz, p, lp);
+                const int y = yv[v];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    a[c] = ((y == c) ? A1[k * C + c] : 0.f) + A2[k * C + c];
+                    pa += p[c] * a[c];
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float oh = (y == c) ? 1.f : 0.f;
+                    zv[c][v] = gce * (p[c] - oh) + gdc * p[c] * (a[c] - pa);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) store_vec<VEC>(dz.p[k] + base + (long)c * HW, zv[c]);
+        }
+    }
+}
+
+}  // namespace uaps

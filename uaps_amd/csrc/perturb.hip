@@ -1,0 +1,274 @@
+// Feature perturbations of the auxiliary decoders (utilities/UAPS_unet.py:156-185) and the
+// confusion-matrix metric kernel (utilities/metrics.py:8-61) for gfx950.
+// All of these are pure streaming kernels: 16 B per lane, grid-stride, HBM-bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/uaps_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 2048;
+
+inline int grid_for(long work) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Philox4x32-10 (Salmon et al., SC'11), counter-based: stateless, so forward and backward regenerate
+// the same draw from (seed, counter) instead of storing masks.
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(uint64_t ctr, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x55415053u /* "UAPS" */, c3 = 0;
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }   // [0,1)
+
+// ---- FeatureNoise: y[b,e] = x[b,e] * n[e] + x[b,e], n ~ U(-range, range), e over C*H*W ------------
+__global__ __launch_bounds__(kThreads) void noise_rng_vec4(const float4* __restrict__ x, float4* __restrict__ y, int B,
+                                                           long chw4, uint64_t seed, uint64_t offset, float range,
+                                                           float4* __restrict__ noise_out) {
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < chw4; e += (long)gridDim.x * kThreads) {
+        const U4 r = philox4x32_10(offset + (uint64_t)e, seed);
+        float4 n;
+        n.x = (2.f * u01(r.x) - 1.f) * range; n.y = (2.f * u01(r.y) - 1.f) * range;
+        n.z = (2.f * u01(r.z) - 1.f) * range; n.w = (2.f * u01(r.w) - 1.f) * range;
+        if (noise_out) noise_out[e] = n;
+        for (int b = 0; b < B; ++b) {
+            const float4 v = x[(long)b * chw4 + e];
+            float4 o;   // x.mul(noise) + x : separate roundings as in UAPS_unet.py:180
+            o.x = __fadd_rn(__fmul_rn(v.x, n.x), v.x); o.y = __fadd_rn(__fmul_rn(v.y, n.y), v.y);
+            o.z = __fadd_rn(__fmul_rn(v.z, n.z), v.z); o.w = __fadd_rn(__fmul_rn(v.w, n.w), v.w);
+            y[(long)b * chw4 + e] = o;
+        }
+    }
+}
+__global__ __launch_bounds__(kThreads) void noise_rng_scalar(const float* __restrict__ x, float* __restrict__ y, int B, long chw,
+                                                             uint64_t seed, uint64_t offset, float range,
+                                                             float* __restrict__ noise_out) {
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < chw; e += (long)gridDim.x * kThreads) {
+        const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
+        const uint32_t rr = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+        const float n = (2.f * u01(rr) - 1.f) * range;
+        if (noise_out) noise_out[e] = n;
+        for (int b = 0; b < B; ++b) { const float v = x[(long)b * chw + e]; y[(long)b * chw + e] = __fadd_rn(__fmul_rn(v, n), v); }
+    }
+}
+__global__ __launch_bounds__(kThreads) void noise_apply_vec4(const float4* __restrict__ x, const float4* __restrict__ noise,
+                                                             float4* __restrict__ y, int B, long chw4) {
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < chw4; e += (long)gridDim.x * kThreads) {
+        const float4 n = noise[e];
+        for (int b = 0; b < B; ++b) {
+            const float4 v = x[(long)b * chw4 + e];
+            float4 o;
+            o.x = __fadd_rn(__fmul_rn(v.x, n.x), v.x); o.y = __fadd_rn(__fmul_rn(v.y, n.y), v.y);
+            o.z = __fadd_rn(__fmul_rn(v.z, n.z), v.z); o.w = __fadd_rn(__fmul_rn(v.w, n.w), v.w);
+            y[(long)b * chw4 + e] = o;
+        }
+    }
+}
+__global__ __launch_bounds__(kThreads) void noise_apply_scalar(const float* __restrict__ x, const float* __restrict__ noise,
+                                                               float* __restrict__ y, int B, long chw) {
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < chw; e += (long)gridDim.x * kThreads) {
+        const float n = noise[e];
+        for (int b = 0; b < B; ++b) { const float v = x[(long)b * chw + e]; y[(long)b * chw + e] = __fadd_rn(__fmul_rn(v, n), v); }
+    }
+}
+
+// ---- Dropout(x, p): y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) ------------------------------------
+__global__ __launch_bounds__(kThreads) void bernoulli_vec4(const float4* __restrict__ x, float4* __restrict__ y, long n4,
+                                                           uint64_t seed, uint64_t offset, float p, float scale,
+                                                           uchar4* __restrict__ keep_out) {
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < n4; e += (long)gridDim.x * kThreads) {
+        const U4 r = philox4x32_10(offset + (uint64_t)e, seed);
+        const float4 v = x[e];
+        const bool k0 = u01(r.x) >= p, k1 = u01(r.y) >= p, k2 = u01(r.z) >= p, k3 = u01(r.w) >= p;
+        float4 o;
+        o.x = k0 ? v.x * scale : 0.f; o.y = k1 ? v.y * scale : 0.f; o.z = k2 ? v.z * scale : 0.f; o.w = k3 ? v.w * scale : 0.f;
+        y[e] = o;
+        if (keep_out) keep_out[e] = make_uchar4(k0, k1, k2, k3);
+    }
+}
+__global__ __launch_bounds__(kThreads) void bernoulli_scalar(const float* __restrict__ x, float* __restrict__ y, long start, long n,
+                                                             uint64_t seed, uint64_t offset, float p, float scale,
+                                                             uint8_t* __restrict__ keep_out) {
+    for (long e = start + (long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long)gridDim.x * kThreads) {
+        const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
+        const uint32_t rr = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+        const bool k = u01(rr) >= p;
+        y[e] = k ? x[e] * scale : 0.f;
+        if (keep_out) keep_out[e] = k;
+    }
+}
+__global__ __launch_bounds__(kThreads) void mask_apply_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep,
+                                                              float scale, float* __restrict__ y, long n) {
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < n; e += (long)gridDim.x * kThreads)
+        y[e] = keep[e] ? x[e] * scale : 0.f;
+}
+
+// ---- FeatureDropout ----------------------------------------------------------------------------------
+// order-preserving float -> uint key so that an integer atomicMax gives a deterministic float max
+__device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// pass A: att[b,hw] = (sum_c x[b,c,hw]) / C, per-sample max via wave reduce + one atomicMax per wave
+__global__ __launch_bounds__(kThreads) void fdrop_attention(const float* __restrict__ x, int C, long HW, float* __restrict__ att,
+                                                            uint32_t* __restrict__ maxkey) {
+    const int b = blockIdx.y;
+    const float* xb = x + (long)b * C * HW;
+    uint32_t best = 0;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
+        float s = xb[i];
+        for (int c = 1; c < C; ++c) s = __fadd_rn(s, xb[(long)c * HW + i]);
+        const float a = s / (float)C;
+        att[(long)b * HW + i] = a;
+        const uint32_t k = fkey(a);
+        best = k > best ? k : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t > best ? t : best; }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(maxkey + b, best);
+}
+// pass B: keep = att < max * u ; y = x * keep
+__global__ __launch_bounds__(kThreads) void fdrop_apply(const float* __restrict__ x, float* __restrict__ y, int C, long HW,
+                                                        const float* __restrict__ att, const uint32_t* __restrict__ maxkey,
+                                                        float u, uint8_t* __restrict__ keep) {
+    const int b = blockIdx.y;
+    const float thr = __fmul_rn(fkey_inv(maxkey[b]), u);
+    const float* xb = x + (long)b * C * HW;
+    float* yb = y + (long)b * C * HW;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
+        const bool k = att[(long)b * HW + i] < thr;
+        keep[(long)b * HW + i] = k;
+        for (int c = 0; c < C; ++c) yb[(long)c * HW + i] = k ? xb[(long)c * HW + i] : 0.f;
+    }
+}
+__global__ __launch_bounds__(kThreads) void fdrop_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
+                                                      float* __restrict__ dx, int C, long HW) {
+    const int b = blockIdx.y;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
+        const bool k = keep[(long)b * HW + i];
+        for (int c = 0; c < C; ++c) { const long o = ((long)b * C + c) * HW + i; dx[o] = k ? dy[o] : 0.f; }
+    }
+}
+
+// ---- confusion matrix ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void confusion_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels, int C,
+                                                             long HW, long N, unsigned long long* __restrict__ counts) {
+    __shared__ unsigned int local[UAPS_MAX_CLASSES * UAPS_MAX_CLASSES];
+    for (int i = threadIdx.x; i < C * C; i += kThreads) local[i] = 0;
+    __syncthreads();
+    for (long n = (long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long)gridDim.x * kThreads) {
+        const long b = n / HW, hw = n - b * HW;
+        const float* p = z + b * C * HW + hw;
+        float best = p[0]; int arg = 0;
+        for (int c = 1; c < C; ++c) { const float v = p[(long)c * HW]; if (v > best) { best = v; arg = c; } }
+        const long y = labels[n];
+        if (y >= 0 && y < C) atomicAdd(&local[(int)y * C + arg], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += kThreads) if (local[i]) atomicAdd(counts + i, (unsigned long long)local[i]);
+}
+
+}  // namespace
+
+extern "C" int uaps_feat_noise(const float* x, float* y, int B, int C, int H, int W, uint64_t seed, uint64_t offset,
+                               float range, float* noise_out, uaps_stream_t stream) {
+    if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    const long chw = (long)C * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if (chw % 4 == 0 && al16(x) && al16(y) && (!noise_out || al16(noise_out)))
+        hipLaunchKernelGGL(noise_rng_vec4, dim3(grid_for(chw / 4)), dim3(kThreads), 0, s, (const float4*)x, (float4*)y, B, chw / 4, seed, offset, range, (float4*)noise_out);
+    else
+        hipLaunchKernelGGL(noise_rng_scalar, dim3(grid_for(chw)), dim3(kThreads), 0, s, x, y, B, chw, seed, offset, range, noise_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_feat_noise_apply(const float* x, const float* noise, float* y, int B, long chw, uaps_stream_t stream) {
+    if (!x || !y || !noise || B <= 0 || chw <= 0) return UAPS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (chw % 4 == 0 && al16(x) && al16(y) && al16(noise))
+        hipLaunchKernelGGL(noise_apply_vec4, dim3(grid_for(chw / 4)), dim3(kThreads), 0, s, (const float4*)x, (const float4*)noise, (float4*)y, B, chw / 4);
+    else
+        hipLaunchKernelGGL(noise_apply_scalar, dim3(grid_for(chw)), dim3(kThreads), 0, s, x, noise, y, B, chw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_feat_bernoulli(const float* x, float* y, long n, uint64_t seed, uint64_t offset, float p,
+                                   uint8_t* keep_out, uaps_stream_t stream) {
+    if (!x || !y || n <= 0 || !(p >= 0.f && p < 1.f)) return UAPS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const float scale = 1.f / (1.f - p);
+    long done = 0;
+    if (al16(x) && al16(y) && (!keep_out || (reinterpret_cast<uintptr_t>(keep_out) & 3) == 0) && n >= 4) {
+        const long n4 = n / 4;
+        hipLaunchKernelGGL(bernoulli_vec4, dim3(grid_for(n4)), dim3(kThreads), 0, s, (const float4*)x, (float4*)y, n4, seed, offset, p, scale, (uchar4*)keep_out);
+        done = n4 * 4;
+    }
+    if (done < n)
+        hipLaunchKernelGGL(bernoulli_scalar, dim3(grid_for(n - done)), dim3(kThreads), 0, s, x, y, done, n, seed, offset, p, scale, keep_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_feat_mask_apply(const float* x, const uint8_t* keep, float scale, float* y, long n, uaps_stream_t stream) {
+    if (!x || !y || !keep || n <= 0) return UAPS_EINVAL;
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(grid_for(n)), dim3(kThreads), 0, (hipStream_t)stream, x, keep, scale, y, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_feat_dropout_workspace_bytes(int B, int C, int H, int W, size_t* out) {
+    if (!out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    *out = (((size_t)B * 4 + 255) / 256) * 256 + (size_t)B * H * W * 4;
+    return UAPS_OK;
+}
+
+extern "C" int uaps_feat_dropout_fwd(const float* x, float* y, int B, int C, int H, int W, float u, uint8_t* keep,
+                                     void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    if (!x || !y || !keep || !ws || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    size_t need; uaps_feat_dropout_workspace_bytes(B, C, H, W, &need);
+    if (ws_bytes < need) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    uint32_t* maxkey = (uint32_t*)ws;
+    float* att = (float*)((char*)ws + (((size_t)B * 4 + 255) / 256) * 256);
+    hipError_t e = hipMemsetAsync(maxkey, 0, (size_t)B * 4, s);
+    if (e != hipSuccess) return (int)e;
+    int gx = grid_for(HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
+    hipLaunchKernelGGL(fdrop_attention, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
+    hipLaunchKernelGGL(fdrop_apply, dim3(gx, B), dim3(kThreads), 0, s, x, y, C, HW, att, maxkey, u, keep);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int B, int C, int H, int W,
+                                     uaps_stream_t stream) {
+    if (!dy || !dx || !keep || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    int gx = grid_for(HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
+    hipLaunchKernelGGL(fdrop_bwd, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_seg_confusion(const float* logits, const int64_t* labels, int B, int C, int H, int W, int64_t* counts,
+                                  uaps_stream_t stream) {
+    if (!logits || !labels || !counts || B <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (C < 1 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W, N = (long)B * HW;
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int64_t) * C * C, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(N) > 512 ? 512 : grid_for(N)), dim3(kThreads), 0, s, logits, labels, C, HW, N,
+                       (unsigned long long*)counts);
+    return (int)hipGetLastError();
+}

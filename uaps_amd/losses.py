@@ -1,0 +1,255 @@
+"""Host side of the fused UAPS loss block (HIP kernels in csrc/loss_*.hip, C ABI include/uaps_hip.h).
+
+Mirrors what the reference step computes between the model forward and `loss.backward()`
+(UAPS_train.py:186-282) and the helper it calls (utilities/pytorch_losses.py:54-89 `dice_loss`).
+Every function here launches hand-written kernels on the current HIP stream; nothing falls back to
+PyTorch ops or to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_HEADS, MAX_CLASSES = 8, 8
+
+
+# ---- offsets into the `scalars` outputs (include/uaps_hip.h) ----------------------------------
+def _u_off(D, C):
+    b = 4 * D + 4
+    return {"ce": 0, "dice": D, "s": 2 * D, "E": 3 * D, "ps_loss": 4 * D, "l_uncert": 4 * D + 1, "loss": 4 * D + 2,
+            "a1": b, "a2": b + D * C, "I": b + 2 * D * C, "card": b + 3 * D * C, "cnt": b + 4 * D * C,
+            "n": b + 4 * D * C + C}
+
+
+def _s_off(D, C):
+    b = 2 * D + 2
+    return {"ce": 0, "dice": D, "sup": 2 * D, "bad": 2 * D + 1, "a1": b, "a2": b + D * C, "I": b + 2 * D * C,
+            "card": b + 3 * D * C, "cnt": b + 4 * D * C, "n": b + 4 * D * C + C}
+
+
+_ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+
+# bench.py sets this to a dict {kernel name: [(start_event, end_event), ...]} to time individual
+# launches with HIP events on the stream they run on; None (the default) records nothing.
+KERNEL_EVENTS: Optional[Dict[str, list]] = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if KERNEL_EVENTS is not None:
+            self.e.record()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Per (device, stream) scratch for the block partial sums; grown on demand, never shrunk."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _lib.current_stream(device))
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _check_heads(logits: Sequence[torch.Tensor], what: str):
+    D = len(logits)
+    if not 1 <= D <= MAX_HEADS:
+        raise ValueError(f"{what}: {D} heads, supported 1..{MAX_HEADS}")
+    z0 = logits[0]
+    _lib.require_device(z0, what)
+    if z0.dim() != 4:
+        raise ValueError(f"{what}: logits must be [B,C,H,W], got {tuple(z0.shape)}")
+    B, Cc, H, W = z0.shape
+    if not 2 <= Cc <= MAX_CLASSES:
+        raise ValueError(f"{what}: {Cc} classes, supported 2..{MAX_CLASSES}")
+    out = []
+    for z in logits:
+        if z.shape != z0.shape or z.device != z0.device:
+            raise ValueError(f"{what}: all heads must share shape and device")
+        if z.dtype != torch.float32:
+            raise TypeError(f"{what}: logits must be float32 (the reference computes the loss in fp32), got {z.dtype}")
+        out.append(z.contiguous())
+    return out, D, B, Cc, H, W
+
+
+class UnsupOut(NamedTuple):
+    loss: torch.Tensor          # cw1 * ps_loss + cw2 * l_uncert   (differentiable, 0-dim)
+    pseudo: torch.Tensor        # int64 [B,H,W]
+    var: Optional[torch.Tensor]  # fp32 [D,B,H,W] KL(mean || p_k), None if not requested
+    scalars: torch.Tensor       # fp32 vector, see scalar_views()
+
+
+class _UnsupLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, cw1, cw2, eps, want_var, *logits):
+        zs, D, B, Cc, H, W = _check_heads(logits, "uaps_unsup_loss")
+        dev = zs[0].device
+        L = _lib.lib()
+        off = _u_off(D, Cc)
+        need = C.c_size_t()
+        _lib.check(L.uaps_loss_workspace_bytes(D, B, Cc, H, W, C.byref(need)), "uaps_loss_workspace_bytes")
+        ws = _workspace(dev, need.value)
+        pseudo = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        var = torch.empty((D, B, H, W), dtype=torch.float32, device=dev) if want_var else None
+        scalars = torch.empty(off["n"], dtype=torch.float32, device=dev)
+        w64 = (C.c_double * D)(*[float(x) for x in w])
+        with torch.cuda.device(dev), _timed("uaps_unsup_fwd"):
+            rc = L.uaps_unsup_fwd(_lib.ptr_array(zs), w64, D, B, Cc, H, W, float(cw1), float(cw2), float(eps),
+                                  pseudo.data_ptr(), var.data_ptr() if want_var else None, scalars.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_unsup_fwd")
+        ctx.save_for_backward(pseudo, scalars, *zs)
+        ctx.meta = (D, B, Cc, H, W, float(cw1), float(cw2))
+        loss = scalars[off["loss"]].clone()
+        ctx.mark_non_differentiable(pseudo, scalars)
+        if want_var:
+            ctx.mark_non_differentiable(var)
+            return loss, pseudo, var, scalars
+        return loss, pseudo, scalars
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        pseudo, scalars, *zs = ctx.saved_tensors
+        D, B, Cc, H, W, cw1, cw2 = ctx.meta
+        dev = zs[0].device
+        g = g_loss.contiguous().to(torch.float32)
+        dz = [torch.empty_like(z) for z in zs]
+        with torch.cuda.device(dev), _timed("uaps_unsup_bwd"):
+            rc = _lib.lib().uaps_unsup_bwd(_lib.ptr_array(zs), pseudo.data_ptr(), scalars.data_ptr(), cw1, cw2,
+                                           g.data_ptr(), D, B, Cc, H, W, _lib.ptr_array(dz), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_unsup_bwd")
+        return (None, None, None, None, None) + tuple(dz)
+
+
+def uaps_unsup_loss(un_logits: Sequence[torch.Tensor], w, cw1: float, cw2: float, eps: float = 1e-7,
+                    return_var: bool = False) -> UnsupOut:
+    """Unsupervised branch of the step, UAPS_train.py:186-189 + 223-282, as two kernel launches.
+
+    un_logits : the D decoder outputs on the unlabelled batch, main head first (UAPS_unet.py:233)
+    w         : D mixing weights, e.g. np.random.dirichlet(np.ones(D)) (UAPS_train.py:251)
+    cw1, cw2  : consistency weights (UAPS_train.py:279-280)
+    Returns loss = cw1*ps_loss + cw2*l_uncert (differentiable w.r.t. every head), the arg-max
+    pseudo-label, optionally the D uncertainty maps, and the scalar block (see unsup_scalars()).
+    """
+    if len(w) != len(un_logits):
+        raise ValueError("one mixing weight per head")
+    out = _UnsupLoss.apply(tuple(float(x) for x in w), cw1, cw2, eps, bool(return_var), *un_logits)
+    if return_var:
+        return UnsupOut(out[0], out[1], out[2], out[3])
+    return UnsupOut(out[0], out[1], None, out[2])
+
+
+def unsup_scalars(scalars: torch.Tensor, D: int, C_: int) -> Dict[str, torch.Tensor]:
+    """Named views into the unsupervised scalar block (no copies, no sync)."""
+    o = _u_off(D, C_)
+    return {"ce": scalars[o["ce"]:o["ce"] + D], "dice": scalars[o["dice"]:o["dice"] + D], "s": scalars[o["s"]:o["s"] + D],
+            "E": scalars[o["E"]:o["E"] + D], "ps_loss": scalars[o["ps_loss"]], "l_uncert": scalars[o["l_uncert"]],
+            "loss": scalars[o["loss"]], "I": scalars[o["I"]:o["I"] + D * C_].view(D, C_),
+            "card": scalars[o["card"]:o["card"] + D * C_].view(D, C_), "cnt": scalars[o["cnt"]:o["cnt"] + C_]}
+
+
+class SupOut(NamedTuple):
+    loss: torch.Tensor      # sum_k ce_coef*CE_k + dice_coef*Dice_k (differentiable, 0-dim)
+    scalars: torch.Tensor
+
+
+class _SupLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, labels, ce_coef, dice_coef, eps, *logits):
+        zs, D, B, Cc, H, W = _check_heads(logits, "uaps_sup_loss")
+        dev = zs[0].device
+        if labels.shape != (B, H, W):
+            raise ValueError(f"labels must be [B,H,W]={B, H, W}, got {tuple(labels.shape)}")
+        if labels.device != dev:
+            raise ValueError("labels and logits on different devices")
+        y = labels.to(torch.int64).contiguous()
+        L = _lib.lib()
+        off = _s_off(D, Cc)
+        need = C.c_size_t()
+        _lib.check(L.uaps_loss_workspace_bytes(D, B, Cc, H, W, C.byref(need)), "uaps_loss_workspace_bytes")
+        ws = _workspace(dev, need.value)
+        scalars = torch.empty(off["n"], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _timed("uaps_sup_fwd"):
+            rc = L.uaps_sup_fwd(_lib.ptr_array(zs), y.data_ptr(), D, B, Cc, H, W, float(ce_coef), float(dice_coef),
+                                float(eps), scalars.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_sup_fwd")
+        ctx.save_for_backward(y, scalars, *zs)
+        ctx.meta = (D, B, Cc, H, W, float(ce_coef), float(dice_coef))
+        ctx.mark_non_differentiable(scalars)
+        return scalars[off["sup"]].clone(), scalars
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_scalars):
+        y, scalars, *zs = ctx.saved_tensors
+        D, B, Cc, H, W, ce_coef, dice_coef = ctx.meta
+        dev = zs[0].device
+        g = g_loss.contiguous().to(torch.float32)
+        dz = [torch.empty_like(z) for z in zs]
+        with torch.cuda.device(dev), _timed("uaps_sup_bwd"):
+            rc = _lib.lib().uaps_sup_bwd(_lib.ptr_array(zs), y.data_ptr(), scalars.data_ptr(), ce_coef, dice_coef,
+                                         g.data_ptr(), D, B, Cc, H, W, _lib.ptr_array(dz), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_sup_bwd")
+        return (None, None, None, None) + tuple(dz)
+
+
+def uaps_sup_loss(lab_logits: Sequence[torch.Tensor], labels: torch.Tensor, eps: float = 1e-7) -> SupOut:
+    """supervised_loss of UAPS_train.py:194-218: mean over heads of 0.5 (CrossEntropy + dice_loss)."""
+    D = len(lab_logits)
+    loss, scalars = _SupLoss.apply(labels, 0.5 / D, 0.5 / D, eps, *lab_logits)
+    return SupOut(loss, scalars)
+
+
+def sup_scalars(scalars: torch.Tensor, D: int, C_: int) -> Dict[str, torch.Tensor]:
+    o = _s_off(D, C_)
+    return {"ce": scalars[o["ce"]:o["ce"] + D], "dice": scalars[o["dice"]:o["dice"] + D], "sup": scalars[o["sup"]],
+            "bad_labels": scalars[o["bad"]], "I": scalars[o["I"]:o["I"] + D * C_].view(D, C_),
+            "card": scalars[o["card"]:o["card"] + D * C_].view(D, C_), "cnt": scalars[o["cnt"]:o["cnt"] + C_]}
+
+
+# ---- the reference's own call signatures --------------------------------------------------------
+
+def dice_loss(true: torch.Tensor, logits: torch.Tensor, eps: float = 1e-7) -> torch.Tensor:
+    """Drop-in for utilities/pytorch_losses.py:54-89 `dice_loss(true[B,1,H,W], logits[B,C,H,W], eps)`
+    (multi-class branch, C >= 2; sums over batch and space, mean over classes)."""
+    if true.dim() != 4 or true.shape[1] != 1:
+        raise ValueError(f"true must be [B,1,H,W], got {tuple(true.shape)}")
+    loss, _ = _SupLoss.apply(true[:, 0], 0.0, 1.0, eps, logits)
+    return loss
+
+
+def ce_loss(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """nn.CrossEntropyLoss()(logits[B,C,H,W], target[B,H,W]) as used at UAPS_train.py:194-197, 259-262."""
+    loss, _ = _SupLoss.apply(target, 1.0, 0.0, 1e-7, logits)
+    return loss
+
+
+class StepLoss(NamedTuple):
+    loss: torch.Tensor
+    sup: torch.Tensor
+    unsup: torch.Tensor
+    pseudo: torch.Tensor
+    var: Optional[torch.Tensor]
+    sup_scalars: torch.Tensor
+    unsup_scalars: torch.Tensor
+
+
+def uaps_step_loss(lab_logits, labels, un_logits, w, cw1, cw2, eps=1e-7, return_var=False) -> StepLoss:
+    """loss = supervised_loss + cw1*ps_loss + cw2*l_uncert  (UAPS_train.py:282)."""
+    s = uaps_sup_loss(lab_logits, labels, eps)
+    u = uaps_unsup_loss(un_logits, w, cw1, cw2, eps, return_var)
+    return StepLoss(s.loss + u.loss, s.loss, u.loss, u.pseudo, u.var, s.scalars, u.scalars)

@@ -1,0 +1,251 @@
+"""Feature perturbations of the three auxiliary decoders (reference utilities/UAPS_unet.py:156-185),
+as HIP kernels with a counter-based on-device RNG (csrc/perturb.hip).
+
+Names and call forms follow the reference: `FeatureNoise()(x)`, `Dropout(x)`, `FeatureDropout(x)`.
+The reference draws FeatureNoise / Dropout from the torch CPU/GPU generators and the FeatureDropout
+threshold from numpy's global RNG; here noise and keep-masks come from Philox4x32-10 keyed by
+`manual_seed()` (+ rank), regenerated in the backward instead of stored, and the FeatureDropout
+threshold still comes from numpy's global RNG (a host scalar, as in the reference).  The `*_with`
+forms take recorded draws, for parity tests against the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _RngState:
+    """(seed, running Philox counter offset).  One per process; ranks use different seeds."""
+    seed = 0x5EED_0A95
+    offset = 0
+
+    @classmethod
+    def reserve(cls, n_elements: int) -> Tuple[int, int]:
+        off = cls.offset
+        cls.offset += (n_elements + 3) // 4 + 1
+        return cls.seed, off
+
+
+def manual_seed(seed: int, rank: int = 0) -> None:
+    _RngState.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
+    _RngState.offset = 0
+
+
+def get_rng_state() -> Tuple[int, int]:
+    return _RngState.seed, _RngState.offset
+
+
+def set_rng_state(state: Tuple[int, int]) -> None:
+    _RngState.seed, _RngState.offset = int(state[0]), int(state[1])
+
+
+def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
+    _lib.require_device(x, what)
+    if x.dtype != torch.float32:
+        raise TypeError(f"{what}: float32 features expected, got {x.dtype}")
+    if x.dim() != 4:
+        raise ValueError(f"{what}: [B,C,H,W] expected, got {tuple(x.shape)}")
+    return x.contiguous()
+
+
+# ---- FeatureNoise -------------------------------------------------------------------------------
+
+class _NoiseRng(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seed, offset, rng, want_noise):
+        x = _prep(x, "FeatureNoise")
+        B, Cc, H, W = x.shape
+        y = torch.empty_like(x)
+        noise = torch.empty((Cc, H, W), dtype=torch.float32, device=x.device) if want_noise else None
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().uaps_feat_noise(x.data_ptr(), y.data_ptr(), B, Cc, H, W, seed, offset, float(rng),
+                                            noise.data_ptr() if want_noise else None, _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_feat_noise")
+        ctx.meta = (seed, offset, float(rng))
+        if want_noise:
+            ctx.mark_non_differentiable(noise)
+            return y, noise
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *unused):
+        seed, offset, rng = ctx.meta
+        gy = gy.contiguous()
+        B, Cc, H, W = gy.shape
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            rc = _lib.lib().uaps_feat_noise(gy.data_ptr(), gx.data_ptr(), B, Cc, H, W, seed, offset, rng, None,
+                                            _lib.current_stream(gy.device))
+        _lib.check(rc, "uaps_feat_noise (backward)")
+        return gx, None, None, None, None
+
+
+class _NoiseApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, noise):
+        x = _prep(x, "feature_noise_with")
+        noise = noise.to(torch.float32).contiguous()
+        if tuple(noise.shape) != tuple(x.shape[1:]):
+            raise ValueError("noise must have the per-sample shape [C,H,W]")
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().uaps_feat_noise_apply(x.data_ptr(), noise.data_ptr(), y.data_ptr(), x.shape[0],
+                                                  noise.numel(), _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_feat_noise_apply")
+        ctx.save_for_backward(noise)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (noise,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            rc = _lib.lib().uaps_feat_noise_apply(gy.data_ptr(), noise.data_ptr(), gx.data_ptr(), gy.shape[0],
+                                                  noise.numel(), _lib.current_stream(gy.device))
+        _lib.check(rc, "uaps_feat_noise_apply (backward)")
+        return gx, None
+
+
+def feature_noise_with(x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """x*noise + x with a given [C,H,W] noise tensor (UAPS_unet.py:177-181 with the draw recorded)."""
+    return _NoiseApply.apply(x, noise)
+
+
+class FeatureNoise(nn.Module):
+    """UAPS_unet.py:172-185: x * n + x, n ~ U(-r, r) of shape [C,H,W], shared by the batch."""
+
+    def __init__(self, uniform_range: float = 0.3):
+        super().__init__()
+        self.uniform_range = float(uniform_range)
+
+    def forward(self, x: torch.Tensor, return_noise: bool = False):
+        seed, off = _RngState.reserve(x[0].numel())
+        return _NoiseRng.apply(x, seed, off, self.uniform_range, return_noise)
+
+
+# ---- Dropout(x, p=0.5), always in training mode ---------------------------------------------------
+
+class _Bernoulli(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seed, offset, p, want_keep):
+        x = _prep(x, "Dropout")
+        y = torch.empty_like(x)
+        keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_keep else None
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().uaps_feat_bernoulli(x.data_ptr(), y.data_ptr(), x.numel(), seed, offset, float(p),
+                                                keep.data_ptr() if want_keep else None, _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_feat_bernoulli")
+        ctx.meta = (seed, offset, float(p))
+        if want_keep:
+            ctx.mark_non_differentiable(keep)
+            return y, keep
+        return y
+
+    @staticmethod
+    def backward(ctx, gy, *unused):
+        seed, offset, p = ctx.meta
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            rc = _lib.lib().uaps_feat_bernoulli(gy.data_ptr(), gx.data_ptr(), gy.numel(), seed, offset, p, None,
+                                                _lib.current_stream(gy.device))
+        _lib.check(rc, "uaps_feat_bernoulli (backward)")
+        return gx, None, None, None, None
+
+
+class _MaskApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep, scale):
+        x = _prep(x, "feature_mask_with")
+        keep = keep.to(torch.uint8).contiguous()
+        if keep.shape != x.shape:
+            raise ValueError("keep mask must have the shape of x")
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().uaps_feat_mask_apply(x.data_ptr(), keep.data_ptr(), float(scale), y.data_ptr(), x.numel(),
+                                                 _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_feat_mask_apply")
+        ctx.save_for_backward(keep)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (keep,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            rc = _lib.lib().uaps_feat_mask_apply(gy.data_ptr(), keep.data_ptr(), ctx.scale, gx.data_ptr(), gy.numel(),
+                                                 _lib.current_stream(gy.device))
+        _lib.check(rc, "uaps_feat_mask_apply (backward)")
+        return gx, None, None
+
+
+def dropout_with(x: torch.Tensor, keep: torch.Tensor, p: float = 0.5) -> torch.Tensor:
+    """F.dropout(x, p, training=True) with the keep mask recorded: x * keep / (1-p)."""
+    return _MaskApply.apply(x, keep, 1.0 / (1.0 - p))
+
+
+def Dropout(x: torch.Tensor, p: float = 0.5, return_keep: bool = False):
+    """UAPS_unet.py:156-158: F.dropout(x, p) with training=True unconditionally (also in eval())."""
+    seed, off = _RngState.reserve(x.numel())
+    return _Bernoulli.apply(x, seed, off, p, return_keep)
+
+
+# ---- FeatureDropout -------------------------------------------------------------------------------
+
+_fd_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+class _FeatDrop(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, u):
+        x = _prep(x, "FeatureDropout")
+        B, Cc, H, W = x.shape
+        L = _lib.lib()
+        need = C.c_size_t()
+        _lib.check(L.uaps_feat_dropout_workspace_bytes(B, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
+        key = (x.device.index, _lib.current_stream(x.device))
+        ws = _fd_ws.get(key)
+        if ws is None or ws.numel() < need.value:
+            ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+            _fd_ws[key] = ws
+        y = torch.empty_like(x)
+        keep = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = L.uaps_feat_dropout_fwd(x.data_ptr(), y.data_ptr(), B, Cc, H, W, float(u), keep.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_feat_dropout_fwd")
+        ctx.save_for_backward(keep)
+        ctx.mark_non_differentiable(keep)
+        return y, keep
+
+    @staticmethod
+    def backward(ctx, gy, _gk):
+        (keep,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, Cc, H, W = gy.shape
+        gx = torch.empty_like(gy)
+        with torch.cuda.device(gy.device):
+            rc = _lib.lib().uaps_feat_dropout_bwd(gy.data_ptr(), keep.data_ptr(), gx.data_ptr(), B, Cc, H, W,
+                                                  _lib.current_stream(gy.device))
+        _lib.check(rc, "uaps_feat_dropout_bwd")
+        return gx, None
+
+
+def feature_dropout_with(x: torch.Tensor, u: float, return_keep: bool = False):
+    """UAPS_unet.py:161-169 with the np.random.uniform(0.7, 0.9) draw passed in."""
+    y, keep = _FeatDrop.apply(x, float(u))
+    return (y, keep) if return_keep else y
+
+
+def FeatureDropout(x: torch.Tensor) -> torch.Tensor:
+    """UAPS_unet.py:161-169: zero the pixels whose channel-mean reaches U(0.7,0.9) x the sample maximum."""
+    return feature_dropout_with(x, np.random.uniform(0.7, 0.9))

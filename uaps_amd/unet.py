@@ -1,0 +1,172 @@
+"""Shared-encoder / multi-decoder U-Net of UAPS, parameter-for-parameter compatible with the
+reference checkpoint layout (utilities/UAPS_unet.py:31-233; 334 state_dict entries for
+UNet_UAPS(3, 4), optionally `module.`-prefixed by the reference's nn.DataParallel wrapper).
+
+Module tree and key names (they ARE the drop-in contract, see tests/test_model_state_dict.py):
+  encoder.in_conv.conv_conv.{0,1,4,5}            conv3x3, BN, conv3x3, BN   (UAPS_unet.py:36-44)
+  encoder.down{1..4}.maxpool_conv.1.conv_conv.*  max-pool(2) + ConvBlock    (:55-58)
+  <decoder>.up{1..4}.conv1x1 / .conv.conv_conv.* conv1x1, bilinear x2 (align_corners), cat, ConvBlock (:72-86)
+  <decoder>.out_conv                             conv3x3 -> class logits    (:138-139)
+  decoders: main_decoder, aux_decoder1 (FeatureNoise), aux_decoder2 (Dropout), aux_decoder3 (FeatureDropout)
+
+The convolutions/BatchNorm run through PyTorch-ROCm (MIOpen) in this round; the perturbations and
+everything after the logits are the HIP kernels of this package.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import perturb
+
+FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
+ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
+LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
+
+
+class ConvBlock(nn.Module):
+    """conv3x3 + BN + LeakyReLU + Dropout(p) + conv3x3 + BN + LeakyReLU (UAPS_unet.py:31-47)."""
+
+    def __init__(self, in_channels: int, out_channels: int, dropout_p: float):
+        super().__init__()
+        layers = [nn.Conv2d(in_channels, out_channels, 3, padding=1), nn.BatchNorm2d(out_channels),
+                  nn.LeakyReLU(LEAKY_SLOPE), nn.Dropout(dropout_p),
+                  nn.Conv2d(out_channels, out_channels, 3, padding=1), nn.BatchNorm2d(out_channels),
+                  nn.LeakyReLU(LEAKY_SLOPE)]
+        self.conv_conv = nn.Sequential(*layers)      # indices 0,1,4,5 carry the parameters
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv_conv(x)
+
+
+class DownBlock(nn.Module):
+    """max-pool 2x2 then ConvBlock (UAPS_unet.py:50-62)."""
+
+    def __init__(self, in_channels: int, out_channels: int, dropout_p: float):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), ConvBlock(in_channels, out_channels, dropout_p))
+
+    def forward(self, x):
+        return self.maxpool_conv(x)
+
+
+class UpBlock(nn.Module):
+    """conv1x1 on the coarse map, bilinear x2 (align_corners=True), concat [skip, up], ConvBlock.
+
+    The reference's Decoder never forwards its `bilinear` flag (UAPS_unet.py:129-136), so the
+    bilinear branch (72-75) is the one every shipped checkpoint has; that is what is built here."""
+
+    def __init__(self, in_channels1: int, in_channels2: int, out_channels: int, dropout_p: float = 0.0):
+        super().__init__()
+        self.conv1x1 = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
+
+    def forward(self, coarse, skip):
+        up = self.up(self.conv1x1(coarse))
+        return self.conv(torch.cat([skip, up], dim=1))
+
+
+class Encoder(nn.Module):
+    """Five-scale feature pyramid (UAPS_unet.py:89-116)."""
+
+    def __init__(self, in_chns: int, feature_chns: Sequence[int] = FEATURE_CHANNELS,
+                 dropout: Sequence[float] = ENCODER_DROPOUT):
+        super().__init__()
+        if len(feature_chns) != 5:
+            raise AssertionError("five feature scales expected")       # UAPS_unet.py:98
+        f = list(feature_chns)
+        self.in_conv = ConvBlock(in_chns, f[0], dropout[0])
+        self.down1 = DownBlock(f[0], f[1], dropout[1])
+        self.down2 = DownBlock(f[1], f[2], dropout[2])
+        self.down3 = DownBlock(f[2], f[3], dropout[3])
+        self.down4 = DownBlock(f[3], f[4], dropout[4])
+
+    def forward(self, x) -> List[torch.Tensor]:
+        feats = [self.in_conv(x)]
+        for blk in (self.down1, self.down2, self.down3, self.down4):
+            feats.append(blk(feats[-1]))
+        return feats
+
+
+class Decoder(nn.Module):
+    """Four UpBlocks + 3x3 classifier (UAPS_unet.py:119-153)."""
+
+    def __init__(self, class_num: int, feature_chns: Sequence[int] = FEATURE_CHANNELS):
+        super().__init__()
+        if len(feature_chns) != 5:
+            raise AssertionError("five feature scales expected")       # UAPS_unet.py:127
+        f = list(feature_chns)
+        self.up1 = UpBlock(f[4], f[3], f[3])
+        self.up2 = UpBlock(f[3], f[2], f[2])
+        self.up3 = UpBlock(f[2], f[1], f[1])
+        self.up4 = UpBlock(f[1], f[0], f[0])
+        self.out_conv = nn.Conv2d(f[0], class_num, kernel_size=3, padding=1)
+
+    def forward(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+        x = self.up1(feats[4], feats[3])
+        x = self.up2(x, feats[2])
+        x = self.up3(x, feats[1])
+        x = self.up4(x, feats[0])
+        return self.out_conv(x)
+
+
+class UNet(nn.Module):
+    """Single-decoder U-Net (UAPS_unet.py:188-205; same blocks as utilities/baseline_unet.py:159-176)."""
+
+    def __init__(self, in_chns: int, class_num: int, feature_chns: Sequence[int] = FEATURE_CHANNELS):
+        super().__init__()
+        self.encoder = Encoder(in_chns, feature_chns)
+        self.decoder = Decoder(class_num, feature_chns)
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+
+# perturbation applied in front of auxiliary decoder i (UAPS_unet.py:227-231); decoders beyond the
+# reference's three (the K=5 stress config has no reference implementation) cycle through the same three.
+_PERTURBATIONS = ("noise", "dropout", "feature_dropout")
+
+
+class UNet_UAPS(nn.Module):
+    """Shared encoder, main decoder on clean features, `n_aux` auxiliary decoders on perturbed
+    features; returns (main, aux1, ..., aux_n) logits, each [B, class_num, H, W] fp32
+    (UAPS_unet.py:208-233).  `n_aux=3` is the reference model."""
+
+    def __init__(self, in_chns: int, class_num: int, n_aux: int = 3,
+                 feature_chns: Sequence[int] = FEATURE_CHANNELS, dropout: Sequence[float] = ENCODER_DROPOUT):
+        super().__init__()
+        if not 0 <= n_aux <= 7:
+            raise ValueError("n_aux must be in 0..7")
+        self.n_aux = n_aux
+        self.encoder = Encoder(in_chns, feature_chns, dropout)
+        self.main_decoder = Decoder(class_num, feature_chns)
+        for i in range(1, n_aux + 1):
+            setattr(self, f"aux_decoder{i}", Decoder(class_num, feature_chns))
+        self._noise = perturb.FeatureNoise()
+
+    def aux_decoders(self) -> List[Decoder]:
+        return [getattr(self, f"aux_decoder{i}") for i in range(1, self.n_aux + 1)]
+
+    def _perturb(self, kind: str, feats):
+        if kind == "noise":
+            return [self._noise(f) for f in feats]
+        if kind == "dropout":
+            return [perturb.Dropout(f) for f in feats]
+        return [perturb.FeatureDropout(f) for f in feats]
+
+    def forward(self, x, perturbations=None):
+        """`perturbations`: optional list (one entry per auxiliary decoder) of callables
+        feats -> feats replacing the random draws (parity tests inject recorded draws here)."""
+        feats = self.encoder(x)
+        outs = [self.main_decoder(feats)]
+        for i, dec in enumerate(self.aux_decoders()):
+            if perturbations is not None and perturbations[i] is not None:
+                pf = perturbations[i](feats)
+            else:
+                pf = self._perturb(_PERTURBATIONS[i % 3], feats)
+            outs.append(dec(pf))
+        return tuple(outs)
