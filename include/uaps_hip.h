@@ -136,6 +136,45 @@ int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int B
                           uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ConvBlock / UpBlock glue between the convolutions (utilities/UAPS_unet.py:36-44, 81-86).
+ * ------------------------------------------------------------------------------------------- */
+
+/* nn.BatchNorm2d (training statistics) -> nn.LeakyReLU(slope) -> nn.Dropout(drop_p) on a conv
+ * output y [B,C,H,W], fused (UAPS_unet.py:38-40, 42-43).  conv_bias (may be NULL) is the bias of the
+ * preceding conv when the caller ran the conv without it: train-mode BN cancels it exactly, it only
+ * enters running_mean.  Updates running_mean/running_var (momentum form of nn.BatchNorm2d, unbiased
+ * variance) and increments *num_batches_tracked when those pointers are non-NULL.  Writes
+ * save_mean/save_invstd [C] for the backward.  Dropout keep-masks come from Philox(seed, offset)
+ * and are regenerated by the backward; drop_p = 0 disables it. */
+int uaps_bn_workspace_bytes(int B, int C, int H, int W, size_t* out_host);
+int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                          float eps, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C,
+                          int H, int W, float* out, float* save_mean, float* save_invstd, void* workspace,
+                          size_t workspace_bytes, uaps_stream_t stream);
+/* eval(): running statistics, no dropout.  save_mean receives running_mean - conv_bias (for the backward). */
+int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                         const float* running_mean, const float* running_var, float eps, float slope, int B,
+                         int C, int H, int W, float* out, float* save_mean, void* workspace,
+                         size_t workspace_bytes, uaps_stream_t stream);
+/* Backward of the train-mode op: dy [B,C,H,W], dgamma [C], dbeta [C] from dout and the saved y. */
+int uaps_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta,
+                    const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                    uint64_t offset, int B, int C, int H, int W, float* dy, float* dgamma, float* dbeta,
+                    void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_bn_act_bwd_eval(const float* dout, const float* y, const float* gamma, const float* beta,
+                         const float* mean_eff, const float* running_var, float eps, float slope, int B, int C,
+                         int H, int W, float* dy, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+
+/* UpBlock.forward lines 83-85: out[:, :Cs] = skip ; out[:, Cs:] = bilinear x2 (align_corners=True) of
+ * low [B,Cl,h,w]; out is [B,Cs+Cl,2h,2w].  Backward: dskip = dout[:, :Cs] (may be NULL), dlow = the
+ * transposed interpolation of dout[:, Cs:] (gather form, deterministic). */
+int uaps_up_cat_fwd(const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w,
+                    uaps_stream_t stream);
+int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs, int Cl, int h, int w,
+                    uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Metrics: utilities/metrics.py:8-61 (pixel_accuracy, mIoU, mDice) need only the C x C confusion
  * matrix of arg-max(logits) against the labels: counts[t*C + p], int64, overwritten.
  * ------------------------------------------------------------------------------------------- */

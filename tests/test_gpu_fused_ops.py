@@ -1,0 +1,116 @@
+"""-m gpu: the ConvBlock/UpBlock glue kernels (BN+LeakyReLU+Dropout, bilinear-x2+concat) against a
+plain PyTorch fp32 reference of the same ops (the reference's own modules: nn.BatchNorm2d,
+nn.LeakyReLU, nn.Dropout, nn.Upsample(align_corners=True), torch.cat -- UAPS_unet.py:36-44, 72-86)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ref_bn_act(y, bias, bn, slope, train):
+    z = F.batch_norm(y + bias.view(1, -1, 1, 1), bn.running_mean, bn.running_var, bn.weight, bn.bias, training=train,
+                     momentum=bn.momentum, eps=bn.eps)
+    return F.leaky_relu(z, slope)
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 64, 64), (3, 5, 7, 9), (2, 64, 16, 16), (16, 16, 256, 256), (2, 256, 2, 2)])
+def test_bn_act_train_vs_torch(shape):
+    from uaps_amd import fused
+    torch.manual_seed(1)
+    B, C, H, W = shape
+    y = (torch.randn(shape, device=DEV) * 1.7 + 0.3).requires_grad_(True)
+    bias = torch.randn(C, device=DEV).requires_grad_(True)
+    bn = nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    bn_ref = nn.BatchNorm2d(C).to(DEV); bn_ref.load_state_dict(bn.state_dict())
+    out = fused.bn_act(y, bias, bn, 0.01, 0.0, True)
+    yr = y.detach().clone().requires_grad_(True); br = bias.detach().clone().requires_grad_(True)
+    bn_ref.num_batches_tracked += 1
+    ref = _ref_bn_act(yr, br, bn_ref, 0.01, True)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(bn.running_mean, bn_ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, bn_ref.running_var, rtol=1e-4, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g)
+    scale = float(yr.grad.abs().max())
+    # at the LeakyReLU kink (|z| ~ 1 ulp) the slope choice may legitimately differ: exclude those pixels
+    z = F.batch_norm(yr.detach() + br.detach().view(1, -1, 1, 1), None, None, bn_ref.weight, bn_ref.bias, training=True, eps=bn.eps)
+    ok = z.abs() > 1e-5
+    assert float((~ok).float().mean()) < 1e-4
+    chan_ok = ok.all(dim=3).all(dim=2).all(dim=0)          # channels without a kink pixel
+    ok = ok & chan_ok.view(1, -1, 1, 1)
+    torch.testing.assert_close(y.grad[ok], yr.grad[ok], rtol=1e-3, atol=2e-5 * scale)
+    torch.testing.assert_close(bn.weight.grad[chan_ok], bn_ref.weight.grad[chan_ok], rtol=1e-4, atol=1e-4 * float(bn_ref.weight.grad.abs().max()))
+    torch.testing.assert_close(bn.bias.grad[chan_ok], bn_ref.bias.grad[chan_ok], rtol=1e-4, atol=1e-4 * float(bn_ref.bias.grad.abs().max()))
+    assert torch.count_nonzero(bias.grad) == 0                     # exact zero; torch's is rounding noise
+    assert float(br.grad.abs().max()) < 1e-3 * float(g.abs().sum() / C)
+
+
+def test_bn_act_eval_vs_torch():
+    from uaps_amd import fused
+    torch.manual_seed(2)
+    y = torch.randn(3, 8, 20, 12, device=DEV, requires_grad=True)
+    bias = torch.randn(8, device=DEV)
+    bn = nn.BatchNorm2d(8).to(DEV).eval()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    rm0 = bn.running_mean.clone()
+    out = fused.bn_act(y, bias, bn, 0.01, 0.3, False)             # dropout is off in eval
+    yr = y.detach().clone().requires_grad_(True)
+    ref = _ref_bn_act(yr, bias, bn, 0.01, False)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    assert torch.equal(bn.running_mean, rm0)
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g)
+    torch.testing.assert_close(y.grad, yr.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,p", [((4, 16, 64, 64), 0.3), ((3, 5, 7, 9), 0.5), ((8, 32, 128, 128), 0.05)])
+def test_bn_act_dropout_consistency(shape, p):
+    """Dropout draws come from the device RNG: check rate, scaling, and that the backward regenerates the
+    same mask (gradient equals autograd through the reference ops with the mask read back from the output)."""
+    from uaps_amd import fused, perturb
+    torch.manual_seed(3)
+    perturb.manual_seed(7)
+    B, C, H, W = shape
+    y = torch.randn(shape, device=DEV, requires_grad=True)
+    bn = nn.BatchNorm2d(C).to(DEV)
+    bn_ref = nn.BatchNorm2d(C).to(DEV)
+    out = fused.bn_act(y, None, bn, 0.01, p, True)
+    yr = y.detach().clone().requires_grad_(True)
+    nod = F.leaky_relu(bn_ref(yr), 0.01)
+    keep = (out != 0) | (nod == 0)
+    rate = float((out != 0).float().mean())
+    assert abs(rate - (1 - p)) < 0.01 + 3 * np.sqrt(p * (1 - p) / out.numel())
+    ref = nod * keep / (1 - p)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-5)
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g)
+    torch.testing.assert_close(y.grad, yr.grad, rtol=1e-3, atol=2e-5 * float(yr.grad.abs().max()))
+    torch.testing.assert_close(bn.weight.grad, bn_ref.weight.grad, rtol=1e-3, atol=1e-4 * float(bn_ref.weight.grad.abs().max()))
+    # determinism of the stream: same seed -> same mask
+    perturb.manual_seed(7)
+    out2 = fused.bn_act(y.detach(), None, nn.BatchNorm2d(C).to(DEV), 0.01, p, True)
+    assert torch.equal(out2 != 0, out != 0)
+
+
+@pytest.mark.parametrize("B,Cs,Cl,h,w", [(2, 4, 4, 5, 6), (16, 16, 16, 128, 128), (3, 7, 5, 1, 1), (2, 8, 8, 2, 3), (4, 128, 128, 16, 16)])
+def test_up_cat_vs_torch(B, Cs, Cl, h, w):
+    from uaps_amd import fused
+    torch.manual_seed(4)
+    skip = torch.randn(B, Cs, 2 * h, 2 * w, device=DEV, requires_grad=True)
+    low = torch.randn(B, Cl, h, w, device=DEV, requires_grad=True)
+    out = fused.up_cat(skip, low)
+    sr, lr = skip.detach().clone().requires_grad_(True), low.detach().clone().requires_grad_(True)
+    ref = torch.cat([sr, F.interpolate(lr, scale_factor=2, mode="bilinear", align_corners=True)], dim=1)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6)
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g)
+    assert torch.equal(skip.grad, sr.grad)
+    torch.testing.assert_close(low.grad, lr.grad, rtol=1e-4, atol=1e-5)

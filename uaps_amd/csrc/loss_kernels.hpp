@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rn_math.hpp"
 
 namespace uaps {
 
@@ -159,9 +160,9 @@ __global__ __launch_bounds__(kThreads) void unsup_fwd_kernel(HeadPtrs<D> z, Head
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 float s = p[0][c];
-                float mix = __fmul_rn(w.w[0], p[0][c]);
+                float mix = mul_rn(w.w[0], p[0][c]);
 #pragma unroll
-                for (int k = 1; k < D; ++k) { s = __fadd_rn(s, p[k][c]); mix = __fadd_rn(mix, __fmul_rn(w.w[k], p[k][c])); }
+                for (int k = 1; k < D; ++k) { s = add_rn(s, p[k][c]); mix = add_rn(mix, mul_rn(w.w[k], p[k][c])); }
                 m[c] = s / (float)D;
                 xm += (m[c] > 0.f) ? m[c] * flog(m[c]) : 0.f;           // xlogy(m, m)
                 if (c == 0 || mix > best) { best = mix; y = c; }          // first maximum wins, as torch.argmax
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, Head
             for (int c = 0; c < C; ++c) {
                 float s = p[0][c];
 #pragma unroll
-                for (int k = 1; k < D; ++k) s = __fadd_rn(s, p[k][c]);
+                for (int k = 1; k < D; ++k) s = add_rn(s, p[k][c]);
                 m[c] = s / (float)D;
                 const float lm = (m[c] > 0.f) ? flog(m[c]) : 0.f;
                 xm += m[c] * lm;

@@ -1,0 +1,401 @@
+// Fused BatchNorm2d(train) + LeakyReLU + Dropout, forward and backward, for gfx950.
+//
+// Replaces, per ConvBlock half (utilities/UAPS_unet.py:36-44): nn.BatchNorm2d -> nn.LeakyReLU ->
+// nn.Dropout on the conv output, i.e. MIOpenBatchNormFwdTrainSpatial + a leaky_relu kernel + a
+// fused_dropout kernel (forward) and their three backward kernels.  MIOpen's spatial BN launches
+// one workgroup per channel, so the 16-channel full-resolution layers of this U-Net run on 16 of
+// the chip's 256 CUs (measured 420 us per call, profiles/r01_baseline_miopen_kernel_stats.csv);
+// here every (sample, channel) plane is cut into chunks, so all CUs stream:
+//   forward : stats pass (1 read) -> per-channel finalize -> apply pass (1 read, 1 write)
+//   backward: sums pass (2 reads) -> per-channel finalize -> dx pass (2 reads, 1 write)
+// Reductions are block partials + fixed-order double finalize: bitwise reproducible, no float atomics.
+// The conv bias (which train-mode BN cancels exactly) is folded in: it only shifts running_mean.
+// Dropout masks come from Philox (philox.hpp) and are regenerated in the backward, never stored.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/uaps_hip.h"
+#include "philox.hpp"
+
+namespace {
+using uaps::philox4x32_10; using uaps::u01; using uaps::U4; using uaps::pick;
+
+constexpr int kThreads = 256;
+constexpr int kChunk = 4096;       // floats per block: 4 float4 per thread
+
+inline int nchunks_for(long HW) { return (int)((HW + kChunk - 1) / kChunk); }
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct BnWs { float2* partials; float* coef; };   // coef: 4*C floats
+inline size_t bn_ws_bytes(int B, int C, long HW) { return align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)) + (size_t)4 * C * sizeof(float); }
+inline BnWs carve(void* ws, int B, int C, long HW) {
+    BnWs w; w.partials = (float2*)ws;
+    w.coef = (float*)((char*)ws + align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)));
+    return w;
+}
+
+__device__ __forceinline__ float2 block_sum2(float a, float b) {
+    __shared__ float2 red[kThreads / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_float2(a, b);
+    __syncthreads();
+    float2 r = red[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) { r.x += red[w].x; r.y += red[w].y; }
+    return r;
+}
+
+// ---- forward pass 1: per-chunk (sum, sum of squares) ------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ y, int C, long HW, int nchunks,
+                                                            float2* __restrict__ partials) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int b = plane / C, c = plane - b * C;
+    const float* p = y + (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    float s = 0.f, ss = 0.f;
+    if (VEC) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) { const float v = p[i]; s += v; ss += v * v; }
+    }
+    const float2 r = block_sum2(s, ss);
+    if (threadIdx.x == 0) partials[((long)c * gridDim.y / C + b) * nchunks + chunk] = r;
+}
+
+// ---- forward finalize: one wave per channel ------------------------------------------------------------
+__global__ __launch_bounds__(64) void bn_finalize_fwd(const float2* __restrict__ partials, int nparts, double M,
+                                                      const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                      float momentum, float eps, float* __restrict__ save_mean,
+                                                      float* __restrict__ save_invstd, float* __restrict__ coef, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int i = lane; i < nparts; i += 64) { const float2 v = partials[(long)c * nparts + i]; s += v.x; ss += v.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (lane == 0) {
+        const double mean = s / M;
+        double var = ss / M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[c] = (float)mean;
+        save_invstd[c] = invstd;
+        coef[c] = gamma[c] * invstd;                 // scale
+        coef[C + c] = beta[c];                       // shift applied after (y - mean) * scale
+        if (running_mean) {
+            const double bias = conv_bias ? (double)conv_bias[c] : 0.0;
+            const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + bias));
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        if (nbt && c == 0) nbt[0] += 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void bn_coef_eval(const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ running_mean,
+                                                   const float* __restrict__ running_var, float eps, float* __restrict__ coef,
+                                                   float* __restrict__ mean_out, int C) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+    coef[c] = gamma[c] * invstd;
+    coef[C + c] = beta[c];
+    mean_out[c] = running_mean[c] - (conv_bias ? conv_bias[c] : 0.f);     // (y + b - rm) = y - (rm - b)
+}
+
+// ---- forward pass 2: out = dropout(leaky_relu((y - mean) * scale + beta)) ---------------------------------
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, float* __restrict__ out, int C, long HW,
+                                                            const float* __restrict__ mean, const float* __restrict__ coef,
+                                                            float slope, float drop_p, float drop_scale, uint64_t seed,
+                                                            uint64_t offset) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int c = plane % C;
+    const float mu = mean[c], sc = coef[c], sh = coef[C + c];
+    const long pbase = (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    if (VEC) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
+            const float4 v = *reinterpret_cast<const float4*>(y + pbase + i);
+            float z[4] = {(v.x - mu) * sc + sh, (v.y - mu) * sc + sh, (v.z - mu) * sc + sh, (v.w - mu) * sc + sh};
+            if (DROP) {
+                const U4 r = philox4x32_10(offset + (uint64_t)((pbase + i) >> 2), seed);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { z[k] = z[k] > 0.f ? z[k] : z[k] * slope; z[k] = u01(pick(r, k)) >= drop_p ? z[k] * drop_scale : 0.f; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) z[k] = z[k] > 0.f ? z[k] : z[k] * slope;
+            }
+            *reinterpret_cast<float4*>(out + pbase + i) = make_float4(z[0], z[1], z[2], z[3]);
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
+            float z = (y[pbase + i] - mu) * sc + sh;
+            z = z > 0.f ? z : z * slope;
+            if (DROP) {
+                const long e = pbase + i;
+                const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
+                z = u01(pick(r, (int)(e & 3))) >= drop_p ? z * drop_scale : 0.f;
+            }
+            out[pbase + i] = z;
+        }
+    }
+}
+
+// ---- backward helpers -------------------------------------------------------------------------------------
+// d(pre-activation) from d(out): dropout mask/scale, then LeakyReLU slope chosen by the sign of the
+// recomputed BN output z (torch: grad * (z > 0 ? 1 : slope)).
+__device__ __forceinline__ float dpre(float dout, float yv, float mu, float sc, float sh, float slope) {
+    const float z = (yv - mu) * sc + sh;
+    return z > 0.f ? dout : dout * slope;
+}
+
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(kThreads) void bn_bwd_sums_kernel(const float* __restrict__ dout, const float* __restrict__ y, int C,
+                                                               long HW, int nchunks, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float slope, float drop_p,
+                                                               float drop_scale, uint64_t seed, uint64_t offset,
+                                                               float2* __restrict__ partials) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int b = plane / C, c = plane - b * C;
+    const float mu = mean[c], is = invstd[c], sc = gamma[c] * is, sh = beta[c];
+    const long pbase = (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    float s1 = 0.f, s2 = 0.f;
+    if (VEC) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + pbase + i);
+            const float4 y4 = *reinterpret_cast<const float4*>(y + pbase + i);
+            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+            if (DROP) {
+                const U4 r = philox4x32_10(offset + (uint64_t)((pbase + i) >> 2), seed);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = u01(pick(r, k)) >= drop_p ? g[k] * drop_scale : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = dpre(g[k], yy[k], mu, sc, sh, slope);
+                s1 += d; s2 += d * ((yy[k] - mu) * is);
+            }
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
+            float g = dout[pbase + i];
+            const float yv = y[pbase + i];
+            if (DROP) {
+                const long e = pbase + i;
+                const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
+                g = u01(pick(r, (int)(e & 3))) >= drop_p ? g * drop_scale : 0.f;
+            }
+            const float d = dpre(g, yv, mu, sc, sh, slope);
+            s1 += d; s2 += d * ((yv - mu) * is);
+        }
+    }
+    const float2 r = block_sum2(s1, s2);
+    if (threadIdx.x == 0) partials[((long)c * gridDim.y / C + b) * nchunks + chunk] = r;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_bwd(const float2* __restrict__ partials, int nparts, double M,
+                                                      const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      float* __restrict__ coef, int C) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = lane; i < nparts; i += 64) { const float2 v = partials[(long)c * nparts + i]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (lane == 0) {
+        dbeta[c] = (float)s1;
+        dgamma[c] = (float)s2;
+        coef[2 * C + c] = (float)(s1 / M);
+        coef[3 * C + c] = (float)(s2 / M);
+    }
+}
+
+// dy = gamma * invstd * (dpre - mean(dpre) - xhat * mean(dpre * xhat))
+template <bool VEC, bool DROP>
+__global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                             float* __restrict__ dy, int C, long HW, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ coef,
+                                                             float slope, float drop_p, float drop_scale, uint64_t seed,
+                                                             uint64_t offset) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int c = plane % C;
+    const float mu = mean[c], is = invstd[c], sc = gamma[c] * is, sh = beta[c], k2 = coef[2 * C + c], k3 = coef[3 * C + c];
+    const long pbase = (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    if (VEC) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + pbase + i);
+            const float4 y4 = *reinterpret_cast<const float4*>(y + pbase + i);
+            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+            if (DROP) {
+                const U4 r = philox4x32_10(offset + (uint64_t)((pbase + i) >> 2), seed);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = u01(pick(r, k)) >= drop_p ? g[k] * drop_scale : 0.f;
+            }
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = dpre(g[k], yy[k], mu, sc, sh, slope);
+                o[k] = sc * (d - k2 - ((yy[k] - mu) * is) * k3);
+            }
+            *reinterpret_cast<float4*>(dy + pbase + i) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
+            float g = dout[pbase + i];
+            const float yv = y[pbase + i];
+            if (DROP) {
+                const long e = pbase + i;
+                const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
+                g = u01(pick(r, (int)(e & 3))) >= drop_p ? g * drop_scale : 0.f;
+            }
+            const float d = dpre(g, yv, mu, sc, sh, slope);
+            dy[pbase + i] = sc * (d - k2 - ((yv - mu) * is) * k3);
+        }
+    }
+}
+
+// eval-mode backward (running statistics are constants): dy = scale * dpre ; used only if someone
+// differentiates through an eval() forward.
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_eval_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                               float* __restrict__ dy, int C, long HW, const float* __restrict__ mean,
+                                                               const float* __restrict__ coef, float slope) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int c = plane % C;
+    const float mu = mean[c], sc = coef[c], sh = coef[C + c];
+    const long pbase = (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    const int step = VEC ? 4 : 1;
+    for (long i = lo + step * threadIdx.x; i < hi; i += step * kThreads) {
+        if (VEC) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + pbase + i);
+            const float4 y4 = *reinterpret_cast<const float4*>(y + pbase + i);
+            *reinterpret_cast<float4*>(dy + pbase + i) = make_float4(sc * dpre(g4.x, y4.x, mu, sc, sh, slope), sc * dpre(g4.y, y4.y, mu, sc, sh, slope),
+                                                                     sc * dpre(g4.z, y4.z, mu, sc, sh, slope), sc * dpre(g4.w, y4.w, mu, sc, sh, slope));
+        } else {
+            dy[pbase + i] = sc * dpre(dout[pbase + i], y[pbase + i], mu, sc, sh, slope);
+        }
+    }
+}
+
+inline int check(const void* a, const void* b, int B, int C, int H, int W) {
+    if (!a || !b || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if ((long)B * C > 65535) return UAPS_ERANGE;      // planes ride on gridDim.y
+    return UAPS_OK;
+}
+
+}  // namespace
+
+extern "C" int uaps_bn_workspace_bytes(int B, int C, int H, int W, size_t* out) {
+    if (!out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    *out = bn_ws_bytes(B, C, (long)H * W);
+    return UAPS_OK;
+}
+
+extern "C" int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                     float eps, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C, int H,
+                                     int W, float* out, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                     uaps_stream_t stream) {
+    int rc = check(y, out, B, C, H, W);
+    if (rc) return rc;
+    if (!gamma || !beta || !save_mean || !save_invstd || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    const int nch = nchunks_for(HW);
+    const dim3 grid(nch, B * C);
+    const bool vec = (HW % 4 == 0) && al16(y) && al16(out);
+    if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+    else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(64), 0, s, w.partials, B * nch, (double)B * HW, conv_bias, gamma, beta, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
+    const float dscale = 1.f / (1.f - drop_p);
+#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset)
+    if (vec) { if (drop_p > 0.f) UAPS_APPLY(true, true); else UAPS_APPLY(true, false); }
+    else { if (drop_p > 0.f) UAPS_APPLY(false, true); else UAPS_APPLY(false, false); }
+#undef UAPS_APPLY
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                                    const float* running_mean, const float* running_var, float eps, float slope, int B, int C,
+                                    int H, int W, float* out, float* save_mean, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    int rc = check(y, out, B, C, H, W);
+    if (rc) return rc;
+    if (!gamma || !beta || !running_mean || !running_var || !save_mean || !ws) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    hipLaunchKernelGGL(bn_coef_eval, dim3((C + 63) / 64), dim3(64), 0, s, conv_bias, gamma, beta, running_mean, running_var, eps, w.coef, save_mean, C);
+    const dim3 grid(nchunks_for(HW), B * C);
+    if ((HW % 4 == 0) && al16(y) && al16(out))
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_invstd, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C,
+                               int H, int W, float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                               uaps_stream_t stream) {
+    int rc = check(dout, dy, B, C, H, W);
+    if (rc) return rc;
+    if (!y || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    const int nch = nchunks_for(HW);
+    const dim3 grid(nch, B * C);
+    const bool vec = (HW % 4 == 0) && al16(y) && al16(dout) && al16(dy);
+    const float dscale = 1.f / (1.f - drop_p);
+#define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials)
+#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, w.coef, slope, drop_p, dscale, seed, offset)
+    if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
+    else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
+    hipLaunchKernelGGL(bn_finalize_bwd, dim3(C), dim3(64), 0, s, w.partials, B * nch, (double)B * HW, gamma, save_invstd, dgamma, dbeta, w.coef, C);
+    if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }
+    else { if (drop_p > 0.f) UAPS_DX(false, true); else UAPS_DX(false, false); }
+#undef UAPS_SUMS
+#undef UAPS_DX
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_bwd_eval(const float* dout, const float* y, const float* gamma, const float* beta,
+                                    const float* mean_eff, const float* running_var, float eps, float slope, int B, int C, int H,
+                                    int W, float* dy, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    int rc = check(dout, dy, B, C, H, W);
+    if (rc) return rc;
+    if (!y || !gamma || !beta || !mean_eff || !running_var || !ws) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    // coef[0..C) = gamma / sqrt(rv + eps), coef[C..2C) = beta; the mean (running_mean - conv bias) is passed in
+    hipLaunchKernelGGL(bn_coef_eval, dim3((C + 63) / 64), dim3(64), 0, s, (const float*)nullptr, gamma, beta, mean_eff, running_var, eps, w.coef, w.coef + 2 * C, C);
+    const dim3 grid(nchunks_for(HW), B * C);
+    if ((HW % 4 == 0) && al16(y) && al16(dout) && al16(dy))
+        hipLaunchKernelGGL(bn_bwd_eval_kernel<true>, grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, mean_eff, w.coef, slope);
+    else
+        hipLaunchKernelGGL(bn_bwd_eval_kernel<false>, grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, mean_eff, w.coef, slope);
+    return (int)hipGetLastError();
+}

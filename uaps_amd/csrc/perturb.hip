@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/uaps_hip.h"
+#include "rn_math.hpp"
+#include "philox.hpp"
+using uaps::mul_rn; using uaps::add_rn; using uaps::U4; using uaps::philox4x32_10; using uaps::u01;
 
 namespace {
 
@@ -18,24 +21,6 @@ inline int grid_for(long work) {
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Philox4x32-10 (Salmon et al., SC'11), counter-based: stateless, so forward and backward regenerate
-// the same draw from (seed, counter) instead of storing masks.
-struct U4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ U4 philox4x32_10(uint64_t ctr, uint64_t key) {
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x55415053u /* "UAPS" */, c3 = 0;
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return U4{c0, c1, c2, c3};
-}
-__device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }   // [0,1)
-
 // ---- FeatureNoise: y[b,e] = x[b,e] * n[e] + x[b,e], n ~ U(-range, range), e over C*H*W ------------
 __global__ __launch_bounds__(kThreads) void noise_rng_vec4(const float4* __restrict__ x, float4* __restrict__ y, int B,
                                                            long chw4, uint64_t seed, uint64_t offset, float range,
@@ -49,8 +34,8 @@ __global__ __launch_bounds__(kThreads) void noise_rng_vec4(const float4* __restr
         for (int b = 0; b < B; ++b) {
             const float4 v = x[(long)b * chw4 + e];
             float4 o;   // x.mul(noise) + x : separate roundings as in UAPS_unet.py:180
-            o.x = __fadd_rn(__fmul_rn(v.x, n.x), v.x); o.y = __fadd_rn(__fmul_rn(v.y, n.y), v.y);
-            o.z = __fadd_rn(__fmul_rn(v.z, n.z), v.z); o.w = __fadd_rn(__fmul_rn(v.w, n.w), v.w);
+            o.x = add_rn(mul_rn(v.x, n.x), v.x); o.y = add_rn(mul_rn(v.y, n.y), v.y);
+            o.z = add_rn(mul_rn(v.z, n.z), v.z); o.w = add_rn(mul_rn(v.w, n.w), v.w);
             y[(long)b * chw4 + e] = o;
         }
     }
@@ -63,7 +48,7 @@ __global__ __launch_bounds__(kThreads) void noise_rng_scalar(const float* __rest
         const uint32_t rr = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
         const float n = (2.f * u01(rr) - 1.f) * range;
         if (noise_out) noise_out[e] = n;
-        for (int b = 0; b < B; ++b) { const float v = x[(long)b * chw + e]; y[(long)b * chw + e] = __fadd_rn(__fmul_rn(v, n), v); }
+        for (int b = 0; b < B; ++b) { const float v = x[(long)b * chw + e]; y[(long)b * chw + e] = add_rn(mul_rn(v, n), v); }
     }
 }
 __global__ __launch_bounds__(kThreads) void noise_apply_vec4(const float4* __restrict__ x, const float4* __restrict__ noise,
@@ -73,8 +58,8 @@ __global__ __launch_bounds__(kThreads) void noise_apply_vec4(const float4* __res
         for (int b = 0; b < B; ++b) {
             const float4 v = x[(long)b * chw4 + e];
             float4 o;
-            o.x = __fadd_rn(__fmul_rn(v.x, n.x), v.x); o.y = __fadd_rn(__fmul_rn(v.y, n.y), v.y);
-            o.z = __fadd_rn(__fmul_rn(v.z, n.z), v.z); o.w = __fadd_rn(__fmul_rn(v.w, n.w), v.w);
+            o.x = add_rn(mul_rn(v.x, n.x), v.x); o.y = add_rn(mul_rn(v.y, n.y), v.y);
+            o.z = add_rn(mul_rn(v.z, n.z), v.z); o.w = add_rn(mul_rn(v.w, n.w), v.w);
             y[(long)b * chw4 + e] = o;
         }
     }
@@ -83,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void noise_apply_scalar(const float* __re
                                                                float* __restrict__ y, int B, long chw) {
     for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < chw; e += (long)gridDim.x * kThreads) {
         const float n = noise[e];
-        for (int b = 0; b < B; ++b) { const float v = x[(long)b * chw + e]; y[(long)b * chw + e] = __fadd_rn(__fmul_rn(v, n), v); }
+        for (int b = 0; b < B; ++b) { const float v = x[(long)b * chw + e]; y[(long)b * chw + e] = add_rn(mul_rn(v, n), v); }
     }
 }
 
@@ -131,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void fdrop_attention(const float* __restr
     uint32_t best = 0;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
         float s = xb[i];
-        for (int c = 1; c < C; ++c) s = __fadd_rn(s, xb[(long)c * HW + i]);
+        for (int c = 1; c < C; ++c) s = add_rn(s, xb[(long)c * HW + i]);
         const float a = s / (float)C;
         att[(long)b * HW + i] = a;
         const uint32_t k = fkey(a);
@@ -146,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void fdrop_apply(const float* __restrict_
                                                         const float* __restrict__ att, const uint32_t* __restrict__ maxkey,
                                                         float u, uint8_t* __restrict__ keep) {
     const int b = blockIdx.y;
-    const float thr = __fmul_rn(fkey_inv(maxkey[b]), u);
+    const float thr = mul_rn(fkey_inv(maxkey[b]), u);
     const float* xb = x + (long)b * C * HW;
     float* yb = y + (long)b * C * HW;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {

@@ -1,0 +1,162 @@
+// UpBlock glue for gfx950: bilinear x2 up-sampling (align_corners=True) written straight into the
+// channel-concatenated buffer the following ConvBlock reads, and its backward.
+//
+// Replaces utilities/UAPS_unet.py:83-85 (`x1 = self.up(x1); x = torch.cat([x2, x1], dim=1)`), i.e.
+// torch's upsample_bilinear2d_out_frame (660 us per call on the full-resolution layer: it launches
+// 1024 threads per *row block*, profiles/r01_baseline_miopen_kernel_stats.csv) + CatArrayBatchedCopy,
+// and in the backward upsample_bilinear2d_backward + the slice copies.  Streaming, 16 B per lane.
+//
+// Interpolation arithmetic follows ATen's area_pixel_compute_scale / upsample_bilinear2d exactly:
+//   r = (in-1)/(out-1) (fp32); src = r*o; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1
+//   v = l0h*(l0w*v00 + l1w*v01) + l1h*(l0w*v10 + l1w*v11)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/uaps_hip.h"
+#include "rn_math.hpp"
+
+namespace {
+using uaps::mul_rn;
+constexpr int kThreads = 256;
+inline int grid_for(long work, int cap = 4096) {
+    long b = (work + kThreads - 1) / kThreads;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ float bilerp(const float* __restrict__ p, int w, int h0, int h1, float lh0, float lh1, int w0, int w1,
+                                        float lw0, float lw1) {
+    const float top = lw0 * p[(long)h0 * w + w0] + lw1 * p[(long)h0 * w + w1];
+    const float bot = lw0 * p[(long)h1 * w + w0] + lw1 * p[(long)h1 * w + w1];
+    return lh0 * top + lh1 * bot;
+}
+
+// out[b, 0:Cs]      = skip[b]                      (copy)
+// out[b, Cs:Cs+Cl]  = bilinear_x2(low[b])          (low is [B,Cl,h,w], out/skip are [.,.,2h,2w])
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void up_cat_fwd_kernel(const float* __restrict__ skip, const float* __restrict__ low,
+                                                              float* __restrict__ out, int B, int Cs, int Cl, int h, int w,
+                                                              float rh, float rw) {
+    const int H = 2 * h, W = 2 * w;
+    const int Ct = Cs + Cl;
+    constexpr int V = VEC ? 4 : 1;
+    const long Wg = W / V;                               // groups per row
+    const long total = (long)B * Ct * H * Wg;
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < total; g += (long)gridDim.x * kThreads) {
+        const int xg = (int)(g % Wg);
+        long t = g / Wg;
+        const int oy = (int)(t % H); t /= H;
+        const int c = (int)(t % Ct);
+        const int b = (int)(t / Ct);
+        const long o = (((long)b * Ct + c) * H + oy) * W + (long)xg * V;
+        if (c < Cs) {
+            const long si = (((long)b * Cs + c) * H + oy) * W + (long)xg * V;
+            if (VEC) *reinterpret_cast<float4*>(out + o) = *reinterpret_cast<const float4*>(skip + si);
+            else out[o] = skip[si];
+        } else {
+            const float* p = low + ((long)b * Cl + (c - Cs)) * h * w;
+            const float sy = mul_rn(rh, (float)oy);   // rounded product, as ATen: the fraction is taken from it
+            const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
+            const float lh1 = sy - h0, lh0 = 1.f - lh1;
+            float v[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const int ox = xg * V + k;
+                const float sx = mul_rn(rw, (float)ox);
+                const int w0 = (int)sx, w1 = w0 + (w0 < w - 1 ? 1 : 0);
+                const float lw1 = sx - w0, lw0 = 1.f - lw1;
+                v[k] = bilerp(p, w, h0, h1, lh0, lh1, w0, w1, lw0, lw1);
+            }
+            if (VEC) *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            else out[o] = v[0];
+        }
+    }
+}
+
+// d_skip = dout[:, :Cs] (copy) ;  d_low = transpose of the interpolation applied to dout[:, Cs:].
+// The transpose is a gather: low-res pixel (iy, ix) collects from the output rows/cols whose source
+// index touches it, so no atomics and a fixed summation order.
+__global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* __restrict__ dout, float* __restrict__ dlow, int B,
+                                                                  int Cs, int Cl, int h, int w, float rh, float rw) {
+    const int H = 2 * h, W = 2 * w, Ct = Cs + Cl;
+    const long total = (long)B * Cl * h * w;
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < total; g += (long)gridDim.x * kThreads) {
+        const int ix = (int)(g % w);
+        long t = g / w;
+        const int iy = (int)(t % h); t /= h;
+        const int c = (int)(t % Cl);
+        const int b = (int)(t / Cl);
+        const float* p = dout + (((long)b * Ct + Cs + c) * H) * W;
+        // candidate output rows: src = rh*oy in (iy-1, iy+1)
+        int oy_lo = 2 * iy - 3, oy_hi = 2 * iy + 3, ox_lo = 2 * ix - 3, ox_hi = 2 * ix + 3;
+        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+        oy_hi = oy_hi > H - 1 ? H - 1 : oy_hi; ox_hi = ox_hi > W - 1 ? W - 1 : ox_hi;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const float sy = mul_rn(rh, (float)oy);   // rounded product, as ATen: the fraction is taken from it
+            const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
+            const float lh1 = sy - h0, lh0 = 1.f - lh1;
+            const float wy = (h0 == iy ? lh0 : 0.f) + (h1 == iy ? lh1 : 0.f);
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const float sx = mul_rn(rw, (float)ox);
+                const int w0 = (int)sx, w1 = w0 + (w0 < w - 1 ? 1 : 0);
+                const float lw1 = sx - w0, lw0 = 1.f - lw1;
+                const float wx = (w0 == ix ? lw0 : 0.f) + (w1 == ix ? lw1 : 0.f);
+                if (wx != 0.f) row += wx * p[(long)oy * W + ox];
+            }
+            acc += wy * row;
+        }
+        dlow[g] = acc;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void slice_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                                  int Ct, int c0, int Cn, long HW) {
+    constexpr int V = VEC ? 4 : 1;
+    const long per = HW / V;
+    const long total = (long)B * Cn * per;
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < total; g += (long)gridDim.x * kThreads) {
+        const long i = g % per;
+        const long t = g / per;
+        const int c = (int)(t % Cn);
+        const int b = (int)(t / Cn);
+        const long s = (((long)b * Ct + c0 + c) * HW) + i * V, d = (((long)b * Cn + c) * HW) + i * V;
+        if (VEC) *reinterpret_cast<float4*>(dst + d) = *reinterpret_cast<const float4*>(src + s);
+        else dst[d] = src[s];
+    }
+}
+}  // namespace
+
+extern "C" int uaps_up_cat_fwd(const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w,
+                               uaps_stream_t stream) {
+    if (!skip || !low || !out || B <= 0 || Cs < 0 || Cl <= 0 || h <= 0 || w <= 0) return UAPS_EINVAL;
+    const int H = 2 * h, W = 2 * w;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)B * (Cs + Cl) * H * W;
+    if (W % 4 == 0 && al16(skip) && al16(out))
+        hipLaunchKernelGGL(up_cat_fwd_kernel<true>, dim3(grid_for(total / 4)), dim3(kThreads), 0, s, skip, low, out, B, Cs, Cl, h, w, rh, rw);
+    else
+        hipLaunchKernelGGL(up_cat_fwd_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0, s, skip, low, out, B, Cs, Cl, h, w, rh, rw);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs, int Cl, int h, int w,
+                               uaps_stream_t stream) {
+    if (!dout || !dlow || B <= 0 || Cs < 0 || Cl <= 0 || h <= 0 || w <= 0) return UAPS_EINVAL;
+    const int H = 2 * h, W = 2 * w;
+    const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    if (dskip && Cs > 0) {
+        const long HW = (long)H * W;
+        if (HW % 4 == 0 && al16(dout) && al16(dskip))
+            hipLaunchKernelGGL(slice_channels_kernel<true>, dim3(grid_for((long)B * Cs * HW / 4)), dim3(kThreads), 0, s, dout, dskip, B, Cs + Cl, 0, Cs, HW);
+        else
+            hipLaunchKernelGGL(slice_channels_kernel<false>, dim3(grid_for((long)B * Cs * HW)), dim3(kThreads), 0, s, dout, dskip, B, Cs + Cl, 0, Cs, HW);
+    }
+    hipLaunchKernelGGL(up_cat_bwd_low_kernel, dim3(grid_for((long)B * Cl * h * w)), dim3(kThreads), 0, s, dout, dlow, B, Cs, Cl, h, w, rh, rw);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,163 @@
+"""Host side of the ConvBlock / UpBlock glue kernels (csrc/norm_act.hip, csrc/resample.hip):
+fused BatchNorm(train) + LeakyReLU + Dropout and bilinear-x2 + channel concat, with their backwards.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .perturb import _RngState
+
+_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    key = (dev.index, _lib.current_stream(dev))
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _ws[key] = w
+    return w
+
+
+def _bn_ws(dev, B, Cc, H, W):
+    n = C.c_size_t()
+    _lib.check(_lib.lib().uaps_bn_workspace_bytes(B, Cc, H, W, C.byref(n)), "uaps_bn_workspace_bytes")
+    return _workspace(dev, n.value)
+
+
+class _BnActTrain(torch.autograd.Function):
+    """y (conv output, no bias) -> dropout(leaky_relu(batch_norm_train(y + conv_bias)))."""
+
+    @staticmethod
+    def forward(ctx, y, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, drop_p, seed, offset):
+        _lib.require_device(y, "bn_act")
+        y = y.contiguous()
+        B, Cc, H, W = y.shape
+        dev = y.device
+        out = torch.empty_like(y)
+        stats = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        ws = _bn_ws(dev, B, Cc, H, W)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().uaps_bn_act_fwd_train(
+                y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
+                running_mean.data_ptr() if running_mean is not None else None,
+                running_var.data_ptr() if running_var is not None else None,
+                nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), float(slope), float(drop_p),
+                seed, offset, B, Cc, H, W, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_bn_act_fwd_train")
+        ctx.save_for_backward(y, gamma, beta, stats)
+        ctx.meta = (float(slope), float(drop_p), seed, offset, conv_bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, stats = ctx.saved_tensors
+        slope, drop_p, seed, offset, has_bias = ctx.meta
+        dout = dout.contiguous()
+        B, Cc, H, W = y.shape
+        dev = y.device
+        dy = torch.empty_like(y)
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        ws = _bn_ws(dev, B, Cc, H, W)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().uaps_bn_act_bwd(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                            stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B, Cc,
+                                            H, W, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
+                                            ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_bn_act_bwd")
+        # the conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (sum of dy over a channel)
+        dbias = torch.zeros_like(gamma) if has_bias else None
+        return dy, dbias, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+
+
+class _BnActEval(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, conv_bias, gamma, beta, running_mean, running_var, eps, slope):
+        _lib.require_device(y, "bn_act")
+        y = y.contiguous()
+        B, Cc, H, W = y.shape
+        dev = y.device
+        out = torch.empty_like(y)
+        mean_eff = torch.empty(Cc, dtype=torch.float32, device=dev)
+        ws = _bn_ws(dev, B, Cc, H, W)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().uaps_bn_act_fwd_eval(y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None,
+                                                 gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
+                                                 running_var.data_ptr(), float(eps), float(slope), B, Cc, H, W,
+                                                 out.data_ptr(), mean_eff.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _lib.current_stream(dev))
+        _lib.check(rc, "uaps_bn_act_fwd_eval")
+        ctx.save_for_backward(y, gamma, beta, mean_eff, running_var)
+        ctx.meta = (float(eps), float(slope))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, beta, mean_eff, rv = ctx.saved_tensors
+        eps, slope = ctx.meta
+        dout = dout.contiguous()
+        B, Cc, H, W = y.shape
+        dy = torch.empty_like(y)
+        ws = _bn_ws(y.device, B, Cc, H, W)
+        with torch.cuda.device(y.device):
+            rc = _lib.lib().uaps_bn_act_bwd_eval(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 mean_eff.data_ptr(), rv.data_ptr(), eps, slope, B, Cc, H, W, dy.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _lib.current_stream(y.device))
+        _lib.check(rc, "uaps_bn_act_bwd_eval")
+        # parameters are not trained through an eval() forward in the reference; only the input gradient is provided
+        return dy, None, None, None, None, None, None, None
+
+
+def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, slope: float, drop_p: float,
+           training: bool) -> torch.Tensor:
+    """dropout_p(leaky_relu(bn(y + conv_bias))) with nn.BatchNorm2d / nn.LeakyReLU / nn.Dropout semantics
+    (UAPS_unet.py:38-40), as three streaming kernels."""
+    if training or not bn.track_running_stats:
+        p = float(drop_p) if training else 0.0
+        seed, off = _RngState.reserve(y.numel()) if p > 0 else (0, 0)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        return _BnActTrain.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                 mom, bn.eps, slope, p, seed, off)
+    return _BnActEval.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, slope)
+
+
+class _UpCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, low):
+        _lib.require_device(low, "up_cat")
+        skip, low = skip.contiguous(), low.contiguous()
+        B, Cl, h, w = low.shape
+        Cs = skip.shape[1]
+        if skip.shape != (B, Cs, 2 * h, 2 * w):
+            raise ValueError(f"skip {tuple(skip.shape)} is not twice the size of low {tuple(low.shape)}")
+        out = torch.empty((B, Cs + Cl, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
+        with torch.cuda.device(low.device):
+            rc = _lib.lib().uaps_up_cat_fwd(skip.data_ptr(), low.data_ptr(), out.data_ptr(), B, Cs, Cl, h, w,
+                                            _lib.current_stream(low.device))
+        _lib.check(rc, "uaps_up_cat_fwd")
+        ctx.meta = (B, Cs, Cl, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Cs, Cl, h, w = ctx.meta
+        dout = dout.contiguous()
+        need_skip = ctx.needs_input_grad[0]
+        dskip = torch.empty((B, Cs, 2 * h, 2 * w), dtype=torch.float32, device=dout.device) if need_skip else None
+        dlow = torch.empty((B, Cl, h, w), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            rc = _lib.lib().uaps_up_cat_bwd(dout.data_ptr(), dskip.data_ptr() if need_skip else None, dlow.data_ptr(), B, Cs,
+                                            Cl, h, w, _lib.current_stream(dout.device))
+        _lib.check(rc, "uaps_up_cat_bwd")
+        return dskip, dlow
+
+
+def up_cat(skip: torch.Tensor, low: torch.Tensor) -> torch.Tensor:
+    """torch.cat([skip, Upsample(x2, bilinear, align_corners=True)(low)], dim=1)  (UAPS_unet.py:83-85)."""
+    return _UpCat.apply(skip, low)

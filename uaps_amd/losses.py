@@ -116,10 +116,10 @@ class _UnsupLoss(torch.autograd.Function):
         ctx.save_for_backward(pseudo, scalars, *zs)
         ctx.meta = (D, B, Cc, H, W, float(cw1), float(cw2))
         loss = scalars[off["loss"]].clone()
-        ctx.mark_non_differentiable(pseudo, scalars)
         if want_var:
-            ctx.mark_non_differentiable(var)
+            ctx.mark_non_differentiable(pseudo, var, scalars)
             return loss, pseudo, var, scalars
+        ctx.mark_non_differentiable(pseudo, scalars)
         return loss, pseudo, scalars
 
     @staticmethod

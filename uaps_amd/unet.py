@@ -9,8 +9,9 @@ Module tree and key names (they ARE the drop-in contract, see tests/test_model_s
   <decoder>.out_conv                             conv3x3 -> class logits    (:138-139)
   decoders: main_decoder, aux_decoder1 (FeatureNoise), aux_decoder2 (Dropout), aux_decoder3 (FeatureDropout)
 
-The convolutions/BatchNorm run through PyTorch-ROCm (MIOpen) in this round; the perturbations and
-everything after the logits are the HIP kernels of this package.
+On a ROCm device the convolutions run through MIOpen (this round) and everything between them --
+BatchNorm(train)+LeakyReLU+Dropout, bilinear-x2+concat, the three feature perturbations -- and
+everything after the logits are the HIP kernels of this package (csrc/*.hip).
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import perturb
+from . import fused, perturb
 
 FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
 ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
@@ -39,7 +40,13 @@ class ConvBlock(nn.Module):
         self.conv_conv = nn.Sequential(*layers)      # indices 0,1,4,5 carry the parameters
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.conv_conv(x)
+        if not x.is_cuda:
+            return self.conv_conv(x)                  # plain torch modules (CPU inspection / CPU-only tests)
+        # GPU: MIOpen convs without bias (train-mode BN cancels it; the fused kernel folds it into
+        # running_mean / the eval shift) + the fused BN+LeakyReLU+Dropout HIP kernels
+        c0, b0, _, d0, c1, b1, _ = self.conv_conv
+        a = fused.bn_act(F.conv2d(x, c0.weight, None, padding=1), c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
+        return fused.bn_act(F.conv2d(a, c1.weight, None, padding=1), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
 
 
 class DownBlock(nn.Module):
@@ -66,8 +73,10 @@ class UpBlock(nn.Module):
         self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
 
     def forward(self, coarse, skip):
-        up = self.up(self.conv1x1(coarse))
-        return self.conv(torch.cat([skip, up], dim=1))
+        low = self.conv1x1(coarse)
+        if not low.is_cuda:
+            return self.conv(torch.cat([skip, self.up(low)], dim=1))
+        return self.conv(fused.up_cat(skip, low))     # bilinear x2 written straight into the concat buffer
 
 
 class Encoder(nn.Module):
