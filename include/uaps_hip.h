@@ -175,6 +175,34 @@ int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs,
                     uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Convolutions of the U-Net: every nn.Conv2d of utilities/UAPS_unet.py (ConvBlock 3x3 :36-44,
+ * UpBlock.conv1x1 :73, Decoder.out_conv :138-139; stride 1, padding ks/2, ks in {1,3}), fp32 NCHW,
+ * computed on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32) as an implicit GEMM.
+ * They replace the three aten::convolution / convolution_backward calls PyTorch makes per layer.
+ *
+ * Weights are used in a packed, zero-padded layout produced by uaps_conv_pack_weights from the
+ * nn.Conv2d.weight tensor [Cout][Cin][ks][ks]:
+ *   wf [ks*ks][Kpad(Cin)][Npad(Cout)]   for the forward,
+ *   wb [ks*ks][Kpad(Cout)][Npad(Cin)]   (transposed, taps flipped) for the input gradient,
+ * sizes (in floats) from uaps_conv_pack_floats.  `cfg` = 0 selects the tiling automatically; other
+ * values are tuning overrides used by tools/bench_conv.py (low byte: output channels per workgroup,
+ * 16/32/64; bits 8-9: 1 = 8x32 pixel tile, 2 = 16x16; for bwd_weight: number of pixel splits).
+ * ------------------------------------------------------------------------------------------- */
+int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);
+int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream);
+/* y [B,Cout,H,W] = conv2d(x [B,Cin,H,W], w) (+ bias[Cout] if bias != NULL) */
+int uaps_conv_fwd(const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout, int H,
+                  int W, int ks, int cfg, uaps_stream_t stream);
+/* dx [B,Cin,H,W] = conv_transpose2d(dy [B,Cout,H,W], w) */
+int uaps_conv_bwd_data(const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H, int W,
+                       int ks, int cfg, uaps_stream_t stream);
+/* dw [Cout][Cin][ks][ks] = sum over batch and pixels of dy (x) x ; dbias [Cout] = sum dy (may be NULL).
+ * Partial sums per pixel split go to the workspace and are reduced in a fixed order (deterministic). */
+int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks, int cfg, size_t* out_host);
+int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int Cin, int Cout, int H,
+                         int W, int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Metrics: utilities/metrics.py:8-61 (pixel_accuracy, mIoU, mDice) need only the C x C confusion
  * matrix of arg-max(logits) against the labels: counts[t*C + p], int64, overwritten.
  * ------------------------------------------------------------------------------------------- */

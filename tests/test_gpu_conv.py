@@ -1,0 +1,93 @@
+"""GPU parity of the hand-written convolution kernels (csrc/conv_kernels.hpp) against plain PyTorch
+fp32 convolutions evaluated on the CPU (the arithmetic the reference's nn.Conv2d layers perform,
+utilities/UAPS_unet.py:37,41,73,138).  Tolerance: fp32 sums of K = 9*Cin (forward), 9*Cout (input
+gradient) or B*H*W (weight gradient) products in a different order -> 2e-5 of the output scale."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (B, Cin, Cout, H, W, ks)
+SHAPES = [
+    (2, 3, 16, 32, 32, 3),      # first encoder conv (Cin padded to 4)
+    (2, 16, 16, 64, 64, 3),
+    (1, 32, 16, 40, 72, 3),     # concat conv, partial tiles in both directions
+    (2, 16, 4, 32, 32, 3),      # out_conv, C=4
+    (1, 16, 7, 16, 48, 3),      # out_conv, DAGM C=7
+    (1, 16, 2, 24, 20, 3),      # narrow map (16x16 tile path), C=2
+    (2, 64, 64, 16, 16, 3),
+    (1, 128, 256, 16, 16, 3),
+    (2, 256, 128, 16, 16, 1),   # UpBlock conv1x1
+    (2, 32, 16, 64, 64, 1),
+    (1, 20, 40, 18, 18, 3),     # channel counts that are not multiples of the tile sizes
+    (1, 24, 24, 10, 10, 1),
+]
+
+
+def _mk(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", SHAPES)
+def test_conv_forward_backward_vs_torch_cpu(B, Cin, Cout, H, W, ks):
+    from uaps_amd.conv import conv2d
+    x = _mk((B, Cin, H, W), 1)
+    w = _mk((Cout, Cin, ks, ks), 2) / np.sqrt(Cin * ks * ks)
+    b = _mk((Cout,), 3)
+    dy = _mk((B, Cout, H, W), 4)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=ks // 2)
+    yr.backward(dy)
+    dev = torch.device("cuda:0")
+    xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = conv2d(xg, wg, bg)
+    y.backward(dy.to(dev))
+
+    def close(a, ref, what):
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((a.cpu() - ref).abs().max())
+        assert err <= 2e-5 * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+    close(y.detach(), yr.detach(), "y")
+    close(xg.grad, xr.grad, "dx")
+    close(wg.grad, wr.grad, "dw")
+    close(bg.grad, br.grad, "db")
+
+
+def test_conv_no_bias_and_cached_pack_follows_inplace_updates():
+    from uaps_amd.conv import conv2d
+    dev = torch.device("cuda:0")
+    x = _mk((1, 8, 16, 16), 5).to(dev)
+    w = torch.nn.Parameter(_mk((8, 8, 3, 3), 6).to(dev))
+    y0 = conv2d(x, w)
+    assert torch.allclose(y0.cpu(), F.conv2d(x.cpu(), w.detach().cpu(), padding=1), atol=1e-4)
+    with torch.no_grad():
+        w.mul_(2.0)                      # what optimizer.step() does: in-place update -> version bump -> repack
+    y1 = conv2d(x, w)
+    assert torch.allclose(y1, 2 * y0, rtol=1e-6, atol=1e-6)
+
+
+def test_conv_is_deterministic():
+    from uaps_amd.conv import conv2d
+    dev = torch.device("cuda:0")
+    x = _mk((2, 32, 32, 32), 7).to(dev).requires_grad_(True)
+    w = _mk((32, 32, 3, 3), 8).to(dev).requires_grad_(True)
+    dy = _mk((2, 32, 32, 32), 9).to(dev)
+    outs = []
+    for _ in range(2):
+        x.grad = w.grad = None
+        y = conv2d(x, w)
+        y.backward(dy)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)          # no float atomics anywhere: bitwise reproducible
+
+
+def test_conv_refuses_cpu_tensors():
+    from uaps_amd.conv import conv2d
+    from uaps_amd._lib import UapsHipError
+    with pytest.raises(UapsHipError):
+        conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))

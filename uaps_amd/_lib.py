@@ -44,6 +44,12 @@ SIGNATURES = {
     "uaps_bn_act_bwd_eval": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_int] * 4 + [_PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_up_cat_fwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 5 + [_PTR]),
     "uaps_up_cat_bwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 5 + [_PTR]),
+    "uaps_conv_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "uaps_conv_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
+    "uaps_conv_fwd": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_bwd_data": (C.c_int, [_PTR] * 3 + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_wrw_workspace_bytes": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_size_t)]),
+    "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 
