@@ -15,6 +15,6 @@ from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, metrics_from_co
 from .unet import UNet, UNet_UAPS
 from .net_factory import net_factory
 from .trainer import UAPSTrainer
-from . import data, dist
+from . import conv, data, dist
 
 __all__ = [n for n in dir() if not n.startswith("_")]

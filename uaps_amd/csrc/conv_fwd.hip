@@ -7,30 +7,29 @@ using namespace uaps;
 namespace {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-inline int kdim_pad(int c) { return c <= 4 ? 4 : round_up(c, 8); }   // K (contraction) channels: chunk of 4 or 8
+inline int kdim_pad(int c, int ks) { return (ks == 3 && c <= 4) ? 4 : round_up(c, 8); }   // K (contraction) channels: chunk of 4 or 8
 inline int ndim_pad(int c) { return round_up(c, 16); }              // N (output) channels: 16-wide MFMA tiles
 
 template <int KS, int TH, int TW, int BN, int CK>
-int launch_fwd(ConvFwdArgs a, hipStream_t s) {
+int launch_fwd(ConvFwdArgs a, bool vec, hipStream_t s) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     a.nblk = a.CoutP / BN;
-    const long grid = (long)a.B * a.tiles_x * a.tiles_y * a.nblk;
+    const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;   // multiple of 8 for the XCD swizzle
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
-    hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 
 template <int KS, int TH, int TW>
-int dispatch_bn_ck(const ConvFwdArgs& a, int bn, int ck, hipStream_t s) {
-    if (ck == 4) {
-        if (bn == 16) return launch_fwd<KS, TH, TW, 16, 4>(a, s);
-        if (bn == 32) return launch_fwd<KS, TH, TW, 32, 4>(a, s);
-        return launch_fwd<KS, TH, TW, 64, 4>(a, s);
+int dispatch_bn_ck(const ConvFwdArgs& a, int bn, int ck, bool vec, hipStream_t s) {
+    if constexpr (KS == 3) {
+        if (ck == 4) return launch_fwd<KS, TH, TW, 16, 4>(a, vec, s);
     }
-    if (bn == 16) return launch_fwd<KS, TH, TW, 16, 8>(a, s);
-    if (bn == 32) return launch_fwd<KS, TH, TW, 32, 8>(a, s);
-    return launch_fwd<KS, TH, TW, 64, 8>(a, s);
+    if (bn == 16) return launch_fwd<KS, TH, TW, 16, 8>(a, vec, s);
+    if (bn == 32) return launch_fwd<KS, TH, TW, 32, 8>(a, vec, s);
+    return launch_fwd<KS, TH, TW, 64, 8>(a, vec, s);
 }
 
 // x [B,Cin,H,W] * packed weights [taps][CinP][CoutP] -> y [B,Cout,H,W]
@@ -38,10 +37,13 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
                  int cfg, hipStream_t s) {
     if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
+    if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     ConvFwdArgs a{};
     a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    a.CinP = kdim_pad(Cin); a.CoutP = ndim_pad(Cout);
-    const int ck = Cin <= 4 ? 4 : 8;
+    a.CinP = kdim_pad(Cin, ks); a.CoutP = ndim_pad(Cout);
+    const int ck = (ks == 3 && Cin <= 4) ? 4 : 8;
+    // 16-byte loads/stores need rows that start 16-byte aligned
+    const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     // pixel tile: 8 rows x 32 columns, or 16 x 16 for narrow maps (both 256 pixels = 16 M tiles)
     const bool wide = (cfg >> 8) ? ((cfg >> 8) == 1) : (W >= 32);
     const int TH = wide ? 8 : 16, TW = wide ? 32 : 16;
@@ -49,8 +51,9 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     const long tiles = (long)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     while (bn > 16 && tiles * (a.CoutP / bn) < 512) bn /= 2;       // at least two workgroups per CU
     if (cfg & 0xff) { bn = cfg & 0xff; if ((bn != 16 && bn != 32 && bn != 64) || a.CoutP % bn) return UAPS_EINVAL; }
-    if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, bn, ck, s) : dispatch_bn_ck<3, 16, 16>(a, bn, ck, s);
-    return wide ? dispatch_bn_ck<1, 8, 32>(a, bn, ck, s) : dispatch_bn_ck<1, 16, 16>(a, bn, ck, s);
+    if (ck == 4) bn = 16;
+    if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, bn, ck, vec, s) : dispatch_bn_ck<3, 16, 16>(a, bn, ck, vec, s);
+    return wide ? dispatch_bn_ck<1, 8, 32>(a, bn, ck, vec, s) : dispatch_bn_ck<1, 16, 16>(a, bn, ck, vec, s);
 }
 
 }  // namespace
@@ -58,18 +61,18 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
 extern "C" int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats, size_t* bwd_floats) {
     if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) return UAPS_EINVAL;
     const size_t taps = (size_t)ks * ks;
-    if (fwd_floats) *fwd_floats = taps * kdim_pad(Cin) * ndim_pad(Cout);
-    if (bwd_floats) *bwd_floats = taps * kdim_pad(Cout) * ndim_pad(Cin);
+    if (fwd_floats) *fwd_floats = taps * kdim_pad(Cin, ks) * ndim_pad(Cout);
+    if (bwd_floats) *bwd_floats = taps * kdim_pad(Cout, ks) * ndim_pad(Cin);
     return UAPS_OK;
 }
 
 extern "C" int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream) {
     if (!w || Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3) || (!wf && !wb)) return UAPS_EINVAL;
     const int taps = ks * ks;
-    const long n = (long)taps * (kdim_pad(Cin) * ndim_pad(Cout) + kdim_pad(Cout) * ndim_pad(Cin));
+    const long n = (long)taps * (kdim_pad(Cin, ks) * ndim_pad(Cout) + kdim_pad(Cout, ks) * ndim_pad(Cin));
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wf, wb, Cout, Cin, taps,
-                       kdim_pad(Cin), ndim_pad(Cout), kdim_pad(Cout), ndim_pad(Cin));
+                       kdim_pad(Cin, ks), ndim_pad(Cout), kdim_pad(Cout, ks), ndim_pad(Cin));
     return (int)hipGetLastError();
 }
 

@@ -7,8 +7,10 @@
 //
 // GEMM view, forward / input-gradient:  M = pixels, N = output channels, K = (input channel, tap).
 //   * a workgroup (4 waves) owns a TH x TW pixel tile of one image and BN output channels;
-//   * per K-chunk of CK input channels the haloed input tile [CK][TH+2][TW+2] and the weight chunk
-//     [taps][CK][BN] are staged in LDS (register prefetch of the next chunk under the MFMAs);
+//   * per K-chunk of CK input channels the haloed input tile and the weight chunk [taps][CK][BN] are
+//     staged in LDS; the next chunk is fetched into registers (branch-free buffer loads whose range
+//     check supplies the zero padding) while the MFMAs of the current chunk run;
+//   * staged rows start 4 floats left of the tile so that every global load and LDS store is 16 B;
 //   * NCHW makes the MFMA A operand (16 consecutive pixels of one input-channel plane, shifted by the
 //     tap) a conflict-free ds_read_b32: lanes 0-15 walk one row of the plane, the four 16-lane
 //     groups take four consecutive channels, plane stride == 16 (mod 32) dwords;
@@ -28,11 +30,77 @@
 namespace uaps {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kConvThreads = 256;
+constexpr uint32_t kOob = 0x80000000u;   // byte offset no tensor of < 2 GiB reaches: buffer loads return 0
 
 // smallest s >= n with s % 32 == r
 constexpr int pad_to_mod32(int n, int r) { return n + ((r - n % 32) + 32) % 32; }
+
+// Geometry of a staged (haloed) pixel tile: rows start XOFF floats left of the tile so that the row
+// base is 16-byte aligned in global memory (tile origins are multiples of 16 pixels).
+template <int KS, int TH, int TW> struct TileGeom {
+    static constexpr int PAD = KS / 2;
+    static constexpr int XOFF = PAD ? 4 : 0;
+    static constexpr int IH = TH + 2 * PAD;
+    static constexpr int IW = TW + 2 * XOFF;
+    static constexpr int PLANE = IH * IW;
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Map the hardware
+// block id to a logical id such that each XCD works on one contiguous range of logical ids: tiles
+// that share halo rows / cache lines then meet in one L2.  The launch grid is rounded up to a
+// multiple of 8; logical ids >= total exit.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_swizzle(int bid, int grid8) { return (bid % 8) * (grid8 / 8) + bid / 8; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <int VEC> __device__ __forceinline__ void buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t off, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+    }
+}
+// LDS store of VEC floats; ALIGN16: the address is 16-byte aligned (else 8-byte for VEC == 4)
+template <int VEC, bool ALIGN16> __device__ __forceinline__ void lds_store(float* p, const float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        if constexpr (ALIGN16) {
+            *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+            *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
+        }
+    } else {
+        p[0] = v[0];
+    }
+}
+
+// Per-thread plan for staging NPL planes of a TileGeom tile in units of VEC floats:
+// unit u = tid + n*256 -> (plane c, row r, unit xu).  goff = byte offset inside the image's channel
+// block (or kOob for padding / beyond the tile), loff = LDS float offset (or -1).
+template <class G, int NPL, int VEC, int PS> struct StagePlan {
+    static constexpr int UPR = G::IW / VEC, UPP = G::IH * UPR, NUNITS = NPL * UPP;
+    static constexpr int NT = (NUNITS + kConvThreads - 1) / kConvThreads;
+    uint32_t goff[NT];
+    int loff[NT];
+    __device__ __forceinline__ void make(int tid, int y0, int x0, int H, int W) {
+        const int HW = H * W;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int u = tid + n * kConvThreads;
+            const int c = u / UPP, rem = u % UPP, r = rem / UPR, xu = rem % UPR;
+            const int gy = y0 - G::PAD + r, gx = x0 - G::XOFF + xu * VEC;
+            const bool inside = u < NUNITS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            goff[n] = inside ? (uint32_t)(c * HW + gy * W + gx) * 4u : kOob;
+            loff[n] = u < NUNITS ? c * PS + r * G::IW + xu * VEC : -1;
+        }
+    }
+};
 
 struct ConvFwdArgs {
     const float* in;    // [B, Cin, H, W]
@@ -44,37 +112,26 @@ struct ConvFwdArgs {
     int tiles_x, tiles_y, nblk;
 };
 
-template <int KS, int TH, int TW, int BN, int CK> struct FwdCfg {
-    static constexpr int PAD = KS / 2;
-    static constexpr int TAPS = KS * KS;
-    static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD;
-    static constexpr int PS = pad_to_mod32(IH * IW, 16);   // input plane stride in LDS (dwords)
-    static constexpr int BNS = pad_to_mod32(BN, 16);        // weight row stride in LDS (dwords)
-    static constexpr int MT = TH * TW / 16;                 // 16-pixel M tiles per workgroup
-    static constexpr int MW = MT / 4;                       // ... per wave
-    static constexpr int NW = BN / 16;                      // 16-channel N tiles (every wave computes all)
-    static constexpr int XB = TW / 16;
-    static constexpr int NIN = CK * IH * IW;
-    static constexpr int NIN_T = (NIN + kConvThreads - 1) / kConvThreads;
-    static constexpr int NWT = TAPS * CK * BN;              // weight chunk, floats
-    static constexpr int NWT_T4 = (NWT / 4 + kConvThreads - 1) / kConvThreads;   // float4 loads per thread
-    static constexpr int LDS_FLOATS = CK * PS + TAPS * CK * BNS;
-};
-
-template <int KS, int TH, int TW, int BN, int CK>
+template <int KS, int TH, int TW, int BN, int CK, int VEC>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a) {
-    using Cfg = FwdCfg<KS, TH, TW, BN, CK>;
-    constexpr int PAD = Cfg::PAD, TAPS = Cfg::TAPS, IH = Cfg::IH, IW = Cfg::IW, PS = Cfg::PS, BNS = Cfg::BNS;
-    constexpr int MW = Cfg::MW, NW = Cfg::NW, XB = Cfg::XB, NIN = Cfg::NIN, NIN_T = Cfg::NIN_T, NWT_T4 = Cfg::NWT_T4;
-    static_assert(Cfg::MT % 4 == 0 && CK % 4 == 0 && BN % 16 == 0, "tile shape");
+    using G = TileGeom<KS, TH, TW>;
+    constexpr int TAPS = KS * KS, IW = G::IW, XS = G::XOFF - G::PAD;
+    constexpr int PS = pad_to_mod32(G::PLANE, 16);     // input plane stride in LDS (dwords)
+    constexpr int BNS = pad_to_mod32(BN, 16);           // weight row stride in LDS (dwords)
+    constexpr int MT = TH * TW / 16, MW = MT / 4, NW = BN / 16, XB = TW / 16;
+    constexpr int NWT4 = TAPS * CK * BN / 4;            // float4 units of a weight chunk
+    constexpr int NWT_T = (NWT4 + kConvThreads - 1) / kConvThreads;
+    static_assert(MT % 4 == 0 && CK % 4 == 0 && BN % 16 == 0 && PS % 4 == 0, "tile shape");
+    using Plan = StagePlan<G, CK, VEC, PS>;
 
-    __shared__ float sIn[CK * PS];
-    __shared__ float sW[TAPS * CK * BNS];
+    __shared__ __attribute__((aligned(16))) float sIn[CK * PS];
+    __shared__ __attribute__((aligned(16))) float sW[TAPS * CK * BNS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
 
-    int bid = blockIdx.x;
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (bid >= a.B * a.tiles_x * a.tiles_y * a.nblk) return;
     const int nb = bid % a.nblk; bid /= a.nblk;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
     const int ty = bid % a.tiles_y;
@@ -82,49 +139,41 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     const int y0 = ty * TH, x0 = tx * TW, co0 = nb * BN;
     const int HW = a.H * a.W;
 
-    // ---- per-thread staging plan for the input tile (chunk independent) -----------------------
-    int gofs[NIN_T];   // offset inside one chunk of the image (c*HW + gy*W + gx), -1 = zero padding
-    int lofs[NIN_T];   // c << 16 | LDS offset, -1 = no element
+    Plan plan;
+    plan.make(tid, y0, x0, a.H, a.W);
+    // weight chunk plan: float4 unit e4 -> (row = tap*CK + c, co4)
+    uint32_t wgoff[NWT_T];
+    int wloff[NWT_T];
 #pragma unroll
-    for (int n = 0; n < NIN_T; ++n) {
-        const int e = tid + n * kConvThreads;
-        const int c = e / (IH * IW), rem = e % (IH * IW), r = rem / IW, x = rem % IW;
-        const int gy = y0 - PAD + r, gx = x0 - PAD + x;
-        const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        gofs[n] = inside ? c * HW + gy * a.W + gx : -1;
-        lofs[n] = e < NIN ? ((c << 16) | (c * PS + r * IW + x)) : -1;
+    for (int n = 0; n < NWT_T; ++n) {
+        const int e4 = tid + n * kConvThreads;
+        const int co4 = e4 % (BN / 4), row = e4 / (BN / 4);
+        const int c = row % CK, tap = row / CK;
+        const bool ok = e4 < NWT4;
+        wgoff[n] = ok ? (uint32_t)((tap * a.CinP + c) * a.CoutP + co0 + co4 * 4) * 4u : kOob;
+        wloff[n] = ok ? row * BNS + co4 * 4 : -1;
     }
     const float* in_b = a.in + (size_t)b * a.Cin * HW;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)TAPS * a.CinP * a.CoutP * 4u);
 
-    float rin[NIN_T];
-    float4 rw[NWT_T4];
+    float rin[Plan::NT][VEC];
+    float rw[NWT_T][4];
 
     auto load_chunk = [&](int ci0) {
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Cin - ci0) * HW * 4u);
 #pragma unroll
-        for (int n = 0; n < NIN_T; ++n) {
-            const int c = lofs[n] >> 16;
-            const bool ok = lofs[n] >= 0 && gofs[n] >= 0 && (ci0 + c) < a.Cin;
-            rin[n] = ok ? in_b[(size_t)ci0 * HW + gofs[n]] : 0.f;
-        }
+        for (int n = 0; n < Plan::NT; ++n) buf_load<VEC>(rs_in, plan.goff[n], rin[n]);
+        const uint32_t wbase = (uint32_t)ci0 * a.CoutP * 4u;
 #pragma unroll
-        for (int n = 0; n < NWT_T4; ++n) {
-            const int e4 = tid + n * kConvThreads;          // float4 index inside the chunk [TAPS][CK][BN/4]
-            const int co4 = e4 % (BN / 4), row = e4 / (BN / 4);
-            const int c = row % CK, tap = row / CK;
-            if (e4 < Cfg::NWT / 4)
-                rw[n] = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.CinP + ci0 + c) * a.CoutP + co0 + co4 * 4);
-        }
+        for (int n = 0; n < NWT_T; ++n) buf_load<4>(rs_w, wgoff[n] + wbase, rw[n]);
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int n = 0; n < NIN_T; ++n)
-            if (lofs[n] >= 0) sIn[lofs[n] & 0xffff] = rin[n];
+        for (int n = 0; n < Plan::NT; ++n)
+            if (plan.loff[n] >= 0) lds_store<VEC, true>(&sIn[plan.loff[n]], rin[n]);
 #pragma unroll
-        for (int n = 0; n < NWT_T4; ++n) {
-            const int e4 = tid + n * kConvThreads;
-            const int co4 = e4 % (BN / 4), row = e4 / (BN / 4);
-            if (e4 < Cfg::NWT / 4) *reinterpret_cast<float4*>(&sW[row * BNS + co4 * 4]) = rw[n];
-        }
+        for (int n = 0; n < NWT_T; ++n)
+            if (wloff[n] >= 0) lds_store<4, true>(&sW[wloff[n]], rw[n]);
     };
 
     f32x4 acc[MW][NW];
@@ -133,12 +182,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
 #pragma unroll
         for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // A operand base: plane kq, pixel j of this wave's first M tile; B operand base: row kq, column j
+    // A operand base: plane kq, pixel j of this wave's M tiles; B operand base: row kq, column j
     int aoff[MW];
 #pragma unroll
     for (int m = 0; m < MW; ++m) {
         const int mt = wave * MW + m;
-        aoff[m] = kq * PS + (mt / XB) * IW + (mt % XB) * 16 + j;
+        aoff[m] = kq * PS + (mt / XB) * IW + (mt % XB) * 16 + j + XS;
     }
     const int boff = kq * BNS + j;
 
@@ -172,7 +221,6 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     }
 
     // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every tile ------------
-    const bool vec_ok = (a.W % 4) == 0;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         const int co = co0 + n * 16 + j;
@@ -187,8 +235,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
             f32x4 v = acc[m][n];
             v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             float* p = out_c + (size_t)gy * a.W + gx;
-            if (vec_ok && gx + 3 < a.W) {
-                *reinterpret_cast<float4*>(p) = float4{v.x, v.y, v.z, v.w};
+            if (VEC == 4) {                       // W % 4 == 0: the 4 pixels are all inside or all outside
+                if (gx < a.W) *reinterpret_cast<f32x4*>(p) = v;
             } else {
                 if (gx + 0 < a.W) p[0] = v.x;
                 if (gx + 1 < a.W) p[1] = v.y;
@@ -201,11 +249,12 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
 
 // -------------------------------------------------------------------------------------------------
 // Weight gradient.  dw[co][ci][tap] = sum_{b,y,x} dout[b][co][y][x] * in[b][ci][y+ky-PAD][x+kx-PAD].
-// A workgroup owns a (BCO x BCI) channel block and every `nsplit`-th pixel tile; its 4 waves take
-// different rows of each tile (K split), are summed through LDS at the end, and wave 0 writes the
-// block into slab[split][tap][CoutS][CinS].  conv_wrw_reduce_kernel sums the splits.
-// LDS: sD[BCO][TH*TW] (plane stride == 2 mod 32: lanes = 16 channels x 2 pixels hit 32 banks) and
-// sI[BCI][(TH+2)(TW+2)] likewise.
+// A workgroup owns a (16*WCO x 16*WCI) channel block and every `nsplit`-th pixel tile.  Its 4 waves
+// are arranged WCO x WCI x WK: wave (wco, wci, wk) accumulates the 16x16 block (wco, wci) for all
+// taps over the tile rows wk, wk+WK, ...; the WK partial accumulators are summed through LDS at the
+// end and written to slab[split][tap][CoutS][CinS].  conv_wrw_reduce_kernel sums the splits.
+// LDS: sD[16*WCO][TH*TW] and sI[16*WCI][haloed tile], plane strides == 2 (mod 32) so that the
+// 16 channels x 2 pixels of a 32-lane group hit 32 different banks.
 // -------------------------------------------------------------------------------------------------
 struct ConvWrwArgs {
     const float* dout;  // [B, Cout, H, W]
@@ -217,33 +266,40 @@ struct ConvWrwArgs {
     int tiles_x, tiles_y, ncob, ncib, nsplit;
 };
 
-template <int KS, int TH, int TW, int MWC, int NWC> struct WrwCfg {
-    static constexpr int PAD = KS / 2, TAPS = KS * KS;
-    static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * PAD;
-    static constexpr int BCO = 16 * MWC, BCI = 16 * NWC;
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC> struct WrwCfg {
+    using G = TileGeom<KS, TH, TW>;
+    using GD = TileGeom<1, TH, TW>;
+    static constexpr int WK = 4 / (WCO * WCI);
+    static constexpr int TAPS = KS * KS;
+    static constexpr int BCO = 16 * WCO, BCI = 16 * WCI;
     static constexpr int PSD = pad_to_mod32(TH * TW, 2);
-    static constexpr int PSI = pad_to_mod32(IH * IW, 2);
-    static constexpr int ND = BCO * TH * TW, NI = BCI * IH * IW;
+    static constexpr int PSI = pad_to_mod32(G::PLANE, 2);
     static constexpr int STAGE_FLOATS = BCO * PSD + BCI * PSI;
-    static constexpr int RED_FLOATS = 2 * TAPS * MWC * NWC * 256 + 2 * MWC * 256;   // two waves' accumulators
+    static constexpr int RED_FLOATS = (WK / 2) * WCO * WCI * (TAPS + 1) * 256;
     static constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
 };
 
-template <int KS, int TH, int TW, int MWC, int NWC, bool BIAS>
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a) {
-    using Cfg = WrwCfg<KS, TH, TW, MWC, NWC>;
-    constexpr int PAD = Cfg::PAD, TAPS = Cfg::TAPS, IH = Cfg::IH, IW = Cfg::IW, BCO = Cfg::BCO, BCI = Cfg::BCI;
-    constexpr int PSD = Cfg::PSD, PSI = Cfg::PSI, ND = Cfg::ND, NI = Cfg::NI;
-    static_assert(TH % 4 == 0 && TW % 4 == 0, "tile shape");
+    using Cfg = WrwCfg<KS, TH, TW, WCO, WCI, VEC>;
+    using G = typename Cfg::G;
+    using GD = typename Cfg::GD;
+    constexpr int WK = Cfg::WK, TAPS = Cfg::TAPS, IW = G::IW, XS = G::XOFF - G::PAD;
+    constexpr int BCO = Cfg::BCO, BCI = Cfg::BCI, PSD = Cfg::PSD, PSI = Cfg::PSI;
+    static_assert(WCO * WCI * WK == 4 && TH % WK == 0 && TW % 4 == 0, "wave arrangement");
+    using PlanD = StagePlan<GD, BCO, VEC, PSD>;
+    using PlanI = StagePlan<G, BCI, VEC, PSI>;
 
-    __shared__ float smem[Cfg::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
     float* sD = smem;
     float* sI = smem + BCO * PSD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
+    const int wk = wave % WK, wci = (wave / WK) % WCI, wco = wave / (WK * WCI);
 
-    int bid = blockIdx.x;
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (bid >= a.nsplit * a.ncob * a.ncib) return;
     const int cib = bid % a.ncib; bid /= a.ncib;
     const int cob = bid % a.ncob;
     const int split = bid / a.ncob;
@@ -251,160 +307,154 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
     const int HW = a.H * a.W;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = a.B * tiles_per_img;
+    // this split's contiguous tile range (neighbouring tiles share halo cache lines)
+    const int t_begin = (int)((long)ntiles * split / a.nsplit), t_end = (int)((long)ntiles * (split + 1) / a.nsplit);
+    const bool want_bias = a.bslab != nullptr && cib == 0;
 
-    f32x4 acc[TAPS][MWC][NWC];
-    f32x4 accb[MWC];
+    f32x4 acc[TAPS];
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int m = 0; m < MWC; ++m)
-#pragma unroll
-            for (int n = 0; n < NWC; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < MWC; ++m) accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int t = split; t < ntiles; t += a.nsplit) {
+    PlanD pd;
+    PlanI pi;
+    float rd[PlanD::NT][VEC];
+    float ri[PlanI::NT][VEC];
+
+    auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         const int y0 = (tt / a.tiles_x) * TH, x0 = (tt % a.tiles_x) * TW;
-        const float* dout_b = a.dout + ((size_t)b * a.Cout + co0) * HW;
-        const float* in_b = a.in + ((size_t)b * a.Cin + ci0) * HW;
-        __syncthreads();   // previous tile's reads are done
-        // ---- stage dout tile -----------------------------------------------------------------
-        for (int e = tid; e < ND; e += kConvThreads) {
-            const int c = e / (TH * TW), rem = e % (TH * TW), r = rem / TW, x = rem % TW;
-            const int gy = y0 + r, gx = x0 + x;
-            const bool ok = (co0 + c) < a.Cout && gy < a.H && gx < a.W;
-            sD[c * PSD + rem] = ok ? dout_b[(size_t)c * HW + gy * a.W + gx] : 0.f;
-        }
-        // ---- stage haloed input tile -----------------------------------------------------------
-        for (int e = tid; e < NI; e += kConvThreads) {
-            const int c = e / (IH * IW), rem = e % (IH * IW), r = rem / IW, x = rem % IW;
-            const int gy = y0 - PAD + r, gx = x0 - PAD + x;
-            const bool ok = (ci0 + c) < a.Cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            sI[c * PSI + rem] = ok ? in_b[(size_t)c * HW + gy * a.W + gx] : 0.f;
-        }
-        __syncthreads();
-        // ---- MFMAs: wave w takes rows w, w+4, ... ----------------------------------------------
+        pd.make(tid, y0, x0, a.H, a.W);
+        pi.make(tid, y0, x0, a.H, a.W);
+        const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.dout + ((size_t)b * a.Cout + co0) * HW, (uint32_t)(a.Cout - co0) * HW * 4u);
+        const __amdgpu_buffer_rsrc_t rs_i = make_rsrc(a.in + ((size_t)b * a.Cin + ci0) * HW, (uint32_t)(a.Cin - ci0) * HW * 4u);
 #pragma unroll
-        for (int rr = 0; rr < TH / 4; ++rr) {
-            const int row = wave + rr * 4;
-            const float* pa = sD + j * PSD + row * TW + kq;
-            const float* pb = sI + j * PSI + row * IW + kq;
+        for (int n = 0; n < PlanD::NT; ++n) buf_load<VEC>(rs_d, pd.goff[n], rd[n]);
+#pragma unroll
+        for (int n = 0; n < PlanI::NT; ++n) buf_load<VEC>(rs_i, pi.goff[n], ri[n]);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int n = 0; n < PlanD::NT; ++n)
+            if (pd.loff[n] >= 0) lds_store<VEC, false>(&sD[pd.loff[n]], rd[n]);
+#pragma unroll
+        for (int n = 0; n < PlanI::NT; ++n)
+            if (pi.loff[n] >= 0) lds_store<VEC, false>(&sI[pi.loff[n]], ri[n]);
+    };
+
+    const float* pa0 = sD + (wco * 16 + j) * PSD + kq;
+    const float* pb0 = sI + (wci * 16 + j) * PSI + kq + XS;
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        if (more) load_tile(t + 1);
+#pragma unroll
+        for (int rr = 0; rr < TH / WK; ++rr) {
+            const int row = wk + rr * WK;
+            const float* pa = pa0 + row * TW;
+            const float* pb = pb0 + row * IW;
 #pragma unroll
             for (int x4 = 0; x4 < TW / 4; ++x4) {
-                float af[MWC];
-#pragma unroll
-                for (int m = 0; m < MWC; ++m) af[m] = pa[m * 16 * PSD + x4 * 4];
-                if (BIAS) {
-#pragma unroll
-                    for (int m = 0; m < MWC; ++m)
-                        accb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], 1.0f, accb[m], 0, 0, 0);
-                }
+                const float af = pa[x4 * 4];
+                if (want_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(af, 1.0f, accb, 0, 0, 0);
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const int ky = tap / KS, kx = tap % KS;
-                    float bf[NWC];
-#pragma unroll
-                    for (int n = 0; n < NWC; ++n) bf[n] = pb[n * 16 * PSI + ky * IW + x4 * 4 + kx];
-#pragma unroll
-                    for (int m = 0; m < MWC; ++m)
-#pragma unroll
-                        for (int n = 0; n < NWC; ++n)
-                            acc[tap][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[tap][m][n], 0, 0, 0);
+                    const float bf = pb[ky * IW + x4 * 4 + kx];
+                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[tap], 0, 0, 0);
                 }
             }
         }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
     }
 
-    // ---- sum the 4 waves through LDS: (2,3) -> (0,1), then 1 -> 0 ---------------------------------
-    constexpr int NT = TAPS * MWC * NWC;
-    float* red = smem;                       // [2][NT + MWC][4][64]
-    auto red_at = [&](int slot, int tile, int r) { return red + ((slot * (NT + MWC) + tile) * 4 + r) * 64 + lane; };
+    // ---- sum the WK row-split partials of each (wco, wci) block through LDS ------------------------
+    if constexpr (WK > 1) {
+        float* red = smem;   // [slot][TAPS + 1][4][64], slot = (wk - s) * WCO*WCI + wco*WCI + wci
 #pragma unroll
-    for (int round = 0; round < 2; ++round) {
-        const int writers_lo = round == 0 ? 2 : 1, nwr = round == 0 ? 2 : 1;
-        __syncthreads();
-        if (wave >= writers_lo && wave < writers_lo + nwr) {
-            const int slot = wave - writers_lo;
+        for (int s = WK / 2; s >= 1; s >>= 1) {
+            if (wk >= s && wk < 2 * s) {
+                float* p = red + (size_t)(((wk - s) * WCO + wco) * WCI + wci) * (TAPS + 1) * 256 + lane;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t)
+                for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                for (int m = 0; m < MWC; ++m)
+                    for (int r = 0; r < 4; ++r) p[(t * 4 + r) * 64] = acc[t][r];
 #pragma unroll
-                    for (int n = 0; n < NWC; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) *red_at(slot, (t * MWC + m) * NWC + n, r) = acc[t][m][n][r];
-            if (BIAS) {
-#pragma unroll
-                for (int m = 0; m < MWC; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) *red_at(slot, NT + m, r) = accb[m][r];
+                for (int r = 0; r < 4; ++r) p[(TAPS * 4 + r) * 64] = accb[r];
             }
-        }
-        __syncthreads();
-        if (wave < nwr) {
-            const int slot = wave;
+            __syncthreads();
+            if (wk < s) {
+                const float* p = red + (size_t)((wk * WCO + wco) * WCI + wci) * (TAPS + 1) * 256 + lane;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t)
+                for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                for (int m = 0; m < MWC; ++m)
+                    for (int r = 0; r < 4; ++r) acc[t][r] += p[(t * 4 + r) * 64];
 #pragma unroll
-                    for (int n = 0; n < NWC; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[t][m][n][r] += *red_at(slot, (t * MWC + m) * NWC + n, r);
-            if (BIAS) {
-#pragma unroll
-                for (int m = 0; m < MWC; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) accb[m][r] += *red_at(slot, NT + m, r);
+                for (int r = 0; r < 4; ++r) accb[r] += p[(TAPS * 4 + r) * 64];
             }
+            __syncthreads();
         }
     }
-    if (wave != 0) return;
-    // lane (j, kq), register r of tile (m, n): co = co0 + m*16 + kq*4 + r, ci = ci0 + n*16 + j
+    if (wk != 0) return;
+    // lane (j, kq), register r: co = co0 + wco*16 + kq*4 + r, ci = ci0 + wci*16 + j
     float* slab = a.slab + (size_t)split * TAPS * a.CoutS * a.CinS;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int m = 0; m < MWC; ++m)
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wco * 16 + kq * 4 + r, ci = ci0 + wci * 16 + j;
+            slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = acc[t][r];
+        }
+    if (want_bias && wci == 0 && j == 0) {
 #pragma unroll
-            for (int n = 0; n < NWC; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + m * 16 + kq * 4 + r, ci = ci0 + n * 16 + j;
-                    if (co < a.CoutS && ci < a.CinS) slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = acc[t][m][n][r];
-                }
-    if (BIAS && a.bslab && cib == 0 && j == 0) {
-#pragma unroll
-        for (int m = 0; m < MWC; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + m * 16 + kq * 4 + r;
-                if (co < a.CoutS) a.bslab[(size_t)split * a.CoutS + co] = accb[m][r];
-            }
+        for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = accb[r];
     }
 }
 
-// dw[co][ci][tap] = sum_s slab[s][tap][co][ci]  (fixed order, double accumulation not needed: <= 2048 terms
-// of similar magnitude are summed pairwise-free in fp32 like PyTorch's own reductions);
-// db[co] = sum_s bslab[s][co].
-static __global__ void conv_wrw_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab, float* __restrict__ dw,
-                                       float* __restrict__ db, int nsplit, int taps, int Cout, int Cin, int CoutS, int CinS) {
-    const long n = (long)taps * CoutS * CinS;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) {
+// dw[co][ci][tap] = sum_s slab[s][tap][co][ci]; db[co] = sum_s bslab[s][co].  A block owns EL consecutive
+// slab elements; its 256/EL split lanes each sum every (256/EL)-th split with 4 independent chains, then
+// the lanes are combined through LDS in a fixed order -> deterministic, and enough loads in flight to
+// stream the slabs at HBM/L2 rate even when the gradient itself is tiny (2304 floats for 16x16x3x3).
+template <int EL>
+__global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                              float* __restrict__ dw, float* __restrict__ db, int nsplit, int taps,
+                                                              int Cout, int Cin, int CoutS, int CinS) {
+    constexpr int SL = 256 / EL;
+    __shared__ float red[SL][EL];
+    const long n = (long)taps * CoutS * CinS;        // slab elements; the bias partials follow as n .. n+CoutS
+    const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+    const long e = (long)blockIdx.x * EL + el;
+    const bool is_w = e < n, is_b = !is_w && bslab != nullptr && e - n < CoutS;
+    const float* src = is_w ? slab + e : (is_b ? bslab + (e - n) : nullptr);
+    const size_t stride = is_w ? (size_t)n : (size_t)CoutS;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (src) {
+        int k = sl;
+        for (; k + 3 * SL < nsplit; k += 4 * SL) {
+            s0 += src[(size_t)k * stride]; s1 += src[(size_t)(k + SL) * stride];
+            s2 += src[(size_t)(k + 2 * SL) * stride]; s3 += src[(size_t)(k + 3 * SL) * stride];
+        }
+        for (; k < nsplit; k += SL) s0 += src[(size_t)k * stride];
+    }
+    red[sl][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0) return;
+    float s = red[0][el];
+#pragma unroll
+    for (int q = 1; q < SL; ++q) s += red[q][el];
+    if (is_w) {
         const int ci = (int)(e % CinS); const long r = e / CinS;
         const int co = (int)(r % CoutS), t = (int)(r / CoutS);
-        if (co < Cout && ci < Cin) {
-            float s = 0.f;
-            for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + e];
-            dw[((long)co * Cin + ci) * taps + t] = s;
-        }
-    } else if (db && bslab && e - n < Cout) {
-        const int co = (int)(e - n);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += bslab[(size_t)k * CoutS + co];
-        db[co] = s;
+        if (co < Cout && ci < Cin) dw[((long)co * Cin + ci) * taps + t] = s;
+    } else if (is_b && db && e - n < Cout) {
+        db[e - n] = s;
     }
 }
 
@@ -415,7 +465,7 @@ static __global__ void conv_wrw_reduce_kernel(const float* __restrict__ slab, co
 // zero padded; either output may be null.
 // -------------------------------------------------------------------------------------------------
 static __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb,
-                                         int Cout, int Cin, int taps, int CinP, int CoutP, int CoutPk, int CinPn) {
+                                                int Cout, int Cin, int taps, int CinP, int CoutP, int CoutPk, int CinPn) {
     const long nf = (long)taps * CinP * CoutP, nbk = (long)taps * CoutPk * CinPn;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nbk; e += (long)gridDim.x * blockDim.x) {
         if (e < nf) {

@@ -5,20 +5,22 @@ using namespace uaps;
 
 namespace {
 
-struct WrwPlan { int TH, TW, mwc, nwc, ncob, ncib, nsplit, CoutS, CinS; long tiles; };
+// wave arrangement: (WCO, WCI) 16-channel blocks per workgroup, the remaining factor of 4 splits the tile rows
+struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS; long tiles; };
 
 WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
     WrwPlan p{};
-    const bool wide = W >= 32;
-    p.TH = wide ? 8 : 16; p.TW = wide ? 32 : 16;
-    p.mwc = Cout > 16 ? 2 : 1;
-    p.nwc = Cin > 16 ? 2 : 1;
-    p.ncob = (Cout + 16 * p.mwc - 1) / (16 * p.mwc);
-    p.ncib = (Cin + 16 * p.nwc - 1) / (16 * p.nwc);
-    p.CoutS = p.ncob * 16 * p.mwc; p.CinS = p.ncib * 16 * p.nwc;
+    p.wco = Cout > 16 ? 2 : 1;
+    p.wci = Cin > 16 ? 2 : 1;
+    const bool wide = W >= 32, big = p.wco * p.wci == 4;     // 32x32 channel blocks stage half-height tiles (LDS)
+    p.TW = wide ? 32 : 16;
+    p.TH = wide ? (big ? 4 : 8) : (big ? 8 : 16);
+    p.ncob = (Cout + 16 * p.wco - 1) / (16 * p.wco);
+    p.ncib = (Cin + 16 * p.wci - 1) / (16 * p.wci);
+    p.CoutS = p.ncob * 16 * p.wco; p.CinS = p.ncib * 16 * p.wci;
     p.tiles = (long)B * ((H + p.TH - 1) / p.TH) * ((W + p.TW - 1) / p.TW);
-    // pixel splits: fill the chip (two workgroups per CU) without making the slabs larger than needed
-    long want = (512 + (long)p.ncob * p.ncib - 1) / ((long)p.ncob * p.ncib);
+    // pixel splits: fill the chip (>= 3 workgroups per CU) without making the slabs larger than needed
+    long want = (768 + (long)p.ncob * p.ncib - 1) / ((long)p.ncob * p.ncib);
     if (cfg > 0) want = cfg;
     if (want > p.tiles) want = p.tiles;
     if (want < 1) want = 1;
@@ -28,20 +30,22 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
 
 size_t wrw_ws_floats(const WrwPlan& p, int taps) { return (size_t)p.nsplit * ((size_t)taps * p.CoutS * p.CinS + p.CoutS); }
 
-template <int KS, int TH, int TW, int MWC, int NWC>
-int launch_wrw(ConvWrwArgs a, bool bias, hipStream_t s) {
-    const long grid = (long)a.nsplit * a.ncob * a.ncib;
-    if (bias) hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, MWC, NWC, true>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, MWC, NWC, false>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+template <int KS, int TH, int TW, int WCO, int WCI>
+int launch_wrw(const ConvWrwArgs& a, bool vec, hipStream_t s) {
+    const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;      // multiple of 8 for the XCD swizzle
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (vec) hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 
-template <int KS, int TH, int TW>
-int dispatch_wrw(const ConvWrwArgs& a, int mwc, int nwc, bool bias, hipStream_t s) {
-    if (mwc == 1 && nwc == 1) return launch_wrw<KS, TH, TW, 1, 1>(a, bias, s);
-    if (mwc == 1 && nwc == 2) return launch_wrw<KS, TH, TW, 1, 2>(a, bias, s);
-    if (mwc == 2 && nwc == 1) return launch_wrw<KS, TH, TW, 2, 1>(a, bias, s);
-    return launch_wrw<KS, TH, TW, 2, 2>(a, bias, s);
+template <int KS>
+int dispatch_wrw(const ConvWrwArgs& a, const WrwPlan& p, bool vec, hipStream_t s) {
+    const bool wide = p.TW == 32;
+    if (p.wco == 2 && p.wci == 2) return wide ? launch_wrw<KS, 4, 32, 2, 2>(a, vec, s) : launch_wrw<KS, 8, 16, 2, 2>(a, vec, s);
+    if (p.wco == 2) return wide ? launch_wrw<KS, 8, 32, 2, 1>(a, vec, s) : launch_wrw<KS, 16, 16, 2, 1>(a, vec, s);
+    if (p.wci == 2) return wide ? launch_wrw<KS, 8, 32, 1, 2>(a, vec, s) : launch_wrw<KS, 16, 16, 1, 2>(a, vec, s);
+    return wide ? launch_wrw<KS, 8, 32, 1, 1>(a, vec, s) : launch_wrw<KS, 16, 16, 1, 1>(a, vec, s);
 }
 
 }  // namespace
@@ -56,6 +60,7 @@ extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, 
                                     int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
     if (!dy || !x || !dw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
+    if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     const int taps = ks * ks;
     const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
@@ -64,13 +69,16 @@ extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, 
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
     a.bslab = dbias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
+    const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
-    int rc;
-    if (ks == 3) rc = p.TW == 32 ? dispatch_wrw<3, 8, 32>(a, p.mwc, p.nwc, dbias != nullptr, s) : dispatch_wrw<3, 16, 16>(a, p.mwc, p.nwc, dbias != nullptr, s);
-    else rc = p.TW == 32 ? dispatch_wrw<1, 8, 32>(a, p.mwc, p.nwc, dbias != nullptr, s) : dispatch_wrw<1, 16, 16>(a, p.mwc, p.nwc, dbias != nullptr, s);
+    const int rc = ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
     if (rc) return rc;
-    const long n = (long)taps * p.CoutS * p.CinS + (dbias ? Cout : 0);
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.slab, a.bslab, dw, dbias,
-                       p.nsplit, taps, Cout, Cin, p.CoutS, p.CinS);
+    const long n = (long)taps * p.CoutS * p.CinS + (dbias ? p.CoutS : 0);
+    if (n < 32768)
+        hipLaunchKernelGGL(conv_wrw_reduce_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, a.slab, a.bslab, dw, dbias,
+                           p.nsplit, taps, Cout, Cin, p.CoutS, p.CinS);
+    else
+        hipLaunchKernelGGL(conv_wrw_reduce_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, a.slab, a.bslab, dw, dbias,
+                           p.nsplit, taps, Cout, Cin, p.CoutS, p.CinS);
     return (int)hipGetLastError();
 }

@@ -111,5 +111,6 @@ def broadcast_model(model: torch.nn.Module, src: int = 0, group=None):
     """Same initial parameters and BatchNorm buffers on every rank (nn.DataParallel's `replicate`)."""
     if world_size() == 1:
         return
-    for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():                      # in place on the parameter itself: bumps its version counter,
+        for t in list(model.parameters()) + list(model.buffers()):   # which the packed-weight cache keys on
+            dist.broadcast(t, src=src, group=group)

@@ -9,7 +9,7 @@ Module tree and key names (they ARE the drop-in contract, see tests/test_model_s
   <decoder>.out_conv                             conv3x3 -> class logits    (:138-139)
   decoders: main_decoder, aux_decoder1 (FeatureNoise), aux_decoder2 (Dropout), aux_decoder3 (FeatureDropout)
 
-On a ROCm device the convolutions run through MIOpen (this round) and everything between them --
+On a ROCm device the convolutions are the MFMA implicit-GEMM kernels of csrc/conv_kernels.hpp and everything between them --
 BatchNorm(train)+LeakyReLU+Dropout, bilinear-x2+concat, the three feature perturbations -- and
 everything after the logits are the HIP kernels of this package (csrc/*.hip).
 """
@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused, perturb
+from . import conv, fused, perturb
 
 FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
 ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
@@ -42,11 +42,11 @@ class ConvBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             return self.conv_conv(x)                  # plain torch modules (CPU inspection / CPU-only tests)
-        # GPU: MIOpen convs without bias (train-mode BN cancels it; the fused kernel folds it into
-        # running_mean / the eval shift) + the fused BN+LeakyReLU+Dropout HIP kernels
+        # GPU: MFMA implicit-GEMM convs (csrc/conv_kernels.hpp) without bias (train-mode BN cancels it; the
+        # fused kernel folds it into running_mean / the eval shift) + the fused BN+LeakyReLU+Dropout kernels
         c0, b0, _, d0, c1, b1, _ = self.conv_conv
-        a = fused.bn_act(F.conv2d(x, c0.weight, None, padding=1), c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
-        return fused.bn_act(F.conv2d(a, c1.weight, None, padding=1), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
+        a = fused.bn_act(conv.conv2d(x, c0.weight, None), c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
+        return fused.bn_act(conv.conv2d(a, c1.weight, None), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
 
 
 class DownBlock(nn.Module):
@@ -73,9 +73,9 @@ class UpBlock(nn.Module):
         self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
 
     def forward(self, coarse, skip):
-        low = self.conv1x1(coarse)
-        if not low.is_cuda:
-            return self.conv(torch.cat([skip, self.up(low)], dim=1))
+        if not coarse.is_cuda:
+            return self.conv(torch.cat([skip, self.up(self.conv1x1(coarse))], dim=1))
+        low = conv.conv2d(coarse, self.conv1x1.weight, self.conv1x1.bias)
         return self.conv(fused.up_cat(skip, low))     # bilinear x2 written straight into the concat buffer
 
 
@@ -120,7 +120,9 @@ class Decoder(nn.Module):
         x = self.up2(x, feats[2])
         x = self.up3(x, feats[1])
         x = self.up4(x, feats[0])
-        return self.out_conv(x)
+        if not x.is_cuda:
+            return self.out_conv(x)
+        return conv.conv2d(x, self.out_conv.weight, self.out_conv.bias)
 
 
 class UNet(nn.Module):
