@@ -199,6 +199,17 @@ int uaps_conv_bwd_data(const float* dy, const float* wb, float* dx, int B, int C
 /* dw [Cout][Cin][ks][ks] = sum over batch and pixels of dy (x) x ; dbias [Cout] = sum dy (may be NULL).
  * Partial sums per pixel split go to the workspace and are reduced in a fixed order (deterministic). */
 int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks, int cfg, size_t* out_host);
+/* The two launches of uaps_conv_bwd_weight as separate calls (same workspace, same dims and cfg):
+ * the MFMA kernel that writes the per-split partials, then the fixed-order reduction. */
+int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias, int B, int Cin, int Cout, int H, int W,
+                                 int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_conv_bwd_weight_reduce(const void* workspace, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
+                                int ks, int cfg, uaps_stream_t stream);
+/* Name (as rocprofv3 prints it, without namespace) of the kernel instantiation the calls above launch
+ * for these dimensions; buf_host needs >= 64 bytes.  For uaps_conv_bwd_data pass Cin and Cout swapped
+ * to uaps_conv_fwd_variant.  Used by bench.py to group its per-launch HIP-event timings. */
+int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf_host, size_t buflen);
+int uaps_conv_wrw_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf_host, size_t buflen);
 int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int Cin, int Cout, int H,
                          int W, int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
 

@@ -70,6 +70,23 @@ def test_conv_no_bias_and_cached_pack_follows_inplace_updates():
     assert torch.allclose(y1, 2 * y0, rtol=1e-6, atol=1e-6)
 
 
+def test_packed_weights_follow_optimizer_steps():
+    """Fused Adam updates parameters without bumping Tensor._version: the packed-weight cache must
+    still notice (global optimizer post-step hook), otherwise training silently uses stale weights."""
+    from uaps_amd.conv import conv2d
+    dev = torch.device("cuda:0")
+    x = _mk((1, 8, 16, 16), 5).to(dev)
+    w = torch.nn.Parameter(_mk((8, 8, 3, 3), 6).to(dev))
+    for fused in (True, False):
+        opt = torch.optim.Adam([w], lr=0.1, fused=fused)
+        conv2d(x, w).square().mean().backward()
+        opt.step()
+        y = conv2d(x, w)
+        ref = F.conv2d(x.cpu(), w.detach().cpu(), padding=1)
+        assert torch.allclose(y.detach().cpu(), ref, atol=1e-4), f"stale packed weights after Adam(fused={fused})"
+        opt.zero_grad()
+
+
 def test_conv_is_deterministic():
     from uaps_amd.conv import conv2d
     dev = torch.device("cuda:0")

@@ -1,6 +1,7 @@
 // extern "C" entry points of the forward / input-gradient convolution and the weight packing
 // (include/uaps_hip.h, section "Convolutions").
 #include "../../include/uaps_hip.h"
+#include <stdio.h>
 #include "conv_kernels.hpp"
 using namespace uaps;
 
@@ -32,28 +33,41 @@ int dispatch_bn_ck(const ConvFwdArgs& a, int bn, int ck, bool vec, hipStream_t s
     return launch_fwd<KS, TH, TW, 64, 8>(a, vec, s);
 }
 
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP; };
+
+int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (ks != 1 && ks != 3) return UAPS_ERANGE;
+    if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
+    p->CinP = kdim_pad(Cin, ks); p->CoutP = ndim_pad(Cout);
+    p->ck = (ks == 3 && Cin <= 4) ? 4 : 8;
+    // 16-byte loads/stores need rows that start 16-byte aligned
+    p->vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    // pixel tile: 8 rows x 32 columns, or 16 x 16 for narrow maps (both 256 pixels = 16 M tiles)
+    const bool wide = (cfg >> 8) ? ((cfg >> 8) == 1) : (W >= 32);
+    p->th = wide ? 8 : 16; p->tw = wide ? 32 : 16;
+    int bn = (p->CoutP % 64 == 0) ? 64 : (p->CoutP % 32 == 0 ? 32 : 16);
+    const long tiles = (long)B * ((H + p->th - 1) / p->th) * ((W + p->tw - 1) / p->tw);
+    while (bn > 16 && tiles * (p->CoutP / bn) < 512) bn /= 2;       // at least two workgroups per CU
+    if (cfg & 0xff) { bn = cfg & 0xff; if ((bn != 16 && bn != 32 && bn != 64) || p->CoutP % bn) return UAPS_EINVAL; }
+    if (p->ck == 4) bn = 16;
+    p->bn = bn;
+    return UAPS_OK;
+}
+
 // x [B,Cin,H,W] * packed weights [taps][CinP][CoutP] -> y [B,Cout,H,W]
 int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
                  int cfg, hipStream_t s) {
-    if (!x || !wp || !y || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
-    if (ks != 1 && ks != 3) return UAPS_ERANGE;
-    if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
+    if (!x || !wp || !y) return UAPS_EINVAL;
+    FwdPlan p{};
+    const int rc = plan_fwd(x, y, B, Cin, Cout, H, W, ks, cfg, &p);
+    if (rc) return rc;
     ConvFwdArgs a{};
     a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    a.CinP = kdim_pad(Cin, ks); a.CoutP = ndim_pad(Cout);
-    const int ck = (ks == 3 && Cin <= 4) ? 4 : 8;
-    // 16-byte loads/stores need rows that start 16-byte aligned
-    const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    // pixel tile: 8 rows x 32 columns, or 16 x 16 for narrow maps (both 256 pixels = 16 M tiles)
-    const bool wide = (cfg >> 8) ? ((cfg >> 8) == 1) : (W >= 32);
-    const int TH = wide ? 8 : 16, TW = wide ? 32 : 16;
-    int bn = (a.CoutP % 64 == 0) ? 64 : (a.CoutP % 32 == 0 ? 32 : 16);
-    const long tiles = (long)B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    while (bn > 16 && tiles * (a.CoutP / bn) < 512) bn /= 2;       // at least two workgroups per CU
-    if (cfg & 0xff) { bn = cfg & 0xff; if ((bn != 16 && bn != 32 && bn != 64) || a.CoutP % bn) return UAPS_EINVAL; }
-    if (ck == 4) bn = 16;
-    if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, bn, ck, vec, s) : dispatch_bn_ck<3, 16, 16>(a, bn, ck, vec, s);
-    return wide ? dispatch_bn_ck<1, 8, 32>(a, bn, ck, vec, s) : dispatch_bn_ck<1, 16, 16>(a, bn, ck, vec, s);
+    a.CinP = p.CinP; a.CoutP = p.CoutP;
+    const bool wide = p.tw == 32;
+    if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, s);
+    return wide ? dispatch_bn_ck<1, 8, 32>(a, p.bn, p.ck, p.vec, s) : dispatch_bn_ck<1, 16, 16>(a, p.bn, p.ck, p.vec, s);
 }
 
 }  // namespace
@@ -85,4 +99,15 @@ extern "C" int uaps_conv_fwd(const float* x, const float* wf, const float* bias,
 extern "C" int uaps_conv_bwd_data(const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H, int W, int ks,
                                   int cfg, uaps_stream_t stream) {
     return conv_fwd_any(dy, wb, nullptr, dx, B, Cout, Cin, H, W, ks, cfg, (hipStream_t)stream);
+}
+
+// Name of the kernel instantiation uaps_conv_fwd / uaps_conv_bwd_data launch for these dimensions, as
+// rocprofv3 prints it (bench.py groups its HIP-event timings by it).  For bwd_data pass (Cout, Cin) swapped.
+extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf, size_t buflen) {
+    FwdPlan p{};
+    const int rc = plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p);
+    if (rc) return rc;
+    if (!buf || buflen < 64) return UAPS_EINVAL;
+    snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1);
+    return UAPS_OK;
 }

@@ -1,5 +1,6 @@
 // extern "C" entry points of the weight-gradient convolution (include/uaps_hip.h, "Convolutions").
 #include "../../include/uaps_hip.h"
+#include <stdio.h>
 #include "conv_kernels.hpp"
 using namespace uaps;
 
@@ -56,9 +57,10 @@ extern "C" int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, in
     return UAPS_OK;
 }
 
-extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int Cin, int Cout, int H,
-                                    int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
-    if (!dy || !x || !dw || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+// Step 1: per-split partial gradients into the workspace (the MFMA kernel).
+extern "C" int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias, int B, int Cin, int Cout, int H, int W,
+                                            int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    if (!dy || !x || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
     if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     const int taps = ks * ks;
@@ -68,17 +70,42 @@ extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, 
     a.dout = dy; a.in = x; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
-    a.bslab = dbias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
+    a.bslab = want_bias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
     const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
-    const int rc = ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
-    if (rc) return rc;
+    return ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
+}
+
+// Step 2: fixed-order sum of the partials into dw (and dbias).
+extern "C" int uaps_conv_bwd_weight_reduce(const void* ws, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W, int ks,
+                                           int cfg, uaps_stream_t stream) {
+    if (!ws || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3)) return UAPS_EINVAL;
+    const int taps = ks * ks;
+    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
+    const float* slab = (const float*)ws;
+    const float* bslab = dbias ? slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
+    hipStream_t s = (hipStream_t)stream;
     const long n = (long)taps * p.CoutS * p.CinS + (dbias ? p.CoutS : 0);
     if (n < 32768)
-        hipLaunchKernelGGL(conv_wrw_reduce_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, a.slab, a.bslab, dw, dbias,
+        hipLaunchKernelGGL(conv_wrw_reduce_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, s, slab, bslab, dw, dbias,
                            p.nsplit, taps, Cout, Cin, p.CoutS, p.CinS);
     else
-        hipLaunchKernelGGL(conv_wrw_reduce_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, a.slab, a.bslab, dw, dbias,
+        hipLaunchKernelGGL(conv_wrw_reduce_kernel<64>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, slab, bslab, dw, dbias,
                            p.nsplit, taps, Cout, Cin, p.CoutS, p.CinS);
     return (int)hipGetLastError();
+}
+
+extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int Cin, int Cout, int H,
+                                    int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    if (!dw) return UAPS_EINVAL;
+    const int rc = uaps_conv_bwd_weight_partial(dy, x, dbias != nullptr, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return uaps_conv_bwd_weight_reduce(ws, dw, dbias, B, Cin, Cout, H, W, ks, cfg, stream);
+}
+
+extern "C" int uaps_conv_wrw_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf, size_t buflen) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || !buf || buflen < 64) return UAPS_EINVAL;
+    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
+    snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1);
+    return UAPS_OK;
 }
