@@ -152,6 +152,20 @@ int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* g
                           float eps, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C,
                           int H, int W, float* out, float* save_mean, float* save_invstd, void* workspace,
                           size_t workspace_bytes, uaps_stream_t stream);
+/* The same with `groups` statistics groups: the batch is `groups` consecutive blocks of B/groups images, each
+ * normalised with its own batch statistics (save_mean / save_invstd are [groups][C]) and folded into the running
+ * statistics one after the other, exactly as `groups` separate calls in order would (the reference runs the
+ * labelled and the unlabelled batch as two forwards, UAPS_train.py:177,185); num_batches_tracked += groups.
+ * groups in [1,8], B % groups == 0. */
+int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                  float eps, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C,
+                                  int H, int W, int groups, float* out, float* save_mean, float* save_invstd,
+                                  void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                            uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
+                            float* dbeta, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
 /* eval(): running statistics, no dropout.  save_mean receives running_mean - conv_bias (for the backward). */
 int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, float eps, float slope, int B,

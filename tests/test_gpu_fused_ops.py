@@ -114,3 +114,57 @@ def test_up_cat_vs_torch(B, Cs, Cl, h, w):
     out.backward(g); ref.backward(g)
     assert torch.equal(skip.grad, sr.grad)
     torch.testing.assert_close(low.grad, lr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_forward_pair_equals_two_forwards():
+    """UNet_UAPS.forward_pair (one pass over labelled+unlabelled, 2 BatchNorm statistics groups) must compute what
+    the reference's two forwards compute (UAPS_train.py:177,185): same logits, same running statistics after the
+    two successive updates, same loss and parameter gradients.  Randomness is switched off (dropout 0, identity
+    perturbations) so the two routes are comparable."""
+    import copy
+    import uaps_amd
+    from uaps_amd import losses
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m1 = uaps_amd.UNet_UAPS(3, 4, dropout=(0.0,) * 5).to(dev).train()
+    m2 = copy.deepcopy(m1)
+    B, H, W = 2, 32, 32
+    xa, xb = torch.randn(B, 3, H, W, device=dev), torch.randn(B, 3, H, W, device=dev) * 1.7 + 0.3
+    y = torch.randint(0, 4, (B, H, W), device=dev)
+    ident = [lambda f: f] * 3
+    w = np.array([0.1, 0.2, 0.3, 0.4])
+    la, lb = m1(xa, ident), m1(xb, ident)
+    out1 = losses.uaps_step_loss(la, y, lb, w, 0.07, 0.05)
+    out1.loss.backward()
+    both = m2.forward_pair(xa, xb, ident)
+    out2 = losses.uaps_pair_loss(both, y, w, 0.07, 0.05)
+    out2.loss.backward()
+    for k in range(4):
+        assert torch.equal(both[k][:B], la[k]) and torch.equal(both[k][B:], lb[k]), f"head {k} logits differ"
+    assert torch.equal(out1.pseudo, out2.pseudo)
+    assert abs(float(out1.loss) - float(out2.loss)) < 1e-6
+    for (n1, b1), (n2, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), f"buffer {n1} differs"            # running stats: two sequential updates
+    worst = 0.0
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        scale = float(p1.grad.abs().max()) + 1e-12
+        err = float((p1.grad - p2.grad).abs().max())
+        # conv biases in front of a train-mode BatchNorm have an exactly-zero gradient
+        assert err <= 5e-5 * scale + 1e-9, f"{n1}: grad err {err:.3e} vs scale {scale:.3e}"
+        worst = max(worst, err / scale)
+
+
+def test_grouped_perturbations_draw_per_group():
+    from uaps_amd import perturb
+    dev = torch.device("cuda:0")
+    perturb.manual_seed(11)
+    x = torch.ones(4, 3, 8, 8, device=dev)
+    y, noise = perturb.FeatureNoise()(x, return_noise=True, groups=2)
+    assert noise.shape == (2, 3, 8, 8) and not torch.equal(noise[0], noise[1])
+    assert torch.allclose(y[:2], (1 + noise[0]).expand(2, -1, -1, -1)) and torch.allclose(y[2:], (1 + noise[1]).expand(2, -1, -1, -1))
+    assert float(noise.abs().max()) <= 0.3
+    z = torch.rand(4, 5, 8, 8, device=dev)
+    out, keep = perturb.feature_dropout_with(z, (0.7, 0.9), return_keep=True)
+    r0 = perturb.feature_dropout_with(z[:2].contiguous(), 0.7)
+    r1 = perturb.feature_dropout_with(z[2:].contiguous(), 0.9)
+    assert torch.equal(out[:2], r0) and torch.equal(out[2:], r1)

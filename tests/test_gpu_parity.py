@@ -198,47 +198,81 @@ def test_model_forward_vs_reference_fixture():
     np.testing.assert_allclose(y.cpu().numpy(), g["narrow_y_eval"], atol=5e-5)
 
 
-def test_full_step_vs_reference_fixture():
+@pytest.mark.parametrize("pair", [False, True], ids=["two_forwards", "forward_pair"])
+def test_full_step_vs_reference_fixture(pair, monkeypatch):
     """Fixture g6: one whole step of the reference classes (two forwards with recorded perturbation
     draws, loss block, backward, Adam) on a narrow 4-head net; the build's model + HIP kernels +
-    trainer must reproduce logits, loss, pseudo-labels, gradients and the updated parameters."""
+    trainer must reproduce logits, loss, pseudo-labels, gradients and the updated parameters --
+    both as two forwards and through the product path (one pass over the concatenated batch with
+    per-half BatchNorm statistics, UNet_UAPS.forward_pair + uaps_pair_loss)."""
     import uaps_amd
-    from uaps_amd import perturb, unet
+    from uaps_amd import losses, perturb, unet
     g = np.load(os.path.join(GOLDEN, "g6_step.npz"))
     model = unet.UNet_UAPS(3, 4, n_aux=3, feature_chns=[2, 4, 8, 16, 32], dropout=[0.0] * 5)
     model.load_state_dict({k[5:]: torch.tensor(g[k]) for k in g.files if k.startswith("init.")})
     model.to(DEV)
-    tr = uaps_amd.UAPSTrainer(model, base_lr=1e-3)
+    tr = uaps_amd.UAPSTrainer(model, base_lr=1e-3, pair_forward=pair)
+    assert tr.pair_forward == pair
     tr.iter_num = 3 * 80                                   # cw = 0.1 * sigmoid_rampup(3, 200)
     assert abs(tr.consistency_weights()[0] - float(g["cw"])) < 1e-15
 
+    def draws(tag):
+        return ([_t(g[f"noise_{tag}{i}"]) for i in range(5)], [_t(g[f"mask_{tag}{i}"]) for i in range(5)],
+                [float(g[f"u_{tag}{i}"]) for i in range(5)])
+
     def injected(tag):
-        noise = [_t(g[f"noise_{tag}{i}"]) for i in range(5)]
-        mask = [_t(g[f"mask_{tag}{i}"]) for i in range(5)]
-        u = [float(g[f"u_{tag}{i}"]) for i in range(5)]
+        noise, mask, u = draws(tag)
         return [lambda fs: [perturb.feature_noise_with(f, n) for f, n in zip(fs, noise)],
                 lambda fs: [perturb.dropout_with(f, m) for f, m in zip(fs, mask)],
                 lambda fs: [perturb.feature_dropout_with(f, uu) for f, uu in zip(fs, u)]]
 
-    calls = {"n": 0}
-    orig_forward = model.forward
+    def injected_pair():
+        (nl, ml, ul), (nu, mu, uu) = draws("l"), draws("u")
 
-    def forward(x, perturbations=None):
-        tag = "l" if calls["n"] == 0 else "u"
-        calls["n"] += 1
-        return orig_forward(x, perturbations=injected(tag))
+        def halves(f):
+            b = f.shape[0] // 2
+            return f[:b].contiguous(), f[b:].contiguous()
 
-    model.forward = forward
+        def both(fn, fs, dl, du):
+            return [torch.cat([fn(halves(f)[0], a), fn(halves(f)[1], b)]) for f, a, b in zip(fs, dl, du)]
+
+        return [lambda fs: both(perturb.feature_noise_with, fs, nl, nu),
+                lambda fs: both(perturb.dropout_with, fs, ml, mu),
+                lambda fs: [perturb.feature_dropout_with(f, (a, b)) for f, a, b in zip(fs, ul, uu)]]
+
     captured = {}
-    real_loss = tr.loss_fn
+    if pair:
+        orig_pair = model.forward_pair
+        model.forward_pair = lambda a, b: orig_pair(a, b, perturbations=injected_pair())
+        real_pair_loss = losses.uaps_pair_loss
 
-    def loss_fn(lab, y, un, w, cw1, cw2):
-        captured["lab"], captured["un"] = [t.detach() for t in lab], [t.detach() for t in un]
-        out = real_loss(lab, y, un, w, cw1, cw2)
-        captured["pseudo"] = out.pseudo
-        return out
+        def pair_loss(both, y, w, cw1, cw2):
+            B = y.shape[0]
+            captured["lab"], captured["un"] = [t[:B].detach() for t in both], [t[B:].detach() for t in both]
+            out = real_pair_loss(both, y, w, cw1, cw2)
+            captured["pseudo"] = out.pseudo
+            return out
 
-    tr.loss_fn = loss_fn
+        monkeypatch.setattr(losses, "uaps_pair_loss", pair_loss)
+    else:
+        calls = {"n": 0}
+        orig_forward = model.forward
+
+        def forward(x, perturbations=None):
+            tag = "l" if calls["n"] == 0 else "u"
+            calls["n"] += 1
+            return orig_forward(x, perturbations=injected(tag))
+
+        model.forward = forward
+        real_loss = tr.loss_fn
+
+        def loss_fn(lab, y, un, w, cw1, cw2):
+            captured["lab"], captured["un"] = [t.detach() for t in lab], [t.detach() for t in un]
+            out = real_loss(lab, y, un, w, cw1, cw2)
+            captured["pseudo"] = out.pseudo
+            return out
+
+        tr.loss_fn = loss_fn
     grads = {}
     hooks = [p.register_hook(lambda gr, n=n: grads.__setitem__(n, gr.detach().clone())) for n, p in model.named_parameters()]
     res = tr.train_step(_t(g["xl"]), _t(g["yl"]), _t(g["xu"]), w=g["w"])

@@ -9,7 +9,8 @@ Public surface (mirrors the names the reference's UAPS_train.py imports):
   UAPSTrainer                                       (UAPS_train.py:109-450 step/optimizer/checkpoint)
 """
 from .ramps import sigmoid_rampup, get_current_consistency_weight
-from .losses import dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_step_loss, unsup_scalars, sup_scalars
+from .losses import (dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_step_loss, uaps_pair_loss, unsup_scalars,
+                     sup_scalars)
 from .perturb import FeatureNoise, Dropout, FeatureDropout, manual_seed as perturb_manual_seed
 from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, metrics_from_confusion
 from .unet import UNet, UNet_UAPS

@@ -86,18 +86,25 @@ template <int VEC, bool ALIGN16> __device__ __forceinline__ void lds_store(float
 template <class G, int NPL, int VEC, int PS> struct StagePlan {
     static constexpr int UPR = G::IW / VEC, UPP = G::IH * UPR, NUNITS = NPL * UPP;
     static constexpr int NT = (NUNITS + kConvThreads - 1) / kConvThreads;
-    uint32_t goff[NT];
-    int loff[NT];
-    __device__ __forceinline__ void make(int tid, int y0, int x0, int H, int W) {
-        const int HW = H * W;
+    int pos[NT];       // tile-independent: (plane c) << 20 | (row r) << 10 | (column xu*VEC); -1 = no unit
+    int loff[NT];      // LDS float offset, -1 = no unit
+    uint32_t goff[NT]; // per tile: byte offset inside the image's channel block, kOob = zero padding
+    __device__ __forceinline__ void init(int tid) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int u = tid + n * kConvThreads;
             const int c = u / UPP, rem = u % UPP, r = rem / UPR, xu = rem % UPR;
-            const int gy = y0 - G::PAD + r, gx = x0 - G::XOFF + xu * VEC;
-            const bool inside = u < NUNITS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            goff[n] = inside ? (uint32_t)(c * HW + gy * W + gx) * 4u : kOob;
+            pos[n] = u < NUNITS ? (c << 20) | (r << 10) | (xu * VEC) : -1;
             loff[n] = u < NUNITS ? c * PS + r * G::IW + xu * VEC : -1;
+        }
+    }
+    __device__ __forceinline__ void place(int y0, int x0, int H, int W) {
+        const int HW = H * W, ty = y0 - G::PAD, tx = x0 - G::XOFF;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int c = pos[n] >> 20, gy = ty + ((pos[n] >> 10) & 1023), gx = tx + (pos[n] & 1023);
+            const bool inside = pos[n] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            goff[n] = inside ? (uint32_t)(c * HW + gy * W + gx) * 4u : kOob;
         }
     }
 };
@@ -140,7 +147,8 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     const int HW = a.H * a.W;
 
     Plan plan;
-    plan.make(tid, y0, x0, a.H, a.W);
+    plan.init(tid);
+    plan.place(y0, x0, a.H, a.W);
     // weight chunk plan: float4 unit e4 -> (row = tap*CK + c, co4)
     uint32_t wgoff[NWT_T];
     int wloff[NWT_T];
@@ -198,22 +206,27 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) load_chunk((ch + 1) * CK);
+        // k-steps (tap, 4 channels); the fragments of step s+1 are read from LDS before the MFMAs of step s issue
+        constexpr int NSTEP = TAPS * (CK / 4);
+        float af[2][MW], bf[2][NW];
+        auto read_frags = [&](int s, float (&a_)[MW], float (&b_)[NW]) {
+            const int tap = s / (CK / 4), c4 = s % (CK / 4);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
+            for (int n = 0; n < NW; ++n) b_[n] = sW[boff + (tap * CK + c4 * 4) * BNS + n * 16];
 #pragma unroll
-            for (int c4 = 0; c4 < CK / 4; ++c4) {
-                float af[MW], bf[NW];
+            for (int m = 0; m < MW; ++m) a_[m] = sIn[aoff[m] + c4 * 4 * PS + (tap / KS) * IW + tap % KS];
+        };
+        read_frags(0, af[0], bf[0]);
 #pragma unroll
-                for (int n = 0; n < NW; ++n) bf[n] = sW[boff + (tap * CK + c4 * 4) * BNS + n * 16];
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) read_frags(s + 1, af[(s + 1) & 1], bf[(s + 1) & 1]);
 #pragma unroll
-                for (int m = 0; m < MW; ++m) af[m] = sIn[aoff[m] + c4 * 4 * PS + ky * IW + kx];
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
-                for (int m = 0; m < MW; ++m)
-#pragma unroll
-                    for (int n = 0; n < NW; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], bf[n], acc[m][n], 0, 0, 0);
-            }
+                for (int n = 0; n < NW; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][m], bf[s & 1][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MW + NW, 0);   // next step's DS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, MW * NW, 0);   // ... then this step's MFMAs
         }
         __syncthreads();
         if (more) store_chunk();
@@ -318,14 +331,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
 
     PlanD pd;
     PlanI pi;
+    pd.init(tid);
+    pi.init(tid);
     float rd[PlanD::NT][VEC];
     float ri[PlanI::NT][VEC];
 
     auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         const int y0 = (tt / a.tiles_x) * TH, x0 = (tt % a.tiles_x) * TW;
-        pd.make(tid, y0, x0, a.H, a.W);
-        pi.make(tid, y0, x0, a.H, a.W);
+        pd.place(y0, x0, a.H, a.W);
+        pi.place(y0, x0, a.H, a.W);
         const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.dout + ((size_t)b * a.Cout + co0) * HW, (uint32_t)(a.Cout - co0) * HW * 4u);
         const __amdgpu_buffer_rsrc_t rs_i = make_rsrc(a.in + ((size_t)b * a.Cin + ci0) * HW, (uint32_t)(a.Cin - ci0) * HW * 4u);
 #pragma unroll
@@ -353,22 +368,26 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
     for (int t = t_begin; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
         if (more) load_tile(t + 1);
+        // k-steps of this wave: (row rr, x4); the fragments of step s+1 are read from LDS before the MFMAs of
+        // step s issue, so the LDS latency hides under 9 MFMAs instead of stalling the head of every step
+        constexpr int NSTEP = (TH / WK) * (TW / 4);
+        float af[2], bf[2][TAPS];
+        auto read_frags = [&](int s, float& a_, float (&b_)[TAPS]) {
+            const int row = wk + (s / (TW / 4)) * WK, x4 = s % (TW / 4);
+            a_ = pa0[row * TW + x4 * 4];
 #pragma unroll
-        for (int rr = 0; rr < TH / WK; ++rr) {
-            const int row = wk + rr * WK;
-            const float* pa = pa0 + row * TW;
-            const float* pb = pb0 + row * IW;
+            for (int tap = 0; tap < TAPS; ++tap) b_[tap] = pb0[(row + tap / KS) * IW + x4 * 4 + tap % KS];
+        };
+        read_frags(0, af[0], bf[0]);
 #pragma unroll
-            for (int x4 = 0; x4 < TW / 4; ++x4) {
-                const float af = pa[x4 * 4];
-                if (want_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(af, 1.0f, accb, 0, 0, 0);
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) read_frags(s + 1, af[(s + 1) & 1], bf[(s + 1) & 1]);
+            if (want_bias) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1], 1.0f, accb, 0, 0, 0);
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    const int ky = tap / KS, kx = tap % KS;
-                    const float bf = pb[ky * IW + x4 * 4 + kx];
-                    acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[tap], 0, 0, 0);
-                }
-            }
+            for (int tap = 0; tap < TAPS; ++tap)
+                acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1], bf[s & 1][tap], acc[tap], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);   // next step's DS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);       // ... then this step's MFMAs
         }
         __syncthreads();
         if (more) store_tile();

@@ -20,8 +20,10 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
     p.ncib = (Cin + 16 * p.wci - 1) / (16 * p.wci);
     p.CoutS = p.ncob * 16 * p.wco; p.CinS = p.ncib * 16 * p.wci;
     p.tiles = (long)B * ((H + p.TH - 1) / p.TH) * ((W + p.TW - 1) / p.TW);
-    // pixel splits: fill the chip (>= 3 workgroups per CU) without making the slabs larger than needed
-    long want = (768 + (long)p.ncob * p.ncib - 1) / ((long)p.ncob * p.ncib);
+    // pixel splits: the kernels run two workgroups per CU (register-limited), so aim at exactly one round of
+    // 512 equally loaded workgroups; more, smaller ones leave a half-empty second round and grow the slabs
+    const long blocks = (long)p.ncob * p.ncib;
+    long want = blocks >= 512 ? 1 : 512 / blocks;
     if (cfg > 0) want = cfg;
     if (want > p.tiles) want = p.tiles;
     if (want < 1) want = 1;

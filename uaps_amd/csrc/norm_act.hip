@@ -26,8 +26,9 @@ inline int nchunks_for(long HW) { return (int)((HW + kChunk - 1) / kChunk); }
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-struct BnWs { float2* partials; float* coef; };   // coef: 4*C floats
-inline size_t bn_ws_bytes(int B, int C, long HW) { return align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)) + (size_t)4 * C * sizeof(float); }
+constexpr int kMaxGroups = 8;
+struct BnWs { float2* partials; float* coef; };   // coef: [groups][4][C] floats
+inline size_t bn_ws_bytes(int B, int C, long HW) { return align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)) + (size_t)4 * C * kMaxGroups * sizeof(float); }
 inline BnWs carve(void* ws, int B, int C, long HW) {
     BnWs w; w.partials = (float2*)ws;
     w.coef = (float*)((char*)ws + align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)));
@@ -68,35 +69,42 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
     if (threadIdx.x == 0) partials[((long)c * gridDim.y / C + b) * nchunks + chunk] = r;
 }
 
-// ---- forward finalize: one wave per channel ------------------------------------------------------------
-__global__ __launch_bounds__(64) void bn_finalize_fwd(const float2* __restrict__ partials, int nparts, double M,
+// ---- forward finalize: one wave per channel, looping over the G = B / Bg statistics groups in order -------
+// (a group = the images of one reference forward call: the labelled and the unlabelled batch are normalised
+// separately, UAPS_train.py:177,185, and update the running statistics one after the other)
+__global__ __launch_bounds__(64) void bn_finalize_fwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
                                                       const float* __restrict__ conv_bias, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ running_mean,
                                                       float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                       float momentum, float eps, float* __restrict__ save_mean,
                                                       float* __restrict__ save_invstd, float* __restrict__ coef, int C) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double s = 0.0, ss = 0.0;
-    for (int i = lane; i < nparts; i += 64) { const float2 v = partials[(long)c * nparts + i]; s += v.x; ss += v.y; }
+    const int G = B / Bg, nparts = Bg * nch;
+    const double M = (double)Bg * HW;
+    for (int g = 0; g < G; ++g) {
+        const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
+        double s = 0.0, ss = 0.0;
+        for (int i = lane; i < nparts; i += 64) { const float2 v = pp[i]; s += v.x; ss += v.y; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
-    if (lane == 0) {
-        const double mean = s / M;
-        double var = ss / M - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        save_mean[c] = (float)mean;
-        save_invstd[c] = invstd;
-        coef[c] = gamma[c] * invstd;                 // scale
-        coef[C + c] = beta[c];                       // shift applied after (y - mean) * scale
-        if (running_mean) {
-            const double bias = conv_bias ? (double)conv_bias[c] : 0.0;
-            const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + bias));
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (lane == 0) {
+            const double mean = s / M;
+            double var = ss / M - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            save_mean[g * C + c] = (float)mean;
+            save_invstd[g * C + c] = invstd;
+            coef[(g * 4 + 0) * C + c] = gamma[c] * invstd;       // scale
+            coef[(g * 4 + 1) * C + c] = beta[c];                 // shift applied after (y - mean) * scale
+            if (running_mean) {
+                const double bias = conv_bias ? (double)conv_bias[c] : 0.0;
+                const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + bias));
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
         }
-        if (nbt && c == 0) nbt[0] += 1;
     }
+    if (nbt && c == 0 && lane == 0) nbt[0] += G;
 }
 
 __global__ __launch_bounds__(64) void bn_coef_eval(const float* __restrict__ conv_bias, const float* __restrict__ gamma,
@@ -116,10 +124,11 @@ template <bool VEC, bool DROP>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, float* __restrict__ out, int C, long HW,
                                                             const float* __restrict__ mean, const float* __restrict__ coef,
                                                             float slope, float drop_p, float drop_scale, uint64_t seed,
-                                                            uint64_t offset) {
+                                                            uint64_t offset, int Bg) {
     const int plane = blockIdx.y, chunk = blockIdx.x;
-    const int c = plane % C;
-    const float mu = mean[c], sc = coef[c], sh = coef[C + c];
+    const int b = plane / C, c = plane - b * C, g = b / Bg;
+    const float* cf = coef + (long)g * 4 * C;
+    const float mu = mean[g * C + c], sc = cf[c], sh = cf[C + c];
     const long pbase = (long)plane * HW;
     const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
     if (VEC) {
@@ -164,10 +173,10 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sums_kernel(const float* __re
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float slope, float drop_p,
                                                                float drop_scale, uint64_t seed, uint64_t offset,
-                                                               float2* __restrict__ partials) {
+                                                               float2* __restrict__ partials, int Bg) {
     const int plane = blockIdx.y, chunk = blockIdx.x;
-    const int b = plane / C, c = plane - b * C;
-    const float mu = mean[c], is = invstd[c], sc = gamma[c] * is, sh = beta[c];
+    const int b = plane / C, c = plane - b * C, g = b / Bg;
+    const float mu = mean[g * C + c], is = invstd[g * C + c], sc = gamma[c] * is, sh = beta[c];
     const long pbase = (long)plane * HW;
     const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
     float s1 = 0.f, s2 = 0.f;
@@ -205,21 +214,27 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sums_kernel(const float* __re
     if (threadIdx.x == 0) partials[((long)c * gridDim.y / C + b) * nchunks + chunk] = r;
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_bwd(const float2* __restrict__ partials, int nparts, double M,
+__global__ __launch_bounds__(64) void bn_finalize_bwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
                                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ coef, int C) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int i = lane; i < nparts; i += 64) { const float2 v = partials[(long)c * nparts + i]; s1 += v.x; s2 += v.y; }
+    const int G = B / Bg, nparts = Bg * nch;
+    const double M = (double)Bg * HW;
+    double t1 = 0.0, t2 = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = lane; i < nparts; i += 64) { const float2 v = pp[i]; s1 += v.x; s2 += v.y; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    if (lane == 0) {
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
-        coef[2 * C + c] = (float)(s1 / M);
-        coef[3 * C + c] = (float)(s2 / M);
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (lane == 0) {
+            coef[(g * 4 + 2) * C + c] = (float)(s1 / M);
+            coef[(g * 4 + 3) * C + c] = (float)(s2 / M);
+        }
+        t1 += s1; t2 += s2;
     }
+    if (lane == 0) { dbeta[c] = (float)t1; dgamma[c] = (float)t2; }
 }
 
 // dy = gamma * invstd * (dpre - mean(dpre) - xhat * mean(dpre * xhat))
@@ -229,10 +244,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __rest
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ coef,
                                                              float slope, float drop_p, float drop_scale, uint64_t seed,
-                                                             uint64_t offset) {
+                                                             uint64_t offset, int Bg) {
     const int plane = blockIdx.y, chunk = blockIdx.x;
-    const int c = plane % C;
-    const float mu = mean[c], is = invstd[c], sc = gamma[c] * is, sh = beta[c], k2 = coef[2 * C + c], k3 = coef[3 * C + c];
+    const int b = plane / C, c = plane - b * C, g = b / Bg;
+    const float* cf = coef + (long)g * 4 * C;
+    const float mu = mean[g * C + c], is = invstd[g * C + c], sc = gamma[c] * is, sh = beta[c], k2 = cf[2 * C + c], k3 = cf[3 * C + c];
     const long pbase = (long)plane * HW;
     const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
     if (VEC) {
@@ -307,31 +323,41 @@ extern "C" int uaps_bn_workspace_bytes(int B, int C, int H, int W, size_t* out) 
     return UAPS_OK;
 }
 
+extern "C" int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                             float momentum, float eps, float slope, float drop_p, uint64_t seed, uint64_t offset,
+                                             int B, int C, int H, int W, int groups, float* out, float* save_mean,
+                                             float* save_invstd, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    int rc = check(y, out, B, C, H, W);
+    if (rc) return rc;
+    if (!gamma || !beta || !save_mean || !save_invstd || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
+    if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    const int nch = nchunks_for(HW), Bg = B / groups;
+    const dim3 grid(nch, B * C);
+    const bool vec = (HW % 4 == 0) && al16(y) && al16(out);
+    if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+    else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(64), 0, s, w.partials, B, Bg, nch, (double)HW, conv_bias, gamma, beta, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
+    const float dscale = 1.f / (1.f - drop_p);
+#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg)
+    if (vec) { if (drop_p > 0.f) UAPS_APPLY(true, true); else UAPS_APPLY(true, false); }
+    else { if (drop_p > 0.f) UAPS_APPLY(false, true); else UAPS_APPLY(false, false); }
+#undef UAPS_APPLY
+    return (int)hipGetLastError();
+}
+
 extern "C" int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                      float eps, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C, int H,
                                      int W, float* out, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                                      uaps_stream_t stream) {
-    int rc = check(y, out, B, C, H, W);
-    if (rc) return rc;
-    if (!gamma || !beta || !save_mean || !save_invstd || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
-    const long HW = (long)H * W;
-    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    const BnWs w = carve(ws, B, C, HW);
-    const int nch = nchunks_for(HW);
-    const dim3 grid(nch, B * C);
-    const bool vec = (HW % 4 == 0) && al16(y) && al16(out);
-    if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
-    else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
-    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(64), 0, s, w.partials, B * nch, (double)B * HW, conv_bias, gamma, beta, running_mean,
-                       running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
-    const float dscale = 1.f / (1.f - drop_p);
-#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset)
-    if (vec) { if (drop_p > 0.f) UAPS_APPLY(true, true); else UAPS_APPLY(true, false); }
-    else { if (drop_p > 0.f) UAPS_APPLY(false, true); else UAPS_APPLY(false, false); }
-#undef UAPS_APPLY
-    return (int)hipGetLastError();
+    return uaps_bn_act_fwd_train_grouped(y, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                         slope, drop_p, seed, offset, B, C, H, W, 1, out, save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
 extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, const float* gamma, const float* beta,
@@ -347,9 +373,37 @@ extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, cons
     hipLaunchKernelGGL(bn_coef_eval, dim3((C + 63) / 64), dim3(64), 0, s, conv_bias, gamma, beta, running_mean, running_var, eps, w.coef, save_mean, C);
     const dim3 grid(nchunks_for(HW), B * C);
     if ((HW % 4 == 0) && al16(y) && al16(out))
-        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull);
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull);
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const float* gamma, const float* beta,
+                                       const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                                       uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
+                                       float* dbeta, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    int rc = check(dout, dy, B, C, H, W);
+    if (rc) return rc;
+    if (!y || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
+    if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    const int nch = nchunks_for(HW), Bg = B / groups;
+    const dim3 grid(nch, B * C);
+    const bool vec = (HW % 4 == 0) && al16(y) && al16(dout) && al16(dy);
+    const float dscale = 1.f / (1.f - drop_p);
+#define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials, Bg)
+#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, w.coef, slope, drop_p, dscale, seed, offset, Bg)
+    if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
+    else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
+    hipLaunchKernelGGL(bn_finalize_bwd, dim3(C), dim3(64), 0, s, w.partials, B, Bg, nch, (double)HW, gamma, save_invstd, dgamma, dbeta, w.coef, C);
+    if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }
+    else { if (drop_p > 0.f) UAPS_DX(false, true); else UAPS_DX(false, false); }
+#undef UAPS_SUMS
+#undef UAPS_DX
     return (int)hipGetLastError();
 }
 
@@ -357,27 +411,8 @@ extern "C" int uaps_bn_act_bwd(const float* dout, const float* y, const float* g
                                const float* save_invstd, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C,
                                int H, int W, float* dy, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                                uaps_stream_t stream) {
-    int rc = check(dout, dy, B, C, H, W);
-    if (rc) return rc;
-    if (!y || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
-    const long HW = (long)H * W;
-    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    const BnWs w = carve(ws, B, C, HW);
-    const int nch = nchunks_for(HW);
-    const dim3 grid(nch, B * C);
-    const bool vec = (HW % 4 == 0) && al16(y) && al16(dout) && al16(dy);
-    const float dscale = 1.f / (1.f - drop_p);
-#define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials)
-#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, w.coef, slope, drop_p, dscale, seed, offset)
-    if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
-    else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
-    hipLaunchKernelGGL(bn_finalize_bwd, dim3(C), dim3(64), 0, s, w.partials, B * nch, (double)B * HW, gamma, save_invstd, dgamma, dbeta, w.coef, C);
-    if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }
-    else { if (drop_p > 0.f) UAPS_DX(false, true); else UAPS_DX(false, false); }
-#undef UAPS_SUMS
-#undef UAPS_DX
-    return (int)hipGetLastError();
+    return uaps_bn_act_bwd_grouped(dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, 1, dy,
+                                   dgamma, dbeta, ws, ws_bytes, stream);
 }
 
 extern "C" int uaps_bn_act_bwd_eval(const float* dout, const float* y, const float* gamma, const float* beta,

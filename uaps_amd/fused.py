@@ -14,6 +14,28 @@ from .perturb import _RngState
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 
+# Number of statistics groups of the train-mode BatchNorms: the batch is `STAT_GROUPS` consecutive blocks, each
+# normalised on its own (UNet_UAPS.forward_pair runs the labelled and the unlabelled batch of a step as one
+# 2-group batch, which is what the reference's two separate forwards compute, UAPS_train.py:177,185).
+STAT_GROUPS = 1
+
+
+class stat_groups:
+    """Context manager: `with stat_groups(2): model(x)`."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        global STAT_GROUPS
+        self.prev, STAT_GROUPS = STAT_GROUPS, self.n
+        return self
+
+    def __exit__(self, *a):
+        global STAT_GROUPS
+        STAT_GROUPS = self.prev
+        return False
+
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     key = (dev.index, _lib.current_stream(dev))
@@ -34,31 +56,34 @@ class _BnActTrain(torch.autograd.Function):
     """y (conv output, no bias) -> dropout(leaky_relu(batch_norm_train(y + conv_bias)))."""
 
     @staticmethod
-    def forward(ctx, y, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, drop_p, seed, offset):
+    def forward(ctx, y, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, drop_p, seed, offset,
+                groups=1):
         _lib.require_device(y, "bn_act")
         y = y.contiguous()
         B, Cc, H, W = y.shape
+        if B % groups:
+            raise ValueError(f"bn_act: batch {B} is not divisible into {groups} statistics groups")
         dev = y.device
         out = torch.empty_like(y)
-        stats = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        stats = torch.empty((2, groups * Cc), dtype=torch.float32, device=dev)
         ws = _bn_ws(dev, B, Cc, H, W)
         with torch.cuda.device(dev):
-            rc = _lib.lib().uaps_bn_act_fwd_train(
+            rc = _lib.lib().uaps_bn_act_fwd_train_grouped(
                 y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None,
                 nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), float(slope), float(drop_p),
-                seed, offset, B, Cc, H, W, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
+                seed, offset, B, Cc, H, W, groups, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(),
                 ws.numel(), _lib.current_stream(dev))
-        _lib.check(rc, "uaps_bn_act_fwd_train")
+        _lib.check(rc, "uaps_bn_act_fwd_train_grouped")
         ctx.save_for_backward(y, gamma, beta, stats)
-        ctx.meta = (float(slope), float(drop_p), seed, offset, conv_bias is not None)
+        ctx.meta = (float(slope), float(drop_p), seed, offset, conv_bias is not None, groups)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         y, gamma, beta, stats = ctx.saved_tensors
-        slope, drop_p, seed, offset, has_bias = ctx.meta
+        slope, drop_p, seed, offset, has_bias, groups = ctx.meta
         dout = dout.contiguous()
         B, Cc, H, W = y.shape
         dev = y.device
@@ -66,14 +91,14 @@ class _BnActTrain(torch.autograd.Function):
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
         ws = _bn_ws(dev, B, Cc, H, W)
         with torch.cuda.device(dev):
-            rc = _lib.lib().uaps_bn_act_bwd(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                            stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B, Cc,
-                                            H, W, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
-                                            ws.numel(), _lib.current_stream(dev))
-        _lib.check(rc, "uaps_bn_act_bwd")
+            rc = _lib.lib().uaps_bn_act_bwd_grouped(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                    stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B,
+                                                    Cc, H, W, groups, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_bn_act_bwd_grouped")
         # the conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (sum of dy over a channel)
         dbias = torch.zeros_like(gamma) if has_bias else None
-        return dy, dbias, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+        return dy, dbias, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
 
 
 class _BnActEval(torch.autograd.Function):
@@ -123,7 +148,7 @@ def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2
         seed, off = _RngState.reserve(y.numel()) if p > 0 else (0, 0)
         mom = 0.1 if bn.momentum is None else bn.momentum
         return _BnActTrain.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                 mom, bn.eps, slope, p, seed, off)
+                                 mom, bn.eps, slope, p, seed, off, STAT_GROUPS)
     return _BnActEval.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, slope)
 
 

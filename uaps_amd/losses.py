@@ -238,6 +238,74 @@ def ce_loss(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return loss
 
 
+class _PairLoss(torch.autograd.Function):
+    """Supervised branch on rows [:B] and unsupervised branch on rows [B:] of D logit tensors [2B,C,H,W] (the output
+    of UNet_UAPS.forward_pair); the backward writes both halves of the D gradient tensors directly."""
+
+    @staticmethod
+    def forward(ctx, labels, w, cw1, cw2, eps, want_var, *logits):
+        zs, D, B2, Cc, H, W = _check_heads(logits, "uaps_pair_loss")
+        if B2 % 2:
+            raise ValueError("uaps_pair_loss: the batch must hold a labelled and an unlabelled half of equal size")
+        B = B2 // 2
+        dev = zs[0].device
+        if labels.shape != (B, H, W) or labels.device != dev:
+            raise ValueError(f"labels must be [B,H,W]={B, H, W} on {dev}, got {tuple(labels.shape)} on {labels.device}")
+        y = labels.to(torch.int64).contiguous()
+        L = _lib.lib()
+        half = B * Cc * H * W * 4
+        lab_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs])
+        un_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in zs])
+        need = C.c_size_t()
+        _lib.check(L.uaps_loss_workspace_bytes(D, B, Cc, H, W, C.byref(need)), "uaps_loss_workspace_bytes")
+        ws = _workspace(dev, need.value)
+        so, uo = _s_off(D, Cc), _u_off(D, Cc)
+        sscal = torch.empty(so["n"], dtype=torch.float32, device=dev)
+        uscal = torch.empty(uo["n"], dtype=torch.float32, device=dev)
+        pseudo = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+        var = torch.empty((D, B, H, W), dtype=torch.float32, device=dev) if want_var else None
+        w64 = (C.c_double * D)(*[float(x) for x in w])
+        st = _lib.current_stream(dev)
+        with torch.cuda.device(dev):
+            with _timed("uaps_sup_fwd"):
+                rc = L.uaps_sup_fwd(lab_p, y.data_ptr(), D, B, Cc, H, W, 0.5 / D, 0.5 / D, float(eps), sscal.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "uaps_sup_fwd")
+            with _timed("uaps_unsup_fwd"):
+                rc = L.uaps_unsup_fwd(un_p, w64, D, B, Cc, H, W, float(cw1), float(cw2), float(eps), pseudo.data_ptr(),
+                                      var.data_ptr() if want_var else None, uscal.data_ptr(), ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "uaps_unsup_fwd")
+        sup, unsup = sscal[so["sup"]].clone(), uscal[uo["loss"]].clone()
+        ctx.save_for_backward(y, pseudo, sscal, uscal, *zs)
+        ctx.meta = (D, B, Cc, H, W, float(cw1), float(cw2))
+        outs = (sup + unsup, sup, unsup, pseudo, sscal, uscal) + ((var,) if want_var else ())
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_loss, *unused):
+        y, pseudo, sscal, uscal, *zs = ctx.saved_tensors
+        D, B, Cc, H, W, cw1, cw2 = ctx.meta
+        dev = zs[0].device
+        g = g_loss.contiguous().to(torch.float32)
+        half = B * Cc * H * W * 4
+        dz = [torch.empty_like(z) for z in zs]
+        L = _lib.lib()
+        st = _lib.current_stream(dev)
+        lab_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs])
+        un_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in zs])
+        dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz])
+        dun_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in dz])
+        with torch.cuda.device(dev):
+            with _timed("uaps_sup_bwd"):
+                rc = L.uaps_sup_bwd(lab_p, y.data_ptr(), sscal.data_ptr(), 0.5 / D, 0.5 / D, g.data_ptr(), D, B, Cc, H, W, dlab_p, st)
+            _lib.check(rc, "uaps_sup_bwd")
+            with _timed("uaps_unsup_bwd"):
+                rc = L.uaps_unsup_bwd(un_p, pseudo.data_ptr(), uscal.data_ptr(), cw1, cw2, g.data_ptr(), D, B, Cc, H, W, dun_p, st)
+            _lib.check(rc, "uaps_unsup_bwd")
+        return (None, None, None, None, None, None) + tuple(dz)
+
+
 class StepLoss(NamedTuple):
     loss: torch.Tensor
     sup: torch.Tensor
@@ -246,6 +314,15 @@ class StepLoss(NamedTuple):
     var: Optional[torch.Tensor]
     sup_scalars: torch.Tensor
     unsup_scalars: torch.Tensor
+
+
+def uaps_pair_loss(pair_logits, labels, w, cw1, cw2, eps=1e-7, return_var=False) -> StepLoss:
+    """uaps_step_loss for the output of UNet_UAPS.forward_pair: D tensors [2B,C,H,W] whose rows [:B] are the labelled
+    batch (supervised branch, UAPS_train.py:194-218) and rows [B:] the unlabelled one (:186-189, 223-282)."""
+    if len(w) != len(pair_logits):
+        raise ValueError("one mixing weight per head")
+    out = _PairLoss.apply(labels, tuple(float(x) for x in w), cw1, cw2, eps, bool(return_var), *pair_logits)
+    return StepLoss(out[0], out[1], out[2], out[3], out[6] if return_var else None, out[4], out[5])
 
 
 def uaps_step_loss(lab_logits, labels, un_logits, w, cw1, cw2, eps=1e-7, return_var=False) -> StepLoss:

@@ -57,32 +57,44 @@ def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
 # ---- FeatureNoise -------------------------------------------------------------------------------
 
 class _NoiseRng(torch.autograd.Function):
+    """`offsets` holds one Philox offset per group of B/len(offsets) consecutive images: every group gets its own
+    [C,H,W] noise tensor, as one FeatureNoise call per reference forward would draw."""
+
     @staticmethod
-    def forward(ctx, x, seed, offset, rng, want_noise):
+    def forward(ctx, x, seed, offsets, rng, want_noise):
         x = _prep(x, "FeatureNoise")
         B, Cc, H, W = x.shape
+        G = len(offsets)
+        if B % G:
+            raise ValueError(f"FeatureNoise: batch {B} is not divisible into {G} groups")
+        Bg, chw = B // G, Cc * H * W
         y = torch.empty_like(x)
-        noise = torch.empty((Cc, H, W), dtype=torch.float32, device=x.device) if want_noise else None
+        noise = torch.empty((G, Cc, H, W), dtype=torch.float32, device=x.device) if want_noise else None
         with torch.cuda.device(x.device):
-            rc = _lib.lib().uaps_feat_noise(x.data_ptr(), y.data_ptr(), B, Cc, H, W, seed, offset, float(rng),
-                                            noise.data_ptr() if want_noise else None, _lib.current_stream(x.device))
-        _lib.check(rc, "uaps_feat_noise")
-        ctx.meta = (seed, offset, float(rng))
+            for g, off in enumerate(offsets):
+                rc = _lib.lib().uaps_feat_noise(x.data_ptr() + 4 * g * Bg * chw, y.data_ptr() + 4 * g * Bg * chw, Bg, Cc, H, W,
+                                                seed, off, float(rng), noise[g].data_ptr() if want_noise else None,
+                                                _lib.current_stream(x.device))
+                _lib.check(rc, "uaps_feat_noise")
+        ctx.meta = (seed, tuple(offsets), float(rng))
         if want_noise:
+            noise = noise[0] if G == 1 else noise
             ctx.mark_non_differentiable(noise)
             return y, noise
         return y
 
     @staticmethod
     def backward(ctx, gy, *unused):
-        seed, offset, rng = ctx.meta
+        seed, offsets, rng = ctx.meta
         gy = gy.contiguous()
         B, Cc, H, W = gy.shape
+        Bg, chw = B // len(offsets), Cc * H * W
         gx = torch.empty_like(gy)
         with torch.cuda.device(gy.device):
-            rc = _lib.lib().uaps_feat_noise(gy.data_ptr(), gx.data_ptr(), B, Cc, H, W, seed, offset, rng, None,
-                                            _lib.current_stream(gy.device))
-        _lib.check(rc, "uaps_feat_noise (backward)")
+            for g, off in enumerate(offsets):
+                rc = _lib.lib().uaps_feat_noise(gy.data_ptr() + 4 * g * Bg * chw, gx.data_ptr() + 4 * g * Bg * chw, Bg, Cc, H, W,
+                                                seed, off, rng, None, _lib.current_stream(gy.device))
+                _lib.check(rc, "uaps_feat_noise (backward)")
         return gx, None, None, None, None
 
 
@@ -125,9 +137,12 @@ class FeatureNoise(nn.Module):
         super().__init__()
         self.uniform_range = float(uniform_range)
 
-    def forward(self, x: torch.Tensor, return_noise: bool = False):
-        seed, off = _RngState.reserve(x[0].numel())
-        return _NoiseRng.apply(x, seed, off, self.uniform_range, return_noise)
+    def forward(self, x: torch.Tensor, return_noise: bool = False, groups: int = 1):
+        offs = []
+        for _ in range(groups):
+            seed, off = _RngState.reserve(x[0].numel())
+            offs.append(off)
+        return _NoiseRng.apply(x, seed, tuple(offs), self.uniform_range, return_noise)
 
 
 # ---- Dropout(x, p=0.5), always in training mode ---------------------------------------------------
@@ -205,13 +220,20 @@ _fd_ws: Dict[Tuple[int, int], torch.Tensor] = {}
 
 
 class _FeatDrop(torch.autograd.Function):
+    """`u` is one threshold factor, or a tuple with one per group of B/len(u) consecutive images."""
+
     @staticmethod
     def forward(ctx, x, u):
         x = _prep(x, "FeatureDropout")
         B, Cc, H, W = x.shape
+        us = tuple(u) if isinstance(u, (tuple, list)) else (float(u),)
+        G = len(us)
+        if B % G:
+            raise ValueError(f"FeatureDropout: batch {B} is not divisible into {G} groups")
+        Bg = B // G
         L = _lib.lib()
         need = C.c_size_t()
-        _lib.check(L.uaps_feat_dropout_workspace_bytes(B, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
+        _lib.check(L.uaps_feat_dropout_workspace_bytes(Bg, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
         key = (x.device.index, _lib.current_stream(x.device))
         ws = _fd_ws.get(key)
         if ws is None or ws.numel() < need.value:
@@ -220,9 +242,12 @@ class _FeatDrop(torch.autograd.Function):
         y = torch.empty_like(x)
         keep = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
-            rc = L.uaps_feat_dropout_fwd(x.data_ptr(), y.data_ptr(), B, Cc, H, W, float(u), keep.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), _lib.current_stream(x.device))
-        _lib.check(rc, "uaps_feat_dropout_fwd")
+            for g, ug in enumerate(us):
+                o = g * Bg * Cc * H * W * 4
+                rc = L.uaps_feat_dropout_fwd(x.data_ptr() + o, y.data_ptr() + o, Bg, Cc, H, W, float(ug),
+                                             keep.data_ptr() + g * Bg * H * W, ws.data_ptr(), ws.numel(),
+                                             _lib.current_stream(x.device))
+                _lib.check(rc, "uaps_feat_dropout_fwd")
         ctx.save_for_backward(keep)
         ctx.mark_non_differentiable(keep)
         return y, keep
@@ -242,10 +267,13 @@ class _FeatDrop(torch.autograd.Function):
 
 def feature_dropout_with(x: torch.Tensor, u: float, return_keep: bool = False):
     """UAPS_unet.py:161-169 with the np.random.uniform(0.7, 0.9) draw passed in."""
-    y, keep = _FeatDrop.apply(x, float(u))
+    y, keep = _FeatDrop.apply(x, tuple(u) if isinstance(u, (tuple, list)) else float(u))
     return (y, keep) if return_keep else y
 
 
-def FeatureDropout(x: torch.Tensor) -> torch.Tensor:
-    """UAPS_unet.py:161-169: zero the pixels whose channel-mean reaches U(0.7,0.9) x the sample maximum."""
-    return feature_dropout_with(x, np.random.uniform(0.7, 0.9))
+def FeatureDropout(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """UAPS_unet.py:161-169: zero the pixels whose channel-mean reaches U(0.7,0.9) x the sample maximum
+    (one threshold draw per call of the reference, i.e. per group here)."""
+    if groups == 1:
+        return feature_dropout_with(x, np.random.uniform(0.7, 0.9))
+    return feature_dropout_with(x, tuple(np.random.uniform(0.7, 0.9) for _ in range(groups)))

@@ -23,7 +23,7 @@ class UAPSTrainer:
     def __init__(self, model: torch.nn.Module, base_lr: float = 1e-3, consistency1: float = 0.1,
                  consistency2: float = 0.1, consistency_rampup: float = 200, ramp_divisor: int = 80,
                  seed: int = 1337, loss_fn: Optional[Callable] = None, overlap_comm: bool = True,
-                 track_metrics: bool = True):
+                 track_metrics: bool = True, pair_forward: bool = True):
         self.model = model
         params = list(model.parameters())
         self.device = params[0].device
@@ -40,6 +40,9 @@ class UAPSTrainer:
         np.random.seed(seed + self.rank)                      # FeatureDropout thresholds (numpy global RNG)
         perturb.manual_seed(seed, self.rank)                  # Philox streams offset by rank
         self.loss_fn = loss_fn or losses.uaps_step_loss       # no fallback: raises without the HIP library
+        # one pass over the concatenated labelled+unlabelled batch (per-half BatchNorm statistics and perturbation
+        # draws keep the two-forward semantics) instead of two forwards; needs the HIP kernels, i.e. a GPU model
+        self.pair_forward = pair_forward and on_gpu and loss_fn is None and hasattr(model, "forward_pair")
         self.track_metrics = track_metrics and loss_fn is None
         self.buckets = udist.GradBuckets(model, overlap=overlap_comm) if self.world > 1 else None
         self.confusion = None
@@ -53,14 +56,21 @@ class UAPSTrainer:
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u: torch.Tensor, w=None) -> Dict[str, torch.Tensor]:
         """Returns device scalars (loss, sup, unsup); nothing here synchronises with the host."""
         self.model.train()
-        lab = self.model(x_l)                                                     # UAPS_train.py:177
-        un = self.model(x_u)                                                      # :185
-        if not isinstance(lab, (tuple, list)):
-            lab, un = (lab,), (un,)
-        if w is None:
-            w = self.mix_rng.dirichlet(np.ones(len(un)), size=1)[0]              # :251
         cw1, cw2 = self.consistency_weights()
-        out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                             # :186-282
+        if self.pair_forward and x_l.shape == x_u.shape:
+            both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
+            if w is None:
+                w = self.mix_rng.dirichlet(np.ones(len(both)), size=1)[0]        # :251
+            out = losses.uaps_pair_loss(both, y_l, w, cw1, cw2)                   # :186-282
+            lab = tuple(z[: x_l.shape[0]] for z in both)
+        else:
+            lab = self.model(x_l)                                                 # UAPS_train.py:177
+            un = self.model(x_u)                                                  # :185
+            if not isinstance(lab, (tuple, list)):
+                lab, un = (lab,), (un,)
+            if w is None:
+                w = self.mix_rng.dirichlet(np.ones(len(un)), size=1)[0]          # :251
+            out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                         # :186-282
         self.optimizer.zero_grad(set_to_none=True)                                # :285
         out.loss.backward()                                                       # :287
         if self.buckets is not None:

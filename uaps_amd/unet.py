@@ -162,14 +162,26 @@ class UNet_UAPS(nn.Module):
     def aux_decoders(self) -> List[Decoder]:
         return [getattr(self, f"aux_decoder{i}") for i in range(1, self.n_aux + 1)]
 
-    def _perturb(self, kind: str, feats):
+    def _perturb(self, kind: str, feats, groups: int = 1):
         if kind == "noise":
-            return [self._noise(f) for f in feats]
+            return [self._noise(f, groups=groups) for f in feats]
         if kind == "dropout":
             return [perturb.Dropout(f) for f in feats]
-        return [perturb.FeatureDropout(f) for f in feats]
+        return [perturb.FeatureDropout(f, groups=groups) for f in feats]
 
-    def forward(self, x, perturbations=None):
+    def forward_pair(self, x_a, x_b, perturbations=None):
+        """The two forwards of a training step (UAPS_train.py:177 labelled, :185 unlabelled) as ONE pass over the
+        concatenated batch: every convolution runs once on 2B images, while everything the reference computes per
+        forward call keeps its per-call meaning -- train-mode BatchNorm statistics (and the two successive
+        running-statistics updates), the FeatureNoise tensor and the FeatureDropout threshold are per half.
+        Returns D logit tensors of shape [2B, class_num, H, W]; rows [:B] belong to x_a, rows [B:] to x_b.
+        GPU only (the grouped kernels have no PyTorch counterpart)."""
+        if x_a.shape != x_b.shape:
+            raise ValueError("forward_pair: the two batches must have the same shape")
+        with fused.stat_groups(2):
+            return self.forward(torch.cat([x_a, x_b], dim=0), perturbations, _groups=2)
+
+    def forward(self, x, perturbations=None, _groups: int = 1):
         """`perturbations`: optional list (one entry per auxiliary decoder) of callables
         feats -> feats replacing the random draws (parity tests inject recorded draws here)."""
         feats = self.encoder(x)
@@ -178,6 +190,6 @@ class UNet_UAPS(nn.Module):
             if perturbations is not None and perturbations[i] is not None:
                 pf = perturbations[i](feats)
             else:
-                pf = self._perturb(_PERTURBATIONS[i % 3], feats)
+                pf = self._perturb(_PERTURBATIONS[i % 3], feats, _groups)
             outs.append(dec(pf))
         return tuple(outs)
