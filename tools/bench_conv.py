@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--cfg-sweep", action="store_true")
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--lds-sweep", action="store_true", help="forward kernel with 0..56 KB of extra (unused) LDS = fewer workgroups per CU")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
@@ -71,11 +72,18 @@ def main():
         for k, v in zip(("fwd", "bwd", "wrw", "mfwd", "mbwd", "mwrw"), (t_f, t_b, t_w, m_f, m_b, m_w)):
             tot[k] += v * calls
         print(f"{name:28s} {gf:6.2f} | {t_f:8.1f} {gf / t_f * 1e3:6.1f} {m_f:8.1f} | {t_b:8.1f} {gf / t_b * 1e3:6.1f} {m_b:8.1f} | {t_w:8.1f} {gf / t_w * 1e3:6.1f} {m_w:8.1f}", flush=True)
+        if args.lds_sweep:
+            res = []
+            for rep in range(2):
+                for kb in (0, 8, 16, 24, 32, 40, 56):
+                    t = timeit(lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, cfg=kb << 16), iters=20)
+                    res.append(f"{kb}KB:{t:.1f}")
+            print("      fwd extra-LDS sweep (us): " + " ".join(res))
         if args.cfg_sweep:
             for bn in (16, 32, 64):
                 for tile in (1, 2):
                     try:
-                        t = timeit(lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, cfg=bn | (tile << 8)))
+                        t = timeit(lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, cfg=bn | (tile << 8)), iters=20)
                         print(f"      fwd bn={bn} tile={'8x32' if tile == 1 else '16x16'}: {t:8.1f} us {gf / t * 1e3:6.1f} TF/s")
                     except Exception as ex:
                         pass

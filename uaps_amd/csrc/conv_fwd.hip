@@ -12,28 +12,29 @@ inline int kdim_pad(int c, int ks) { return (ks == 3 && c <= 4) ? 4 : round_up(c
 inline int ndim_pad(int c) { return round_up(c, 16); }              // N (output) channels: 16-wide MFMA tiles
 
 template <int KS, int TH, int TW, int BN, int CK>
-int launch_fwd(ConvFwdArgs a, bool vec, hipStream_t s) {
+int launch_fwd(ConvFwdArgs a, bool vec, int extra_lds, hipStream_t s) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     a.nblk = a.CoutP / BN;
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;   // multiple of 8 for the XCD swizzle
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    // extra_lds: unused dynamic LDS, requested only to cap the number of co-resident workgroups per CU
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
     return (int)hipGetLastError();
 }
 
 template <int KS, int TH, int TW>
-int dispatch_bn_ck(const ConvFwdArgs& a, int bn, int ck, bool vec, hipStream_t s) {
+int dispatch_bn_ck(const ConvFwdArgs& a, int bn, int ck, bool vec, int xl, hipStream_t s) {
     if constexpr (KS == 3) {
-        if (ck == 4) return launch_fwd<KS, TH, TW, 16, 4>(a, vec, s);
+        if (ck == 4) return launch_fwd<KS, TH, TW, 16, 4>(a, vec, xl, s);
     }
-    if (bn == 16) return launch_fwd<KS, TH, TW, 16, 8>(a, vec, s);
-    if (bn == 32) return launch_fwd<KS, TH, TW, 32, 8>(a, vec, s);
-    return launch_fwd<KS, TH, TW, 64, 8>(a, vec, s);
+    if (bn == 16) return launch_fwd<KS, TH, TW, 16, 8>(a, vec, xl, s);
+    if (bn == 32) return launch_fwd<KS, TH, TW, 32, 8>(a, vec, xl, s);
+    return launch_fwd<KS, TH, TW, 64, 8>(a, vec, xl, s);
 }
 
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP; };
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
@@ -44,7 +45,8 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // 16-byte loads/stores need rows that start 16-byte aligned
     p->vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     // pixel tile: 8 rows x 32 columns, or 16 x 16 for narrow maps (both 256 pixels = 16 M tiles)
-    const bool wide = (cfg >> 8) ? ((cfg >> 8) == 1) : (W >= 32);
+    const bool wide = ((cfg >> 8) & 3) ? (((cfg >> 8) & 3) == 1) : (W >= 32);
+    p->extra_lds = ((cfg >> 16) & 0xff) * 1024;
     p->th = wide ? 8 : 16; p->tw = wide ? 32 : 16;
     int bn = (p->CoutP % 64 == 0) ? 64 : (p->CoutP % 32 == 0 ? 32 : 16);
     const long tiles = (long)B * ((H + p->th - 1) / p->th) * ((W + p->tw - 1) / p->tw);
@@ -66,8 +68,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     const bool wide = p.tw == 32;
-    if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, s);
-    return wide ? dispatch_bn_ck<1, 8, 32>(a, p.bn, p.ck, p.vec, s) : dispatch_bn_ck<1, 16, 16>(a, p.bn, p.ck, p.vec, s);
+    if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
+    return wide ? dispatch_bn_ck<1, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<1, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
 }
 
 }  // namespace

@@ -19,6 +19,7 @@ namespace uaps {
 
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 1024;
+constexpr int kFinalizeThreads = 1024;   // 16 waves: 3 of the <= 48 sums each
 
 template <int D> struct HeadPtrs { const float* p[D]; };
 template <int D> struct HeadOutPtrs { float* p[D]; };
@@ -81,13 +82,28 @@ template <int C> __device__ __forceinline__ void softmax_regs(const float (&z)[C
     for (int c = 0; c < C; ++c) { p[c] *= inv; lp[c] = z[c] - lse; }
 }
 
+// Sum over the 64 lanes of a wave, result valid in every lane.  Within each row of 16 lanes the adds are DPP
+// modifiers on v_add_f32 (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): no LDS traffic and no waits, unlike
+// __shfl_xor, which lowers to ds_bpermute_b32 + s_waitcnt per step (the 48 sums of the unsupervised forward cost 288
+// dependent LDS round trips per thread that way and dominated the kernel).  The four row sums are then read with
+// v_readlane and added in a fixed order.
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);    // row_half_mirror
+    v += dpp_f32<0x140>(v);    // row_mirror: every lane of a 16-lane row now holds the row sum
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
-// Block reduction of NS per-thread partial sums into row `blockIdx.x` of `partials` ([gridDim.x][NS]).
+// Block reduction of NS per-thread partial sums into column `blockIdx.x` of `partials` ([NS][gridDim.x], sum-major so
+// that the finalize kernel reads each sum's block partials as one coalesced run).
 template <int NS> __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], float* partials) {
     __shared__ float red[kThreads / 64][NS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,7 +117,7 @@ template <int NS> __device__ __forceinline__ void block_reduce_store(float (&acc
         float s = red[0][i];
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) s += red[w][i];
-        partials[(size_t)blockIdx.x * NS + i] = s;
+        partials[(size_t)i * gridDim.x + blockIdx.x] = s;
     }
 }
 
@@ -258,17 +274,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 template <bool UNSUP>
-__global__ __launch_bounds__(kThreads) void finalize_kernel(const float* __restrict__ partials, int nrows, int D, int C,
+__global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const float* __restrict__ partials, int nrows, int D, int C,
                                                             long N, float cw1, float cw2, float eps,
                                                             float* __restrict__ out) {
     __shared__ double tot[4 * UAPS_MAX_HEADS + 2 * UAPS_MAX_HEADS * UAPS_MAX_CLASSES + UAPS_MAX_CLASSES + 1];
     __shared__ double dice_s[UAPS_MAX_HEADS];
     const int NS = UNSUP ? (D + 2 * D * C + C + 2 * D) : (D + 2 * D * C + C + 1);
+    // kFinalizeThreads / 64 waves, one sum per wave at a time: coalesced reads of that sum's nrows block partials,
+    // lane-strided double accumulation, then a fixed-order wave reduction
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < NS; i += kThreads / 64) {
-        double s = 0.0;
-        for (int r = lane; r < nrows; r += 64) s += (double)partials[(size_t)r * NS + i];
-        s = wave_sum_d(s);
+    for (int i = wave; i < NS; i += kFinalizeThreads / 64) {
+        const float* src = partials + (size_t)i * nrows;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = lane;
+        for (; r + 192 < nrows; r += 256) {
+            s0 += (double)src[r]; s1 += (double)src[r + 64]; s2 += (double)src[r + 128]; s3 += (double)src[r + 192];
+        }
+        for (; r < nrows; r += 64) s0 += (double)src[r];
+        const double s = wave_sum_d((s0 + s1) + (s2 + s3));
         if (lane == 0) tot[i] = s;
     }
     __syncthreads();

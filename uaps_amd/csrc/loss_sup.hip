@@ -12,7 +12,7 @@ template <int D, int C> static int run_sup_fwd(const LossArgs& a) {
         nrows = grid_for(N);
         hipLaunchKernelGGL((sup_fwd_kernel<D, C, 1>), dim3(nrows), dim3(kThreads), 0, a.stream, z, (int)HW, N, a.labels, a.partials);
     }
-    hipLaunchKernelGGL((finalize_kernel<false>), dim3(1), dim3(kThreads), 0, a.stream, a.partials, nrows, D, C, N, a.cw1, a.cw2, a.eps, a.scalars);
+    hipLaunchKernelGGL((finalize_kernel<false>), dim3(1), dim3(kFinalizeThreads), 0, a.stream, a.partials, nrows, D, C, N, a.cw1, a.cw2, a.eps, a.scalars);
     return (int)hipGetLastError();
 }
 template <int D, int C> static int run_sup_bwd(const LossArgs& a) {

@@ -14,7 +14,7 @@ template <int D, int C> static int run_unsup_fwd(const LossArgs& a) {
         nrows = grid_for(N);
         hipLaunchKernelGGL((unsup_fwd_kernel<D, C, 1>), dim3(nrows), dim3(kThreads), 0, a.stream, z, w, (int)HW, N, N, a.pseudo, a.var, a.partials);
     }
-    hipLaunchKernelGGL((finalize_kernel<true>), dim3(1), dim3(kThreads), 0, a.stream, a.partials, nrows, D, C, N, a.cw1, a.cw2, a.eps, a.scalars);
+    hipLaunchKernelGGL((finalize_kernel<true>), dim3(1), dim3(kFinalizeThreads), 0, a.stream, a.partials, nrows, D, C, N, a.cw1, a.cw2, a.eps, a.scalars);
     return (int)hipGetLastError();
 }
 int launch_unsup_fwd(const LossArgs& a) { UAPS_DISPATCH_DC(run_unsup_fwd, a) }

@@ -108,25 +108,42 @@ __global__ __launch_bounds__(kThreads) void mask_apply_kernel(const float* __res
 __device__ __forceinline__ uint32_t fkey(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float fkey_inv(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-// pass A: att[b,hw] = (sum_c x[b,c,hw]) / C, per-sample max via wave reduce + one atomicMax per wave
+// pass A: att[b,hw] = (sum_c x[b,c,hw]) / C, per-sample max via wave reduce + one atomicMax per wave.
+// V pixels per lane (16-byte loads when V == 4); the channel sum keeps the c = 0..C-1 order.
+template <int V>
 __global__ __launch_bounds__(kThreads) void fdrop_attention(const float* __restrict__ x, int C, long HW, float* __restrict__ att,
                                                             uint32_t* __restrict__ maxkey) {
     const int b = blockIdx.y;
     const float* xb = x + (long)b * C * HW;
     uint32_t best = 0;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
-        float s = xb[i];
-        for (int c = 1; c < C; ++c) s = add_rn(s, xb[(long)c * HW + i]);
-        const float a = s / (float)C;
-        att[(long)b * HW + i] = a;
-        const uint32_t k = fkey(a);
-        best = k > best ? k : best;
+    for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * V; i < HW; i += (long)gridDim.x * kThreads * V) {
+        float s[V];
+        if constexpr (V == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + i);
+            s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
+            for (int c = 1; c < C; ++c) {
+                const float4 t = *reinterpret_cast<const float4*>(xb + (long)c * HW + i);
+                s[0] = add_rn(s[0], t.x); s[1] = add_rn(s[1], t.y); s[2] = add_rn(s[2], t.z); s[3] = add_rn(s[3], t.w);
+            }
+        } else {
+            s[0] = xb[i];
+            for (int c = 1; c < C; ++c) s[0] = add_rn(s[0], xb[(long)c * HW + i]);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            s[k] = s[k] / (float)C;
+            const uint32_t key = fkey(s[k]);
+            best = key > best ? key : best;
+        }
+        if constexpr (V == 4) *reinterpret_cast<float4*>(att + (long)b * HW + i) = make_float4(s[0], s[1], s[2], s[3]);
+        else att[(long)b * HW + i] = s[0];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t > best ? t : best; }
     if ((threadIdx.x & 63) == 0 && best) atomicMax(maxkey + b, best);
 }
 // pass B: keep = att < max * u ; y = x * keep
+template <int V>
 __global__ __launch_bounds__(kThreads) void fdrop_apply(const float* __restrict__ x, float* __restrict__ y, int C, long HW,
                                                         const float* __restrict__ att, const uint32_t* __restrict__ maxkey,
                                                         float u, uint8_t* __restrict__ keep) {
@@ -134,18 +151,38 @@ __global__ __launch_bounds__(kThreads) void fdrop_apply(const float* __restrict_
     const float thr = mul_rn(fkey_inv(maxkey[b]), u);
     const float* xb = x + (long)b * C * HW;
     float* yb = y + (long)b * C * HW;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
-        const bool k = att[(long)b * HW + i] < thr;
-        keep[(long)b * HW + i] = k;
-        for (int c = 0; c < C; ++c) yb[(long)c * HW + i] = k ? xb[(long)c * HW + i] : 0.f;
+    for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * V; i < HW; i += (long)gridDim.x * kThreads * V) {
+        if constexpr (V == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(att + (long)b * HW + i);
+            const bool k0 = a.x < thr, k1 = a.y < thr, k2 = a.z < thr, k3 = a.w < thr;
+            *reinterpret_cast<uchar4*>(keep + (long)b * HW + i) = make_uchar4(k0, k1, k2, k3);
+            for (int c = 0; c < C; ++c) {
+                const float4 v = *reinterpret_cast<const float4*>(xb + (long)c * HW + i);
+                *reinterpret_cast<float4*>(yb + (long)c * HW + i) = make_float4(k0 ? v.x : 0.f, k1 ? v.y : 0.f, k2 ? v.z : 0.f, k3 ? v.w : 0.f);
+            }
+        } else {
+            const bool k = att[(long)b * HW + i] < thr;
+            keep[(long)b * HW + i] = k;
+            for (int c = 0; c < C; ++c) yb[(long)c * HW + i] = k ? xb[(long)c * HW + i] : 0.f;
+        }
     }
 }
+template <int V>
 __global__ __launch_bounds__(kThreads) void fdrop_bwd(const float* __restrict__ dy, const uint8_t* __restrict__ keep,
                                                       float* __restrict__ dx, int C, long HW) {
     const int b = blockIdx.y;
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < HW; i += (long)gridDim.x * kThreads) {
-        const bool k = keep[(long)b * HW + i];
-        for (int c = 0; c < C; ++c) { const long o = ((long)b * C + c) * HW + i; dx[o] = k ? dy[o] : 0.f; }
+    for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * V; i < HW; i += (long)gridDim.x * kThreads * V) {
+        if constexpr (V == 4) {
+            const uchar4 k = *reinterpret_cast<const uchar4*>(keep + (long)b * HW + i);
+            for (int c = 0; c < C; ++c) {
+                const long o = ((long)b * C + c) * HW + i;
+                const float4 v = *reinterpret_cast<const float4*>(dy + o);
+                *reinterpret_cast<float4*>(dx + o) = make_float4(k.x ? v.x : 0.f, k.y ? v.y : 0.f, k.z ? v.z : 0.f, k.w ? v.w : 0.f);
+            }
+        } else {
+            const bool k = keep[(long)b * HW + i];
+            for (int c = 0; c < C; ++c) { const long o = ((long)b * C + c) * HW + i; dx[o] = k ? dy[o] : 0.f; }
+        }
     }
 }
 
@@ -230,9 +267,15 @@ extern "C" int uaps_feat_dropout_fwd(const float* x, float* y, int B, int C, int
     float* att = (float*)((char*)ws + (((size_t)B * 4 + 255) / 256) * 256);
     hipError_t e = hipMemsetAsync(maxkey, 0, (size_t)B * 4, s);
     if (e != hipSuccess) return (int)e;
-    int gx = grid_for(HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
-    hipLaunchKernelGGL(fdrop_attention, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
-    hipLaunchKernelGGL(fdrop_apply, dim3(gx, B), dim3(kThreads), 0, s, x, y, C, HW, att, maxkey, u, keep);
+    const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)keep % 4 == 0);
+    int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
+    if (vec) {
+        hipLaunchKernelGGL(fdrop_attention<4>, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
+        hipLaunchKernelGGL(fdrop_apply<4>, dim3(gx, B), dim3(kThreads), 0, s, x, y, C, HW, att, maxkey, u, keep);
+    } else {
+        hipLaunchKernelGGL(fdrop_attention<1>, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
+        hipLaunchKernelGGL(fdrop_apply<1>, dim3(gx, B), dim3(kThreads), 0, s, x, y, C, HW, att, maxkey, u, keep);
+    }
     return (int)hipGetLastError();
 }
 
@@ -240,8 +283,10 @@ extern "C" int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float
                                      uaps_stream_t stream) {
     if (!dy || !dx || !keep || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     const long HW = (long)H * W;
-    int gx = grid_for(HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
-    hipLaunchKernelGGL(fdrop_bwd, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
+    const bool vec = (HW % 4 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)keep % 4 == 0);
+    int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
+    if (vec) hipLaunchKernelGGL(fdrop_bwd<4>, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
+    else hipLaunchKernelGGL(fdrop_bwd<1>, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
     return (int)hipGetLastError();
 }
 

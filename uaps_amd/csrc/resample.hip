@@ -75,40 +75,78 @@ __global__ __launch_bounds__(kThreads) void up_cat_fwd_kernel(const float* __res
 
 // d_skip = dout[:, :Cs] (copy) ;  d_low = transpose of the interpolation applied to dout[:, Cs:].
 // The transpose is a gather: low-res pixel (iy, ix) collects from the output rows/cols whose source
-// index touches it, so no atomics and a fixed summation order.
+// index touches it (at most 7 candidates per axis), so no atomics and a fixed summation order:
+//   d_low[iy][ix] = sum_oy wy(oy, iy) * ( sum_ox wx(ox, ix) * dout[oy][ox] ).
+// A block owns an 8 x 32 low-res tile of one (b, c) plane: it stages the 22 x 72 high-res patch in LDS with
+// coalesced 16-byte loads, reduces it along x into T[22][32] (each thread's 7 column weights are computed
+// once), then along y.  Same association as the plain double loop, 26 LDS reads per output instead of 49
+// scattered global ones.
+constexpr int kLy = 8, kLx = 32, kPr = 2 * kLy + 6, kPc = 2 * kLx + 8;   // patch rows / columns (x origin 2*ix0 - 4)
+
+__device__ __forceinline__ float tap_weight(float r, int o, int n_out, int n_in, int i) {
+    if (o < 0 || o >= n_out) return 0.f;
+    const float sx = mul_rn(r, (float)o);   // rounded product, as ATen: the fraction is taken from it
+    const int i0 = (int)sx, i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    const float l1 = sx - i0, l0 = 1.f - l1;
+    return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
 __global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* __restrict__ dout, float* __restrict__ dlow, int B,
-                                                                  int Cs, int Cl, int h, int w, float rh, float rw) {
+                                                                  int Cs, int Cl, int h, int w, float rh, float rw,
+                                                                  int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float sA[kPr * kPc];
+    __shared__ float sT[kPr * kLx];
     const int H = 2 * h, W = 2 * w, Ct = Cs + Cl;
-    const long total = (long)B * Cl * h * w;
-    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < total; g += (long)gridDim.x * kThreads) {
-        const int ix = (int)(g % w);
-        long t = g / w;
-        const int iy = (int)(t % h); t /= h;
-        const int c = (int)(t % Cl);
-        const int b = (int)(t / Cl);
-        const float* p = dout + (((long)b * Ct + Cs + c) * H) * W;
-        // candidate output rows: src = rh*oy in (iy-1, iy+1)
-        int oy_lo = 2 * iy - 3, oy_hi = 2 * iy + 3, ox_lo = 2 * ix - 3, ox_hi = 2 * ix + 3;
-        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
-        oy_hi = oy_hi > H - 1 ? H - 1 : oy_hi; ox_hi = ox_hi > W - 1 ? W - 1 : ox_hi;
-        float acc = 0.f;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            const float sy = mul_rn(rh, (float)oy);   // rounded product, as ATen: the fraction is taken from it
-            const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
-            const float lh1 = sy - h0, lh0 = 1.f - lh1;
-            const float wy = (h0 == iy ? lh0 : 0.f) + (h1 == iy ? lh1 : 0.f);
-            if (wy == 0.f) continue;
-            float row = 0.f;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                const float sx = mul_rn(rw, (float)ox);
-                const int w0 = (int)sx, w1 = w0 + (w0 < w - 1 ? 1 : 0);
-                const float lw1 = sx - w0, lw0 = 1.f - lw1;
-                const float wx = (w0 == ix ? lw0 : 0.f) + (w1 == ix ? lw1 : 0.f);
-                if (wx != 0.f) row += wx * p[(long)oy * W + ox];
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; bid /= tiles_y;
+    const int c = bid % Cl, b = bid / Cl;
+    const int iy0 = ty * kLy, ix0 = tx * kLx;
+    const int oy0 = 2 * iy0 - 3, ox0 = 2 * ix0 - 4;
+    const float* p = dout + (((long)b * Ct + Cs + c) * H) * W;
+    const bool vec = (W % 4) == 0;
+    // ---- stage the patch (zero outside the image) ----
+    for (int u = threadIdx.x; u < kPr * (kPc / 4); u += kThreads) {
+        const int r = u / (kPc / 4), x4 = (u % (kPc / 4)) * 4;
+        const int oy = oy0 + r, ox = ox0 + x4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oy >= 0 && oy < H) {
+            if (vec && ox >= 0 && ox + 3 < W) {
+                v = *reinterpret_cast<const float4*>(p + (long)oy * W + ox);
+            } else {
+                const float* q = p + (long)oy * W;
+                if (ox >= 0 && ox < W) v.x = q[ox];
+                if (ox + 1 >= 0 && ox + 1 < W) v.y = q[ox + 1];
+                if (ox + 2 >= 0 && ox + 2 < W) v.z = q[ox + 2];
+                if (ox + 3 >= 0 && ox + 3 < W) v.w = q[ox + 3];
             }
-            acc += wy * row;
         }
-        dlow[g] = acc;
+        *reinterpret_cast<float4*>(&sA[r * kPc + x4]) = v;
+    }
+    const int lx = threadIdx.x % kLx, ly = threadIdx.x / kLx;
+    const int ix = ix0 + lx, iy = iy0 + ly;
+    float wx[7], wy[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        wx[k] = tap_weight(rw, 2 * ix - 3 + k, W, w, ix);
+        wy[k] = tap_weight(rh, 2 * iy - 3 + k, H, h, iy);
+    }
+    __syncthreads();
+    // ---- reduce along x: T[r][lx] = sum_k wx[k] * A[r][2*lx + 1 + k]   (2*ix - 3 + k - ox0 = 2*lx + 1 + k) ----
+    for (int r = ly; r < kPr; r += kThreads / kLx) {
+        const float* a = &sA[r * kPc + 2 * lx + 1];
+        float row = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) if (wx[k] != 0.f) row += wx[k] * a[k];
+        sT[r * kLx + lx] = row;
+    }
+    __syncthreads();
+    // ---- reduce along y: rows 2*iy - 3 + k - oy0 = 2*ly + k ----
+    if (ix < w && iy < h) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) if (wy[k] != 0.f) acc += wy[k] * sT[(2 * ly + k) * kLx + lx];
+        dlow[(((long)b * Cl + c) * h + iy) * w + ix] = acc;
     }
 }
 
@@ -157,6 +195,9 @@ extern "C" int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int
         else
             hipLaunchKernelGGL(slice_channels_kernel<false>, dim3(grid_for((long)B * Cs * HW)), dim3(kThreads), 0, s, dout, dskip, B, Cs + Cl, 0, Cs, HW);
     }
-    hipLaunchKernelGGL(up_cat_bwd_low_kernel, dim3(grid_for((long)B * Cl * h * w)), dim3(kThreads), 0, s, dout, dlow, B, Cs, Cl, h, w, rh, rw);
+    const int tiles_x = (w + kLx - 1) / kLx, tiles_y = (h + kLy - 1) / kLy;
+    const long nblk = (long)B * Cl * tiles_x * tiles_y;
+    if (nblk > 0x7fffffffL) return UAPS_ERANGE;
+    hipLaunchKernelGGL(up_cat_bwd_low_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, s, dout, dlow, B, Cs, Cl, h, w, rh, rw, tiles_x, tiles_y);
     return (int)hipGetLastError();
 }
