@@ -162,6 +162,14 @@ int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_bias, const 
                                   float eps, float slope, float drop_p, uint64_t seed, uint64_t offset, int B, int C,
                                   int H, int W, int groups, float* out, float* save_mean, float* save_invstd,
                                   void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+/* The same, with the statistics pass already done by the producer of y: `partials` is float2
+ * [C][B][parts_per_image] of per-image partial (sum, sum of squares), as uaps_conv_fwd_stats writes them. */
+int uaps_bn_act_fwd_train_partials(const void* partials, int parts_per_image, const float* y, const float* conv_bias,
+                                   const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                   int64_t* num_batches_tracked, float momentum, float eps, float slope, float drop_p,
+                                   uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* out,
+                                   float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes,
+                                   uaps_stream_t stream);
 int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
                             uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
@@ -204,9 +212,19 @@ int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs,
  * ------------------------------------------------------------------------------------------- */
 int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);
 int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream);
+/* n convolutions packed by one launch (host arrays with n entries; wf[i] or wb[i] may be NULL). */
+int uaps_conv_pack_weights_batch(const float* const* w_host, float* const* wf_host, float* const* wb_host,
+                                 const int* Cout_host, const int* Cin_host, const int* ks_host, int n,
+                                 uaps_stream_t stream);
 /* y [B,Cout,H,W] = conv2d(x [B,Cin,H,W], w) (+ bias[Cout] if bias != NULL) */
 int uaps_conv_fwd(const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout, int H,
                   int W, int ks, int cfg, uaps_stream_t stream);
+/* uaps_conv_fwd that also writes the first pass of the BatchNorm that follows (UAPS_unet.py:37-38, 41-42):
+ * stats = float2 [Cout][B][parts_per_image] per-tile (sum, sum of squares) of y, parts_per_image from
+ * uaps_conv_fwd_stats_parts; consumed by uaps_bn_act_fwd_train_partials. */
+int uaps_conv_fwd_stats(const float* x, const float* wf, const float* bias, float* y, void* stats, int B, int Cin,
+                        int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W, int ks, int cfg, int* parts_per_image_host);
 /* dx [B,Cin,H,W] = conv_transpose2d(dy [B,Cout,H,W], w) */
 int uaps_conv_bwd_data(const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H, int W,
                        int ks, int cfg, uaps_stream_t stream);

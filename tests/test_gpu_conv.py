@@ -108,3 +108,29 @@ def test_conv_refuses_cpu_tensors():
     from uaps_amd._lib import UapsHipError
     with pytest.raises(UapsHipError):
         conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16)])
+def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
+    """conv2d_with_stats: the per-tile (sum, sum of squares) written by the conv epilogue must add up to the
+    statistics of y, and bn_act fed with them must equal bn_act running its own statistics pass."""
+    from uaps_amd import fused
+    from uaps_amd.conv import conv2d, conv2d_with_stats
+    dev = torch.device("cuda:0")
+    x = _mk((B, Cin, H, W), 11).to(dev)
+    w = (_mk((Cout, Cin, 3, 3), 12) / np.sqrt(9 * Cin)).to(dev)
+    y, st = conv2d_with_stats(x, w)
+    assert torch.equal(y, conv2d(x, w))
+    assert st.shape[:2] == (Cout, B) and st.shape[-1] == 2
+    s_ref = y.double().sum(dim=(2, 3)).t()                       # [Cout, B]
+    q_ref = (y.double() ** 2).sum(dim=(2, 3)).t()
+    np.testing.assert_allclose(st[..., 0].double().sum(-1).cpu().numpy(), s_ref.cpu().numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(st[..., 1].double().sum(-1).cpu().numpy(), q_ref.cpu().numpy(), rtol=1e-5)
+    for groups in (1, 2):
+        bn1, bn2 = torch.nn.BatchNorm2d(Cout).to(dev), torch.nn.BatchNorm2d(Cout).to(dev)
+        with fused.stat_groups(groups):
+            a1 = fused.bn_act(y, None, bn1, 0.01, 0.0, True)
+            a2 = fused.bn_act(y, None, bn2, 0.01, 0.0, True, st)
+        assert float((a1 - a2).abs().max()) < 2e-5
+        assert torch.allclose(bn1.running_mean, bn2.running_mean, atol=1e-6) and torch.allclose(bn1.running_var, bn2.running_var, rtol=1e-5)
+        assert int(bn2.num_batches_tracked) == groups

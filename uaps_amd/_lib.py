@@ -40,6 +40,7 @@ SIGNATURES = {
     "uaps_bn_workspace_bytes": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_size_t)]),
     "uaps_bn_act_fwd_train": (C.c_int, [_PTR] * 7 + [C.c_float] * 4 + [C.c_uint64, C.c_uint64] + [C.c_int] * 4 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_fwd_train_grouped": (C.c_int, [_PTR] * 7 + [C.c_float] * 4 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
+    "uaps_bn_act_fwd_train_partials": (C.c_int, [_PTR, C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_bwd_grouped": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_fwd_eval": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_int] * 4 + [_PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_bwd": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_uint64, C.c_uint64] + [C.c_int] * 4 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
@@ -48,7 +49,10 @@ SIGNATURES = {
     "uaps_up_cat_bwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 5 + [_PTR]),
     "uaps_conv_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "uaps_conv_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
+    "uaps_conv_pack_weights_batch": (C.c_int, [_PTR] * 6 + [C.c_int, _PTR]),
     "uaps_conv_fwd": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_fwd_stats": (C.c_int, [_PTR] * 5 + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_fwd_stats_parts": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_int)]),
     "uaps_conv_bwd_data": (C.c_int, [_PTR] * 3 + [C.c_int] * 7 + [_PTR]),
     "uaps_conv_wrw_workspace_bytes": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_size_t)]),
     "uaps_conv_bwd_weight_partial": (C.c_int, [_PTR, _PTR] + [C.c_int] * 8 + [_PTR, C.c_size_t, _PTR]),

@@ -123,14 +123,81 @@ def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
     return wf, wb
 
 
-def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ks: int, cfg: int = 0):
+_parts_cache: Dict[tuple, int] = {}
+
+
+def stats_parts_per_image(B: int, Cin: int, Cout: int, H: int, W: int, ks: int, cfg: int = 0) -> int:
+    key = (B, Cin, Cout, H, W, ks, cfg)
+    n = _parts_cache.get(key)
+    if n is None:
+        out = C.c_int()
+        _lib.check(_lib.lib().uaps_conv_fwd_stats_parts(B, Cin, Cout, H, W, ks, cfg, C.byref(out)), "uaps_conv_fwd_stats_parts")
+        n = _parts_cache[key] = out.value
+    return n
+
+
+def pack_all(weights) -> None:
+    """Pack every stale weight of `weights` (conv parameters [Cout,Cin,k,k] on one device) with ONE kernel launch
+    per 64 convolutions instead of one launch each; pack_weights() then finds them in the cache.  UNet_UAPS calls this
+    at the start of a forward, i.e. once per optimizer step."""
+    todo = []
+    for wt in weights:
+        ent = _packed.get(id(wt))
+        if ent is not None and ent[0]() is wt and ent[1] == wt._version and ent[2] == _generation and ent[3].device == wt.device \
+                and ent[4] is not None:
+            continue
+        todo.append(wt)
+    if not todo:
+        return
+    L = _lib.lib()
+    dev = todo[0].device
+    n = len(todo)
+    bufs = []
+    for wt in todo:
+        Cout, Cin, ks, ks2 = wt.shape
+        if ks != ks2 or ks not in (1, 3) or wt.device != dev or wt.dtype != torch.float32:
+            raise ValueError("pack_all: fp32 3x3 / 1x1 conv weights on one device expected")
+        ent = _packed.get(id(wt))
+        if ent is not None and ent[0]() is wt and ent[3].device == dev and ent[4] is not None:
+            wf, wb = ent[3], ent[4]                  # same parameter, new values: reuse the buffers
+        else:
+            nf, nb = C.c_size_t(), C.c_size_t()
+            _lib.check(L.uaps_conv_pack_floats(Cout, Cin, ks, C.byref(nf), C.byref(nb)), "uaps_conv_pack_floats")
+            wf = torch.empty(nf.value, dtype=torch.float32, device=dev)
+            wb = torch.empty(nb.value, dtype=torch.float32, device=dev)
+        bufs.append((wt.detach().contiguous(), wf, wb))
+    arr = lambda vals: (C.c_void_p * n)(*vals)
+    ints = lambda vals: (C.c_int * n)(*vals)
+    with torch.cuda.device(dev):
+        rc = L.uaps_conv_pack_weights_batch(arr([b[0].data_ptr() for b in bufs]), arr([b[1].data_ptr() for b in bufs]),
+                                            arr([b[2].data_ptr() for b in bufs]), ints([t.shape[0] for t in todo]),
+                                            ints([t.shape[1] for t in todo]), ints([t.shape[2] for t in todo]), n,
+                                            _lib.current_stream(dev))
+    _lib.check(rc, "uaps_conv_pack_weights_batch")
+    for wt, (_, wf, wb) in zip(todo, bufs):
+        _packed[id(wt)] = (weakref.ref(wt), wt._version, _generation, wf, wb)
+
+
+def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ks: int, cfg: int = 0,
+                 want_stats: bool = False):
+    """y = conv(x); with want_stats also the per-tile (sum, sum of squares) of y as float2 [Cout][B][parts_per_image]
+    (the first pass of the BatchNorm that follows), returned as (y, stats, parts_per_image)."""
     B, Cin, H, W = x.shape
     y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    bp = bias.data_ptr() if bias is not None else None
+    if want_stats:
+        ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
+        stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg):
-        rc = _lib.lib().uaps_conv_fwd(x.data_ptr(), wf.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                      B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(x.device))
+        if want_stats:
+            rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
+                                       _lib.current_stream(x.device))
+        else:
+            rc = L.uaps_conv_fwd(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
+                                 _lib.current_stream(x.device))
     _lib.check(rc, "uaps_conv_fwd")
-    return y
+    return (y, stats, ppi) if want_stats else y
 
 
 def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0):
@@ -167,8 +234,9 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_stats=False):
         _lib.require_device(x, "conv2d")
+        ctx.set_materialize_grads(False)          # no zero tensors for the unused gradient of `stats`
         if x.dtype != torch.float32 or weight.dtype != torch.float32:
             raise TypeError("conv2d: fp32 only (the reference trains in fp32)")
         x = x.contiguous()
@@ -177,13 +245,18 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError(f"conv2d: input has {x.shape[1]} channels, weight expects {Cin}")
         need_bwd = ctx.needs_input_grad[0]
         wf, wb = pack_weights(weight, need_bwd=True)
-        y = conv_fwd_raw(x, wf, bias, Cout, ks)
         ctx.save_for_backward(x, wb)
         ctx.meta = (Cin, Cout, ks, bias is not None)
-        return y
+        if want_stats:
+            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, want_stats=True)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return conv_fwd_raw(x, wf, bias, Cout, ks)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
+        if dy is None:
+            return None, None, None, None
         x, wb = ctx.saved_tensors
         Cin, Cout, ks, has_bias = ctx.meta
         dy = dy.contiguous()
@@ -191,9 +264,15 @@ class _Conv2d(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """F.conv2d(x, weight, bias, stride=1, padding=weight.shape[-1] // 2) for 3x3 and 1x1 kernels."""
-    return _Conv2d.apply(x, weight, bias)
+    return _Conv2d.apply(x, weight, bias, False)
+
+
+def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """conv2d that also returns the per-tile (sum, sum of squares) of its output, float32 [Cout, B, parts, 2], for
+    fused.bn_act(..., stats=...): the BatchNorm statistics pass rides in the convolution's epilogue."""
+    return _Conv2d.apply(x, weight, bias, True)

@@ -59,13 +59,13 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
 
 // x [B,Cin,H,W] * packed weights [taps][CinP][CoutP] -> y [B,Cout,H,W]
 int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
-                 int cfg, hipStream_t s) {
+                 int cfg, hipStream_t s, float2* stats = nullptr) {
     if (!x || !wp || !y) return UAPS_EINVAL;
     FwdPlan p{};
     const int rc = plan_fwd(x, y, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
     ConvFwdArgs a{};
-    a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     const bool wide = p.tw == 32;
     if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
@@ -92,9 +92,52 @@ extern "C" int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks,
     return (int)hipGetLastError();
 }
 
+// The same for n convolutions at once (host arrays of n entries each); any wf[i] / wb[i] may be null.
+extern "C" int uaps_conv_pack_weights_batch(const float* const* w, float* const* wf, float* const* wb, const int* Cout,
+                                            const int* Cin, const int* ks, int n, uaps_stream_t stream) {
+    if (!w || !wf || !wb || !Cout || !Cin || !ks || n <= 0) return UAPS_EINVAL;
+    for (int base = 0; base < n; base += kPackBatch) {
+        const int m = n - base < kPackBatch ? n - base : kPackBatch;
+        PackBatch pb{};
+        long most = 0;
+        for (int i = 0; i < m; ++i) {
+            const int k = base + i;
+            if (!w[k] || Cout[k] <= 0 || Cin[k] <= 0 || (ks[k] != 1 && ks[k] != 3)) return UAPS_EINVAL;
+            PackDesc& q = pb.d[i];
+            q.w = w[k]; q.wf = wf[k]; q.wb = wb[k]; q.Cout = Cout[k]; q.Cin = Cin[k]; q.taps = ks[k] * ks[k];
+            q.CinP = kdim_pad(Cin[k], ks[k]); q.CoutP = ndim_pad(Cout[k]); q.CoutPk = kdim_pad(Cout[k], ks[k]); q.CinPn = ndim_pad(Cin[k]);
+            const long e = (long)q.taps * ((long)q.CinP * q.CoutP + (long)q.CoutPk * q.CinPn);
+            if (e > most) most = e;
+        }
+        const int bx = (int)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);
+        hipLaunchKernelGGL(conv_pack_weights_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, pb);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return UAPS_OK;
+}
+
 extern "C" int uaps_conv_fwd(const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                              int ks, int cfg, uaps_stream_t stream) {
     return conv_fwd_any(x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream);
+}
+
+// Forward convolution that also writes, per output channel, image and pixel tile, the (sum, sum of squares) of
+// its output: the first pass of the train-mode BatchNorm that follows every 3x3 conv of a ConvBlock
+// (UAPS_unet.py:37-38, 41-42), for uaps_bn_act_fwd_train_partials.  stats: float2 [Cout][B][parts_per_image].
+extern "C" int uaps_conv_fwd_stats(const float* x, const float* wf, const float* bias, float* y, void* stats, int B, int Cin,
+                                   int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    if (!stats) return UAPS_EINVAL;
+    return conv_fwd_any(x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats);
+}
+
+extern "C" int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W, int ks, int cfg, int* parts_per_image) {
+    FwdPlan p{};
+    const int rc = plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p);
+    if (rc) return rc;
+    if (!parts_per_image) return UAPS_EINVAL;
+    *parts_per_image = ((H + p.th - 1) / p.th) * ((W + p.tw - 1) / p.tw);
+    return UAPS_OK;
 }
 
 // dx = conv(dy, W^T flipped): the same kernel with the roles of the channel counts exchanged

@@ -114,6 +114,7 @@ struct ConvFwdArgs {
     const float* wp;    // packed [taps][CinP][CoutP]
     const float* bias;  // [Cout] or nullptr
     float* out;         // [B, Cout, H, W]
+    float2* stats;      // optional [Cout][B][tiles_y*tiles_x] per-tile (sum, sum of squares) of the output, or nullptr
     int B, Cin, Cout, H, W;
     int CinP, CoutP;
     int tiles_x, tiles_y, nblk;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     constexpr int NWT4 = TAPS * CK * BN / 4;            // float4 units of a weight chunk
     constexpr int NWT_T = (NWT4 + kConvThreads - 1) / kConvThreads;
     static_assert(MT % 4 == 0 && CK % 4 == 0 && BN % 16 == 0 && PS % 4 == 0, "tile shape");
+    static_assert(CK * PS >= 32 * BN, "the statistics epilogue reuses sIn");
     using Plan = StagePlan<G, CK, VEC, PS>;
 
     __shared__ __attribute__((aligned(16))) float sIn[CK * PS];
@@ -234,28 +236,49 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     }
 
     // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every tile ------------
+    float st_s[NW], st_q[NW];
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
+        st_s[n] = 0.f; st_q[n] = 0.f;
         const int co = co0 + n * 16 + j;
-        if (co >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[co] : 0.f;
-        float* out_c = a.out + ((size_t)b * a.Cout + co) * HW;
+        const bool co_ok = co < a.Cout;
+        const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+        float* out_c = a.out + ((size_t)b * a.Cout + (co_ok ? co : 0)) * HW;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int mt = wave * MW + m;
             const int gy = y0 + mt / XB, gx = x0 + (mt % XB) * 16 + kq * 4;
-            if (gy >= a.H) continue;
             f32x4 v = acc[m][n];
             v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             float* p = out_c + (size_t)gy * a.W + gx;
+            const bool row_ok = co_ok && gy < a.H;
             if (VEC == 4) {                       // W % 4 == 0: the 4 pixels are all inside or all outside
-                if (gx < a.W) *reinterpret_cast<f32x4*>(p) = v;
+                const bool ok = row_ok && gx < a.W;
+                if (ok) *reinterpret_cast<f32x4*>(p) = v;
+                if (ok) { st_s[n] += (v.x + v.y) + (v.z + v.w); st_q[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
             } else {
-                if (gx + 0 < a.W) p[0] = v.x;
-                if (gx + 1 < a.W) p[1] = v.y;
-                if (gx + 2 < a.W) p[2] = v.z;
-                if (gx + 3 < a.W) p[3] = v.w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row_ok && gx + r < a.W) { p[r] = v[r]; st_s[n] += v[r]; st_q[n] += v[r] * v[r]; }
             }
+        }
+    }
+    // ---- optional BatchNorm statistics of this tile (UAPS_unet.py:38,42 batch statistics, first pass): per channel
+    // the 16 partial sums (4 waves x 4 lane groups) are combined through LDS in a fixed order -------------------------
+    if (a.stats != nullptr) {                    // wave-uniform
+        float* red = sIn;                        // free: the chunk loop ended with a barrier
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            red[((wave * 4 + kq) * BN + n * 16 + j) * 2 + 0] = st_s[n];
+            red[((wave * 4 + kq) * BN + n * 16 + j) * 2 + 1] = st_q[n];
+        }
+        __syncthreads();
+        if (tid < BN && co0 + tid < a.Cout) {
+            float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0 += red[(r * BN + tid) * 2]; q0 += red[(r * BN + tid) * 2 + 1]; }
+            const int tpi = a.tiles_x * a.tiles_y;
+            a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
         }
     }
 }
@@ -498,6 +521,29 @@ static __global__ void conv_pack_weights_kernel(const float* __restrict__ w, flo
             const int ci = (int)(f % CinPn); const long r = f / CinPn;
             const int co = (int)(r % CoutPk), t = (int)(r / CoutPk);
             wb[f] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + (taps - 1 - t)] : 0.f;
+        }
+    }
+}
+
+// One launch for up to kPackBatch convolutions (the whole U-Net has 62): blockIdx.y selects the descriptor.
+constexpr int kPackBatch = 64;
+struct PackDesc { const float* w; float* wf; float* wb; int Cout, Cin, taps, CinP, CoutP, CoutPk, CinPn; };
+struct PackBatch { PackDesc d[kPackBatch]; };
+static __global__ void conv_pack_weights_batch_kernel(PackBatch pb) {
+    const PackDesc& q = pb.d[blockIdx.y];
+    const long nf = (long)q.taps * q.CinP * q.CoutP, nbk = (long)q.taps * q.CoutPk * q.CinPn;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nbk; e += (long)gridDim.x * blockDim.x) {
+        if (e < nf) {
+            if (!q.wf) continue;
+            const int co = (int)(e % q.CoutP); const long r = e / q.CoutP;
+            const int ci = (int)(r % q.CinP), t = (int)(r / q.CinP);
+            q.wf[e] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + t] : 0.f;
+        } else {
+            if (!q.wb) continue;
+            const long f = e - nf;
+            const int ci = (int)(f % q.CinPn); const long r = f / q.CinPn;
+            const int co = (int)(r % q.CoutPk), t = (int)(r / q.CoutPk);
+            q.wb[f] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + (q.taps - 1 - t)] : 0.f;
         }
     }
 }

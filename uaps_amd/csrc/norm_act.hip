@@ -72,22 +72,28 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
 // ---- forward finalize: one wave per channel, looping over the G = B / Bg statistics groups in order -------
 // (a group = the images of one reference forward call: the labelled and the unlabelled batch are normalised
 // separately, UAPS_train.py:177,185, and update the running statistics one after the other)
-__global__ __launch_bounds__(64) void bn_finalize_fwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
-                                                      const float* __restrict__ conv_bias, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                      float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                      float momentum, float eps, float* __restrict__ save_mean,
-                                                      float* __restrict__ save_invstd, float* __restrict__ coef, int C) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int G = B / Bg, nparts = Bg * nch;
+__global__ __launch_bounds__(kThreads) void bn_finalize_fwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
+                                                            const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                            float momentum, float eps, float* __restrict__ save_mean,
+                                                            float* __restrict__ save_invstd, float* __restrict__ coef, int C) {
+    __shared__ double red[2][kThreads / 64];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int G = B / Bg, nparts = Bg * nch;      // nparts reaches a few thousand when the partials come per conv tile
     const double M = (double)Bg * HW;
     for (int g = 0; g < G; ++g) {
         const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
         double s = 0.0, ss = 0.0;
-        for (int i = lane; i < nparts; i += 64) { const float2 v = pp[i]; s += v.x; ss += v.y; }
+        for (int i = threadIdx.x; i < nparts; i += kThreads) { const float2 v = pp[i]; s += v.x; ss += v.y; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
-        if (lane == 0) {
+        __syncthreads();                           // red[] of the previous group has been consumed
+        if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
             const double mean = s / M;
             double var = ss / M - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(64) void bn_finalize_fwd(const float2* __restrict__
             }
         }
     }
-    if (nbt && c == 0 && lane == 0) nbt[0] += G;
+    if (nbt && c == 0 && threadIdx.x == 0) nbt[0] += G;
 }
 
 __global__ __launch_bounds__(64) void bn_coef_eval(const float* __restrict__ conv_bias, const float* __restrict__ gamma,
@@ -323,7 +329,7 @@ extern "C" int uaps_bn_workspace_bytes(int B, int C, int H, int W, size_t* out) 
     return UAPS_OK;
 }
 
-extern "C" int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_image, const float* y, const float* conv_bias, const float* gamma, const float* beta,
                                              float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                              float momentum, float eps, float slope, float drop_p, uint64_t seed, uint64_t offset,
                                              int B, int C, int H, int W, int groups, float* out, float* save_mean,
@@ -339,9 +345,12 @@ extern "C" int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_b
     const int nch = nchunks_for(HW), Bg = B / groups;
     const dim3 grid(nch, B * C);
     const bool vec = (HW % 4 == 0) && al16(y) && al16(out);
-    if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
-    else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
-    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(64), 0, s, w.partials, B, Bg, nch, (double)HW, conv_bias, gamma, beta, running_mean,
+    if (!given_partials) {
+        if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+        else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+    }
+    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads), 0, s, given_partials ? given_partials : w.partials, B, Bg,
+                       given_partials ? given_parts_per_image : nch, (double)HW, conv_bias, gamma, beta, running_mean,
                        running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
     const float dscale = 1.f / (1.f - drop_p);
 #define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg)
@@ -349,6 +358,29 @@ extern "C" int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_b
     else { if (drop_p > 0.f) UAPS_APPLY(false, true); else UAPS_APPLY(false, false); }
 #undef UAPS_APPLY
     return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_bias, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                             float momentum, float eps, float slope, float drop_p, uint64_t seed, uint64_t offset,
+                                             int B, int C, int H, int W, int groups, float* out, float* save_mean,
+                                             float* save_invstd, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    return bn_fwd_train_impl(nullptr, 0, y, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                             slope, drop_p, seed, offset, B, C, H, W, groups, out, save_mean, save_invstd, ws, ws_bytes, stream);
+}
+
+// The statistics pass is skipped: `partials` (float2 [C][B][parts_per_image], e.g. from uaps_conv_fwd_stats) already
+// holds per-image partial (sum, sum of squares) of y.
+extern "C" int uaps_bn_act_fwd_train_partials(const void* partials, int parts_per_image, const float* y, const float* conv_bias,
+                                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                              int64_t* num_batches_tracked, float momentum, float eps, float slope, float drop_p,
+                                              uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* out,
+                                              float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                              uaps_stream_t stream) {
+    if (!partials || parts_per_image <= 0) return UAPS_EINVAL;
+    return bn_fwd_train_impl((const float2*)partials, parts_per_image, y, conv_bias, gamma, beta, running_mean, running_var,
+                             num_batches_tracked, momentum, eps, slope, drop_p, seed, offset, B, C, H, W, groups, out, save_mean,
+                             save_invstd, ws, ws_bytes, stream);
 }
 
 extern "C" int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* gamma, const float* beta,

@@ -57,7 +57,7 @@ class _BnActTrain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, drop_p, seed, offset,
-                groups=1):
+                groups=1, stats_partials=None):
         _lib.require_device(y, "bn_act")
         y = y.contiguous()
         B, Cc, H, W = y.shape
@@ -67,9 +67,15 @@ class _BnActTrain(torch.autograd.Function):
         out = torch.empty_like(y)
         stats = torch.empty((2, groups * Cc), dtype=torch.float32, device=dev)
         ws = _bn_ws(dev, B, Cc, H, W)
+        if stats_partials is not None:
+            if stats_partials.shape[:2] != (Cc, B) or stats_partials.shape[-1] != 2 or not stats_partials.is_contiguous():
+                raise ValueError("bn_act: stats must be the [C, B, parts, 2] tensor conv2d_with_stats returned for this y")
+            fn, head = _lib.lib().uaps_bn_act_fwd_train_partials, (stats_partials.data_ptr(), int(stats_partials.shape[2]))
+        else:
+            fn, head = _lib.lib().uaps_bn_act_fwd_train_grouped, ()
         with torch.cuda.device(dev):
-            rc = _lib.lib().uaps_bn_act_fwd_train_grouped(
-                y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
+            rc = fn(
+                *head, y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None,
                 nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), float(slope), float(drop_p),
@@ -98,7 +104,7 @@ class _BnActTrain(torch.autograd.Function):
         _lib.check(rc, "uaps_bn_act_bwd_grouped")
         # the conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (sum of dy over a channel)
         dbias = torch.zeros_like(gamma) if has_bias else None
-        return dy, dbias, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
+        return dy, dbias, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BnActEval(torch.autograd.Function):
@@ -140,7 +146,7 @@ class _BnActEval(torch.autograd.Function):
 
 
 def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, slope: float, drop_p: float,
-           training: bool) -> torch.Tensor:
+           training: bool, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dropout_p(leaky_relu(bn(y + conv_bias))) with nn.BatchNorm2d / nn.LeakyReLU / nn.Dropout semantics
     (UAPS_unet.py:38-40), as three streaming kernels."""
     if training or not bn.track_running_stats:
@@ -148,7 +154,7 @@ def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2
         seed, off = _RngState.reserve(y.numel()) if p > 0 else (0, 0)
         mom = 0.1 if bn.momentum is None else bn.momentum
         return _BnActTrain.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                 mom, bn.eps, slope, p, seed, off, STAT_GROUPS)
+                                 mom, bn.eps, slope, p, seed, off, STAT_GROUPS, stats)
     return _BnActEval.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, slope)
 
 

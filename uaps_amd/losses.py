@@ -97,6 +97,7 @@ class UnsupOut(NamedTuple):
 class _UnsupLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, cw1, cw2, eps, want_var, *logits):
+        ctx.set_materialize_grads(False)
         zs, D, B, Cc, H, W = _check_heads(logits, "uaps_unsup_loss")
         dev = zs[0].device
         L = _lib.lib()
@@ -126,6 +127,8 @@ class _UnsupLoss(torch.autograd.Function):
     def backward(ctx, g_loss, *unused):
         pseudo, scalars, *zs = ctx.saved_tensors
         D, B, Cc, H, W, cw1, cw2 = ctx.meta
+        if g_loss is None:
+            return (None,) * (5 + D)
         dev = zs[0].device
         g = g_loss.contiguous().to(torch.float32)
         dz = [torch.empty_like(z) for z in zs]
@@ -171,6 +174,7 @@ class SupOut(NamedTuple):
 class _SupLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, labels, ce_coef, dice_coef, eps, *logits):
+        ctx.set_materialize_grads(False)
         zs, D, B, Cc, H, W = _check_heads(logits, "uaps_sup_loss")
         dev = zs[0].device
         if labels.shape != (B, H, W):
@@ -197,6 +201,8 @@ class _SupLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_scalars):
         y, scalars, *zs = ctx.saved_tensors
         D, B, Cc, H, W, ce_coef, dice_coef = ctx.meta
+        if g_loss is None:
+            return (None,) * (4 + D)
         dev = zs[0].device
         g = g_loss.contiguous().to(torch.float32)
         dz = [torch.empty_like(z) for z in zs]
@@ -244,6 +250,7 @@ class _PairLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, labels, w, cw1, cw2, eps, want_var, *logits):
+        ctx.set_materialize_grads(False)
         zs, D, B2, Cc, H, W = _check_heads(logits, "uaps_pair_loss")
         if B2 % 2:
             raise ValueError("uaps_pair_loss: the batch must hold a labelled and an unlabelled half of equal size")
@@ -286,6 +293,8 @@ class _PairLoss(torch.autograd.Function):
     def backward(ctx, g_loss, *unused):
         y, pseudo, sscal, uscal, *zs = ctx.saved_tensors
         D, B, Cc, H, W, cw1, cw2 = ctx.meta
+        if g_loss is None:
+            return (None,) * (6 + D)
         dev = zs[0].device
         g = g_loss.contiguous().to(torch.float32)
         half = B * Cc * H * W * 4

@@ -62,6 +62,7 @@ class _NoiseRng(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, seed, offsets, rng, want_noise):
+        ctx.set_materialize_grads(False)
         x = _prep(x, "FeatureNoise")
         B, Cc, H, W = x.shape
         G = len(offsets)
@@ -86,6 +87,8 @@ class _NoiseRng(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *unused):
         seed, offsets, rng = ctx.meta
+        if gy is None:
+            return None, None, None, None, None
         gy = gy.contiguous()
         B, Cc, H, W = gy.shape
         Bg, chw = B // len(offsets), Cc * H * W
@@ -150,6 +153,7 @@ class FeatureNoise(nn.Module):
 class _Bernoulli(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, seed, offset, p, want_keep):
+        ctx.set_materialize_grads(False)
         x = _prep(x, "Dropout")
         y = torch.empty_like(x)
         keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_keep else None
@@ -166,6 +170,8 @@ class _Bernoulli(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *unused):
         seed, offset, p = ctx.meta
+        if gy is None:
+            return None, None, None, None, None
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
         with torch.cuda.device(gy.device):
@@ -224,6 +230,7 @@ class _FeatDrop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, u):
+        ctx.set_materialize_grads(False)
         x = _prep(x, "FeatureDropout")
         B, Cc, H, W = x.shape
         us = tuple(u) if isinstance(u, (tuple, list)) else (float(u),)
@@ -255,6 +262,8 @@ class _FeatDrop(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gk):
         (keep,) = ctx.saved_tensors
+        if gy is None:
+            return None, None
         gy = gy.contiguous()
         B, Cc, H, W = gy.shape
         gx = torch.empty_like(gy)

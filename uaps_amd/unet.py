@@ -15,6 +15,7 @@ everything after the logits are the HIP kernels of this package (csrc/*.hip).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -26,6 +27,7 @@ from . import conv, fused, perturb
 FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
 ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
 LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
+_EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switch for tools/ab_bench.sh
 
 
 class ConvBlock(nn.Module):
@@ -45,6 +47,11 @@ class ConvBlock(nn.Module):
         # GPU: MFMA implicit-GEMM convs (csrc/conv_kernels.hpp) without bias (train-mode BN cancels it; the
         # fused kernel folds it into running_mean / the eval shift) + the fused BN+LeakyReLU+Dropout kernels
         c0, b0, _, d0, c1, b1, _ = self.conv_conv
+        if self.training and _EPILOGUE_STATS:      # batch statistics: their first pass rides in the conv epilogue
+            y, st = conv.conv2d_with_stats(x, c0.weight, None)
+            a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, True, st)
+            y, st = conv.conv2d_with_stats(a, c1.weight, None)
+            return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
         a = fused.bn_act(conv.conv2d(x, c0.weight, None), c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
         return fused.bn_act(conv.conv2d(a, c1.weight, None), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
 
@@ -158,6 +165,7 @@ class UNet_UAPS(nn.Module):
         for i in range(1, n_aux + 1):
             setattr(self, f"aux_decoder{i}", Decoder(class_num, feature_chns))
         self._noise = perturb.FeatureNoise()
+        self._conv_weights = None
 
     def aux_decoders(self) -> List[Decoder]:
         return [getattr(self, f"aux_decoder{i}") for i in range(1, self.n_aux + 1)]
@@ -184,6 +192,10 @@ class UNet_UAPS(nn.Module):
     def forward(self, x, perturbations=None, _groups: int = 1):
         """`perturbations`: optional list (one entry per auxiliary decoder) of callables
         feats -> feats replacing the random draws (parity tests inject recorded draws here)."""
+        if x.is_cuda:                            # all conv weights packed by one launch (once per optimizer step)
+            if self._conv_weights is None:
+                self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
+            conv.pack_all(self._conv_weights)
         feats = self.encoder(x)
         outs = [self.main_decoder(feats)]
         for i, dec in enumerate(self.aux_decoders()):
