@@ -135,6 +135,10 @@ int uaps_feat_dropout_fwd(const float* x, float* y, int B, int C, int H, int W, 
 int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int B, int C, int H, int W,
                           uaps_stream_t stream);
 
+/* Gradient fan-in of an encoder feature map that feeds several decoders (UAPS_unet.py:226-232 use each
+ * feature list once per decoder): out = in[0] + ... + in[n-1], left to right, n in [1,4], `count` floats. */
+int uaps_sum_tensors(const float* const* in_host, int n, float* out, long count, uaps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * ConvBlock / UpBlock glue between the convolutions (utilities/UAPS_unet.py:36-44, 81-86).
  * ------------------------------------------------------------------------------------------- */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "uaps_conv_fwd_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_wrw_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
+    "uaps_sum_tensors": (C.c_int, [_PTR, C.c_int, _PTR, C.c_long, _PTR]),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 

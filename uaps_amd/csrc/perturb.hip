@@ -121,7 +121,17 @@ __global__ __launch_bounds__(kThreads) void fdrop_attention(const float* __restr
         if constexpr (V == 4) {
             const float4 v = *reinterpret_cast<const float4*>(xb + i);
             s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
-            for (int c = 1; c < C; ++c) {
+            int c = 1;
+            for (; c + 3 < C; c += 4) {            // four loads in flight, adds in channel order
+                float4 t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(xb + (long)(c + q) * HW + i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    s[0] = add_rn(s[0], t[q].x); s[1] = add_rn(s[1], t[q].y); s[2] = add_rn(s[2], t[q].z); s[3] = add_rn(s[3], t[q].w);
+                }
+            }
+            for (; c < C; ++c) {
                 const float4 t = *reinterpret_cast<const float4*>(xb + (long)c * HW + i);
                 s[0] = add_rn(s[0], t.x); s[1] = add_rn(s[1], t.y); s[2] = add_rn(s[2], t.z); s[3] = add_rn(s[3], t.w);
             }
@@ -156,6 +166,7 @@ __global__ __launch_bounds__(kThreads) void fdrop_apply(const float* __restrict_
             const float4 a = *reinterpret_cast<const float4*>(att + (long)b * HW + i);
             const bool k0 = a.x < thr, k1 = a.y < thr, k2 = a.z < thr, k3 = a.w < thr;
             *reinterpret_cast<uchar4*>(keep + (long)b * HW + i) = make_uchar4(k0, k1, k2, k3);
+#pragma unroll 4
             for (int c = 0; c < C; ++c) {
                 const float4 v = *reinterpret_cast<const float4*>(xb + (long)c * HW + i);
                 *reinterpret_cast<float4*>(yb + (long)c * HW + i) = make_float4(k0 ? v.x : 0.f, k1 ? v.y : 0.f, k2 ? v.z : 0.f, k3 ? v.w : 0.f);
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(kThreads) void fdrop_bwd(const float* __restrict__ 
     for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * V; i < HW; i += (long)gridDim.x * kThreads * V) {
         if constexpr (V == 4) {
             const uchar4 k = *reinterpret_cast<const uchar4*>(keep + (long)b * HW + i);
+#pragma unroll 4
             for (int c = 0; c < C; ++c) {
                 const long o = ((long)b * C + c) * HW + i;
                 const float4 v = *reinterpret_cast<const float4*>(dy + o);
@@ -184,6 +196,25 @@ __global__ __launch_bounds__(kThreads) void fdrop_bwd(const float* __restrict__ 
             for (int c = 0; c < C; ++c) { const long o = ((long)b * C + c) * HW + i; dx[o] = k ? dy[o] : 0.f; }
         }
     }
+}
+
+// ---- sum of up to 4 equally shaped tensors (gradient fan-in of a feature map used by several decoders) ------
+struct SumPtrs { const float* p[4]; };
+__global__ __launch_bounds__(kThreads) void sum_n_kernel(SumPtrs in, int n, float* __restrict__ out, long n4, long total) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kThreads) {
+        float4 a = *reinterpret_cast<const float4*>(in.p[0] + 4 * i);
+        for (int k = 1; k < n; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(in.p[k] + 4 * i);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        *reinterpret_cast<float4*>(out + 4 * i) = a;
+    }
+    if (blockIdx.x == 0)
+        for (long i = 4 * n4 + threadIdx.x; i < total; i += kThreads) {
+            float a = in.p[0][i];
+            for (int k = 1; k < n; ++k) a += in.p[k][i];
+            out[i] = a;
+        }
 }
 
 // ---- confusion matrix ---------------------------------------------------------------------------------
@@ -287,6 +318,17 @@ extern "C" int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float
     int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
     if (vec) hipLaunchKernelGGL(fdrop_bwd<4>, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
     else hipLaunchKernelGGL(fdrop_bwd<1>, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
+    return (int)hipGetLastError();
+}
+
+// out = in[0] + in[1] + ... + in[n-1] (left to right), n in [1,4], `count` floats each; out may alias in[0].
+extern "C" int uaps_sum_tensors(const float* const* in, int n, float* out, long count, uaps_stream_t stream) {
+    if (!in || !out || n < 1 || n > 4 || count <= 0) return UAPS_EINVAL;
+    SumPtrs sp{};
+    bool al = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int k = 0; k < n; ++k) { if (!in[k]) return UAPS_EINVAL; sp.p[k] = in[k]; al = al && (reinterpret_cast<uintptr_t>(in[k]) & 15) == 0; }
+    const long n4 = al ? count / 4 : 0;
+    hipLaunchKernelGGL(sum_n_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, sp, n, out, n4, count);
     return (int)hipGetLastError();
 }
 

@@ -192,3 +192,37 @@ class _UpCat(torch.autograd.Function):
 def up_cat(skip: torch.Tensor, low: torch.Tensor) -> torch.Tensor:
     """torch.cat([skip, Upsample(x2, bilinear, align_corners=True)(low)], dim=1)  (UAPS_unet.py:83-85)."""
     return _UpCat.apply(skip, low)
+
+
+class _FanOut(torch.autograd.Function):
+    """x -> n aliases of x; the backward sums the n incoming gradients with ONE kernel (in[0] + in[1] + ... left to
+    right) instead of autograd's n-1 separate accumulation adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        acc = gs
+        while len(acc) > 1:                     # the kernel takes up to 4 operands
+            chunk, acc = acc[:4], acc[4:]
+            ptrs = (C.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
+            with torch.cuda.device(out.device):
+                rc = _lib.lib().uaps_sum_tensors(ptrs, len(chunk), out.data_ptr(), out.numel(), _lib.current_stream(out.device))
+            _lib.check(rc, "uaps_sum_tensors")
+            acc = [out] + acc
+        return out, None
+
+
+def fan_out(x: torch.Tensor, n: int):
+    """n handles on the same tensor whose gradients are summed by one kernel (GPU tensors only)."""
+    _lib.require_device(x, "fan_out")
+    return _FanOut.apply(x, n)

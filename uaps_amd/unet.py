@@ -197,11 +197,17 @@ class UNet_UAPS(nn.Module):
                 self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
             conv.pack_all(self._conv_weights)
         feats = self.encoder(x)
-        outs = [self.main_decoder(feats)]
+        if x.is_cuda and torch.is_grad_enabled() and self.n_aux > 0:
+            # every decoder gets its own handle on each feature map: the 1 + n_aux gradients are summed by one kernel
+            handles = [fused.fan_out(f, 1 + self.n_aux) if f.requires_grad else (f,) * (1 + self.n_aux) for f in feats]
+            per_dec = [[h[d] for h in handles] for d in range(1 + self.n_aux)]
+        else:
+            per_dec = [feats] * (1 + self.n_aux)
+        outs = [self.main_decoder(per_dec[0])]
         for i, dec in enumerate(self.aux_decoders()):
             if perturbations is not None and perturbations[i] is not None:
-                pf = perturbations[i](feats)
+                pf = perturbations[i](per_dec[i + 1])
             else:
-                pf = self._perturb(_PERTURBATIONS[i % 3], feats, _groups)
+                pf = self._perturb(_PERTURBATIONS[i % 3], per_dec[i + 1], _groups)
             outs.append(dec(pf))
         return tuple(outs)
