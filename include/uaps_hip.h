@@ -241,6 +241,17 @@ int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias,
                                  int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
 int uaps_conv_bwd_weight_reduce(const void* workspace, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
                                 int ks, int cfg, uaps_stream_t stream);
+/* Convolutions over a channel concatenation that is never materialised: the first ConvBlock conv of an UpBlock
+ * reads torch.cat([skip, upsampled], dim=1) (UAPS_unet.py:84-85).  x1 [B,C1,H,W], x2 [B,C2,H,W], weights packed for
+ * Cin = C1 + C2 as usual; C1 must be a multiple of 16.  The input gradient comes back as two tensors, and the
+ * weight gradient reads the two inputs; uaps_conv_bwd_weight_reduce(.., Cin = C1 + C2, ..) finishes it. */
+int uaps_conv_fwd_cat(const float* x1, int C1, const float* x2, int C2, const float* wf, const float* bias, float* y,
+                      void* stats_or_null, int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_bwd_data_cat(const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2, int B, int Cout,
+                           int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_bwd_weight_partial_cat(const float* dy, const float* x1, int C1, const float* x2, int C2, int want_bias,
+                                     int B, int Cout, int H, int W, int ks, int cfg, void* workspace,
+                                     size_t workspace_bytes, uaps_stream_t stream);
 /* Name (as rocprofv3 prints it, without namespace) of the kernel instantiation the calls above launch
  * for these dimensions; buf_host needs >= 64 bytes.  For uaps_conv_bwd_data pass Cin and Cout swapped
  * to uaps_conv_fwd_variant.  Used by bench.py to group its per-launch HIP-event timings. */

@@ -134,3 +134,27 @@ def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
         assert float((a1 - a2).abs().max()) < 2e-5
         assert torch.allclose(bn1.running_mean, bn2.running_mean, atol=1e-6) and torch.allclose(bn1.running_var, bn2.running_var, rtol=1e-5)
         assert int(bn2.num_batches_tracked) == groups
+
+
+@pytest.mark.parametrize("B,C1,C2,Cout,H,W,ks", [(2, 16, 16, 16, 64, 64, 3), (2, 32, 32, 32, 32, 32, 3), (1, 128, 128, 128, 16, 16, 3),
+                                                  (2, 16, 24, 20, 24, 40, 3), (2, 32, 16, 8, 16, 16, 1)])
+def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
+    """conv2d_cat(x1, x2, w) must be conv2d(cat([x1, x2]), w) bit for bit (same kernels, same order of operations),
+    and so must its three gradients."""
+    from uaps_amd.conv import conv2d, conv2d_cat
+    dev = torch.device("cuda:0")
+    x1, x2 = _mk((B, C1, H, W), 21).to(dev).requires_grad_(True), _mk((B, C2, H, W), 22).to(dev).requires_grad_(True)
+    w = (_mk((Cout, C1 + C2, ks, ks), 23) / np.sqrt((C1 + C2) * ks * ks)).to(dev).requires_grad_(True)
+    b = _mk((Cout,), 24).to(dev).requires_grad_(True)
+    dy = _mk((B, Cout, H, W), 25).to(dev)
+    y, st = conv2d_cat(x1, x2, w, b, with_stats=True)
+    y.backward(dy)
+    g = (x1.grad.clone(), x2.grad.clone(), w.grad.clone(), b.grad.clone())
+    x1.grad = x2.grad = w.grad = b.grad = None
+    xc = torch.cat([x1, x2], dim=1).detach().requires_grad_(True)
+    yr = conv2d(xc, w, b)
+    yr.backward(dy)
+    assert torch.equal(y, yr)
+    assert torch.equal(g[0], xc.grad[:, :C1]) and torch.equal(g[1], xc.grad[:, C1:])
+    assert torch.equal(g[2], w.grad) and torch.equal(g[3], b.grad)
+    np.testing.assert_allclose(st[..., 0].double().sum((1, 2)).cpu().numpy(), y.detach().double().sum((0, 2, 3)).cpu().numpy(), rtol=1e-4, atol=1e-2)

@@ -57,6 +57,9 @@ SIGNATURES = {
     "uaps_conv_wrw_workspace_bytes": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_size_t)]),
     "uaps_conv_bwd_weight_partial": (C.c_int, [_PTR, _PTR] + [C.c_int] * 8 + [_PTR, C.c_size_t, _PTR]),
     "uaps_conv_bwd_weight_reduce": (C.c_int, [_PTR, _PTR, _PTR] + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_fwd_cat": (C.c_int, [_PTR, C.c_int, _PTR, C.c_int] + [_PTR] * 4 + [C.c_int] * 6 + [_PTR]),
+    "uaps_conv_bwd_data_cat": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, C.c_int] + [C.c_int] * 6 + [_PTR]),
+    "uaps_conv_bwd_weight_partial_cat": (C.c_int, [_PTR, _PTR, C.c_int, _PTR, C.c_int] + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
     "uaps_conv_fwd_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_wrw_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),

@@ -276,3 +276,80 @@ def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     """conv2d that also returns the per-tile (sum, sum of squares) of its output, float32 [Cout, B, parts, 2], for
     fused.bn_act(..., stats=...): the BatchNorm statistics pass rides in the convolution's epilogue."""
     return _Conv2d.apply(x, weight, bias, True)
+
+
+class _Conv2dCat(torch.autograd.Function):
+    """conv2d(torch.cat([x1, x2], dim=1), weight) without materialising the concatenation (UpBlock.forward,
+    UAPS_unet.py:84-85): the kernels read the two tensors, the input gradient comes back as two tensors."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, want_stats):
+        _lib.require_device(x1, "conv2d_cat")
+        ctx.set_materialize_grads(False)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        B, C1, H, W = x1.shape
+        C2 = x2.shape[1]
+        Cout, Cin, ks, _ = weight.shape
+        if x2.shape != (B, C2, H, W) or C1 + C2 != Cin:
+            raise ValueError(f"conv2d_cat: inputs {tuple(x1.shape)} + {tuple(x2.shape)} do not concatenate to {Cin} channels")
+        if C1 % 16:
+            raise ValueError("conv2d_cat: the first tensor must have a multiple of 16 channels")
+        wf, wb = pack_weights(weight, need_bwd=True)
+        dev = x1.device
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        stats = None
+        if want_stats:
+            stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0):
+            rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
+                                              bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                              stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, 0, _lib.current_stream(dev))
+        _lib.check(rc, "uaps_conv_fwd_cat")
+        ctx.save_for_backward(x1, x2, wb)
+        ctx.meta = (C1, C2, Cout, ks, bias is not None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, *_unused):
+        if dy is None:
+            return None, None, None, None, None
+        x1, x2, wb = ctx.saved_tensors
+        C1, C2, Cout, ks, has_bias = ctx.meta
+        dy = dy.contiguous()
+        B, _, H, W = dy.shape
+        dev = dy.device
+        L = _lib.lib()
+        st = _lib.current_stream(dev)
+        dx1 = dx2 = dw = db = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                dx1 = torch.empty_like(x1)
+                dx2 = torch.empty_like(x2)
+                with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, 0):
+                    rc = L.uaps_conv_bwd_data_cat(dy.data_ptr(), wb.data_ptr(), dx1.data_ptr(), C1, dx2.data_ptr(), C2, B, Cout, H, W,
+                                                  ks, 0, st)
+                _lib.check(rc, "uaps_conv_bwd_data_cat")
+            want_db = has_bias and ctx.needs_input_grad[3]
+            if ctx.needs_input_grad[2] or want_db:
+                n = C.c_size_t()
+                _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
+                ws = _workspace(dev, n.value)
+                dw = torch.empty((Cout, C1 + C2, ks, ks), dtype=torch.float32, device=dev)
+                db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
+                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0):
+                    rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
+                                                            H, W, ks, 0, ws.data_ptr(), ws.numel(), st)
+                _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
+                rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
+                                                   H, W, ks, 0, st)
+                _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+        return dx1, dx2, dw, db, None
+
+
+def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               with_stats: bool = False):
+    """F.conv2d(torch.cat([x1, x2], 1), weight, bias, padding=k//2) reading the two tensors in place."""
+    return _Conv2dCat.apply(x1, x2, weight, bias, with_stats)

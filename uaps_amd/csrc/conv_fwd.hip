@@ -58,14 +58,21 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
 }
 
 // x [B,Cin,H,W] * packed weights [taps][CinP][CoutP] -> y [B,Cout,H,W]
+// x2 / Csplit: optional second input tensor holding channels [Csplit, Cin); y2 / Osplit likewise for the output
 int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
-                 int cfg, hipStream_t s, float2* stats = nullptr) {
+                 int cfg, hipStream_t s, float2* stats = nullptr, const float* x2 = nullptr, int Csplit = -1,
+                 float* y2 = nullptr, int Osplit = -1) {
     if (!x || !wp || !y) return UAPS_EINVAL;
+    if (Csplit < 0 || !x2) Csplit = Cin;
+    if (Osplit < 0 || !y2) Osplit = Cout;
+    if (Csplit > Cin || Osplit > Cout || (Csplit < Cin && (Csplit % 8 || Csplit == 0)) || (Osplit < Cout && Osplit == 0)) return UAPS_EINVAL;
     FwdPlan p{};
     const int rc = plan_fwd(x, y, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
+    if ((x2 && (uintptr_t)x2 % 16) || (y2 && (uintptr_t)y2 % 16)) p.vec = false;
     ConvFwdArgs a{};
-    a.in = x; a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
+    a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     const bool wide = p.tw == 32;
     if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
@@ -138,6 +145,21 @@ extern "C" int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W,
     if (!parts_per_image) return UAPS_EINVAL;
     *parts_per_image = ((H + p.th - 1) / p.th) * ((W + p.tw - 1) / p.tw);
     return UAPS_OK;
+}
+
+// Convolution of the never-materialised concatenation torch.cat([x1, x2], dim=1) (UpBlock, UAPS_unet.py:84-85):
+// x1 [B,C1,H,W], x2 [B,C2,H,W], weights packed for Cin = C1 + C2; C1 % 8 == 0.  stats may be NULL.
+extern "C" int uaps_conv_fwd_cat(const float* x1, int C1, const float* x2, int C2, const float* wf, const float* bias, float* y,
+                                 void* stats, int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    if (!x2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
+    return conv_fwd_any(x1, wf, bias, y, B, C1 + C2, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, x2, C1);
+}
+
+// Input gradient of that convolution, written as two tensors: dx1 [B,C1,H,W] and dx2 [B,C2,H,W].
+extern "C" int uaps_conv_bwd_data_cat(const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2, int B, int Cout,
+                                      int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    if (!dx2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
+    return conv_fwd_any(dy, wb, nullptr, dx1, B, Cout, C1 + C2, H, W, ks, cfg, (hipStream_t)stream, nullptr, nullptr, -1, dx2, C1);
 }
 
 // dx = conv(dy, W^T flipped): the same kernel with the roles of the channel counts exchanged

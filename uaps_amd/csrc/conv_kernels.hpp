@@ -109,11 +109,18 @@ template <class G, int NPL, int VEC, int PS> struct StagePlan {
     }
 };
 
+// The input may be the channel concatenation of two tensors that is never materialised (UpBlock: torch.cat([skip,
+// up], dim=1), UAPS_unet.py:84): channels [0, Csplit) come from `in` [B,Csplit,H,W], the rest from `in2`
+// [B,Cin-Csplit,H,W]; Csplit is a multiple of the channel chunk.  Likewise the output (the input gradient of such a
+// conv) may be split: channels [0, Osplit) go to `out`, the rest to `out2`.  Csplit = Cin / Osplit = Cout: one tensor.
 struct ConvFwdArgs {
-    const float* in;    // [B, Cin, H, W]
+    const float* in;    // [B, Csplit, H, W]
+    const float* in2;   // [B, Cin - Csplit, H, W] or nullptr
     const float* wp;    // packed [taps][CinP][CoutP]
     const float* bias;  // [Cout] or nullptr
-    float* out;         // [B, Cout, H, W]
+    float* out;         // [B, Osplit, H, W]
+    float* out2;        // [B, Cout - Osplit, H, W] or nullptr
+    int Csplit, Osplit;
     float2* stats;      // optional [Cout][B][tiles_y*tiles_x] per-tile (sum, sum of squares) of the output, or nullptr
     int B, Cin, Cout, H, W;
     int CinP, CoutP;
@@ -163,14 +170,19 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
         wgoff[n] = ok ? (uint32_t)((tap * a.CinP + c) * a.CoutP + co0 + co4 * 4) * 4u : kOob;
         wloff[n] = ok ? row * BNS + co4 * 4 : -1;
     }
-    const float* in_b = a.in + (size_t)b * a.Cin * HW;
+    const float* in_b = a.in + (size_t)b * a.Csplit * HW;
+    const float* in2_b = a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW;     // only used when Csplit < Cin
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)TAPS * a.CinP * a.CoutP * 4u);
 
     float rin[Plan::NT][VEC];
     float rw[NWT_T][4];
 
     auto load_chunk = [&](int ci0) {
-        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Cin - ci0) * HW * 4u);
+        // the chunk lies in one of the two sources (Csplit % CK == 0); channels past the source's end read as zero
+        const bool second = ci0 >= a.Csplit;
+        const __amdgpu_buffer_rsrc_t rs_in = second
+            ? make_rsrc(in2_b + (size_t)(ci0 - a.Csplit) * HW, (uint32_t)(a.Cin - ci0) * HW * 4u)
+            : make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Csplit - ci0) * HW * 4u);
 #pragma unroll
         for (int n = 0; n < Plan::NT; ++n) buf_load<VEC>(rs_in, plan.goff[n], rin[n]);
         const uint32_t wbase = (uint32_t)ci0 * a.CoutP * 4u;
@@ -243,7 +255,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
         const int co = co0 + n * 16 + j;
         const bool co_ok = co < a.Cout;
         const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
-        float* out_c = a.out + ((size_t)b * a.Cout + (co_ok ? co : 0)) * HW;
+        const int coc = co_ok ? co : 0;
+        float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
+                                      : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int mt = wave * MW + m;
@@ -294,7 +308,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
 // -------------------------------------------------------------------------------------------------
 struct ConvWrwArgs {
     const float* dout;  // [B, Cout, H, W]
-    const float* in;    // [B, Cin, H, W]
+    const float* in;    // [B, Csplit, H, W]   (channels [0, Csplit) of the conv input; Csplit % 16 == 0 or == Cin)
+    const float* in2;   // [B, Cin - Csplit, H, W] or nullptr: the rest of a never-materialised channel concatenation
+    int Csplit;
     float* slab;        // [nsplit][taps][CoutS][CinS]
     float* bslab;       // [nsplit][CoutS] (bias gradient partials) or nullptr
     int B, Cin, Cout, H, W;
@@ -323,8 +339,10 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
     constexpr int WK = Cfg::WK, TAPS = Cfg::TAPS, IW = G::IW, XS = G::XOFF - G::PAD;
     constexpr int BCO = Cfg::BCO, BCI = Cfg::BCI, PSD = Cfg::PSD, PSI = Cfg::PSI;
     static_assert(WCO * WCI * WK == 4 && TH % WK == 0 && TW % 4 == 0, "wave arrangement");
-    using PlanD = StagePlan<GD, BCO, VEC, PSD>;
-    using PlanI = StagePlan<G, BCI, VEC, PSI>;
+    // staging is done in groups of 16 channel planes (one MFMA tile of channels): all groups share one plan, each
+    // has its own buffer descriptor, so a group can come from either tensor of a split input
+    using PlanD = StagePlan<GD, 16, VEC, PSD>;
+    using PlanI = StagePlan<G, 16, VEC, PSI>;
 
     __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
     float* sD = smem;
@@ -356,28 +374,44 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
     PlanI pi;
     pd.init(tid);
     pi.init(tid);
-    float rd[PlanD::NT][VEC];
-    float ri[PlanI::NT][VEC];
+    float rd[WCO][PlanD::NT][VEC];
+    float ri[WCI][PlanI::NT][VEC];
 
     auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         const int y0 = (tt / a.tiles_x) * TH, x0 = (tt % a.tiles_x) * TW;
         pd.place(y0, x0, a.H, a.W);
         pi.place(y0, x0, a.H, a.W);
-        const __amdgpu_buffer_rsrc_t rs_d = make_rsrc(a.dout + ((size_t)b * a.Cout + co0) * HW, (uint32_t)(a.Cout - co0) * HW * 4u);
-        const __amdgpu_buffer_rsrc_t rs_i = make_rsrc(a.in + ((size_t)b * a.Cin + ci0) * HW, (uint32_t)(a.Cin - ci0) * HW * 4u);
 #pragma unroll
-        for (int n = 0; n < PlanD::NT; ++n) buf_load<VEC>(rs_d, pd.goff[n], rd[n]);
+        for (int g = 0; g < WCO; ++g) {
+            const int c0 = co0 + g * 16;              // channels past Cout read as zero (range check)
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dout + ((size_t)b * a.Cout + c0) * HW,
+                                                        (uint32_t)(c0 < a.Cout ? a.Cout - c0 : 0) * HW * 4u);
 #pragma unroll
-        for (int n = 0; n < PlanI::NT; ++n) buf_load<VEC>(rs_i, pi.goff[n], ri[n]);
+            for (int n = 0; n < PlanD::NT; ++n) buf_load<VEC>(rs, pd.goff[n], rd[g][n]);
+        }
+#pragma unroll
+        for (int g = 0; g < WCI; ++g) {
+            const int c0 = ci0 + g * 16;
+            const bool second = c0 >= a.Csplit;
+            const int cs = second ? c0 - a.Csplit : c0, cn = second ? a.Cin - a.Csplit : a.Csplit;   // channel in / size of its source
+            const float* src = second ? a.in2 : a.in;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + ((size_t)b * cn + cs) * HW, (uint32_t)(cs < cn ? cn - cs : 0) * HW * 4u);
+#pragma unroll
+            for (int n = 0; n < PlanI::NT; ++n) buf_load<VEC>(rs, pi.goff[n], ri[g][n]);
+        }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int n = 0; n < PlanD::NT; ++n)
-            if (pd.loff[n] >= 0) lds_store<VEC, false>(&sD[pd.loff[n]], rd[n]);
+        for (int g = 0; g < WCO; ++g)
 #pragma unroll
-        for (int n = 0; n < PlanI::NT; ++n)
-            if (pi.loff[n] >= 0) lds_store<VEC, false>(&sI[pi.loff[n]], ri[n]);
+            for (int n = 0; n < PlanD::NT; ++n)
+                if (pd.loff[n] >= 0) lds_store<VEC, false>(&sD[g * 16 * PSD + pd.loff[n]], rd[g][n]);
+#pragma unroll
+        for (int g = 0; g < WCI; ++g)
+#pragma unroll
+            for (int n = 0; n < PlanI::NT; ++n)
+                if (pi.loff[n] >= 0) lds_store<VEC, false>(&sI[g * 16 * PSI + pi.loff[n]], ri[g][n]);
     };
 
     const float* pa0 = sD + (wco * 16 + j) * PSD + kq;

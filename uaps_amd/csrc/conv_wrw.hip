@@ -60,22 +60,38 @@ extern "C" int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, in
 }
 
 // Step 1: per-split partial gradients into the workspace (the MFMA kernel).
-extern "C" int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias, int B, int Cin, int Cout, int H, int W,
-                                            int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+static int wrw_partial_impl(const float* dy, const float* x, const float* x2, int Csplit, int want_bias, int B, int Cin, int Cout,
+                            int H, int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
     if (!dy || !x || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (!x2) Csplit = Cin;
+    if (Csplit > Cin || (Csplit < Cin && (Csplit % 16 || Csplit == 0))) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
     if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     const int taps = ks * ks;
     const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
     ConvWrwArgs a{};
-    a.dout = dy; a.in = x; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.dout = dy; a.in = x; a.in2 = x2; a.Csplit = Csplit; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
     a.bslab = want_bias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
-    const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0);
+    const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!x2 || (uintptr_t)x2 % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
     return ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
+}
+
+extern "C" int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias, int B, int Cin, int Cout, int H, int W,
+                                            int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    return wrw_partial_impl(dy, x, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+}
+
+// Weight gradient of a convolution whose input is the never-materialised concatenation of x1 [B,C1,H,W] and
+// x2 [B,C2,H,W] (C1 % 16 == 0); follow with uaps_conv_bwd_weight_reduce(..., Cin = C1 + C2, ...).
+extern "C" int uaps_conv_bwd_weight_partial_cat(const float* dy, const float* x1, int C1, const float* x2, int C2, int want_bias,
+                                                int B, int Cout, int H, int W, int ks, int cfg, void* ws, size_t ws_bytes,
+                                                uaps_stream_t stream) {
+    if (!x2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
+    return wrw_partial_impl(dy, x1, x2, C1, want_bias, B, C1 + C2, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
 }
 
 // Step 2: fixed-order sum of the partials into dw (and dbias).

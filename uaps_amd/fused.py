@@ -226,3 +226,35 @@ def fan_out(x: torch.Tensor, n: int):
     """n handles on the same tensor whose gradients are summed by one kernel (GPU tensors only)."""
     _lib.require_device(x, "fan_out")
     return _FanOut.apply(x, n)
+
+
+class _Up2x(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (UAPS_unet.py:74-75) on its own: the kernels
+    of up_cat with an empty skip part."""
+
+    @staticmethod
+    def forward(ctx, low):
+        _lib.require_device(low, "upsample2x")
+        low = low.contiguous()
+        B, Cl, h, w = low.shape
+        out = torch.empty((B, Cl, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
+        with torch.cuda.device(low.device):
+            rc = _lib.lib().uaps_up_cat_fwd(low.data_ptr(), low.data_ptr(), out.data_ptr(), B, 0, Cl, h, w,
+                                            _lib.current_stream(low.device))
+        _lib.check(rc, "uaps_up_cat_fwd")
+        ctx.meta = (B, Cl, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Cl, h, w = ctx.meta
+        dout = dout.contiguous()
+        dlow = torch.empty((B, Cl, h, w), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            rc = _lib.lib().uaps_up_cat_bwd(dout.data_ptr(), None, dlow.data_ptr(), B, 0, Cl, h, w, _lib.current_stream(dout.device))
+        _lib.check(rc, "uaps_up_cat_bwd")
+        return dlow
+
+
+def upsample2x(low: torch.Tensor) -> torch.Tensor:
+    return _Up2x.apply(low)

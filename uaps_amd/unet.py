@@ -27,7 +27,8 @@ from . import conv, fused, perturb
 FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
 ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
 LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
-_EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switch for tools/ab_bench.sh
+_EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switches for tools/ab_bench.sh
+_VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 
 
 class ConvBlock(nn.Module):
@@ -41,18 +42,20 @@ class ConvBlock(nn.Module):
                   nn.LeakyReLU(LEAKY_SLOPE)]
         self.conv_conv = nn.Sequential(*layers)      # indices 0,1,4,5 carry the parameters
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x2: second half of a channel concatenation [x, x2] that is not materialised (GPU only)."""
         if not x.is_cuda:
-            return self.conv_conv(x)                  # plain torch modules (CPU inspection / CPU-only tests)
+            return self.conv_conv(x if x2 is None else torch.cat([x, x2], dim=1))   # plain torch modules (CPU tests)
         # GPU: MFMA implicit-GEMM convs (csrc/conv_kernels.hpp) without bias (train-mode BN cancels it; the
         # fused kernel folds it into running_mean / the eval shift) + the fused BN+LeakyReLU+Dropout kernels
         c0, b0, _, d0, c1, b1, _ = self.conv_conv
         if self.training and _EPILOGUE_STATS:      # batch statistics: their first pass rides in the conv epilogue
-            y, st = conv.conv2d_with_stats(x, c0.weight, None)
+            y, st = conv.conv2d_with_stats(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None, True)
             a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, True, st)
             y, st = conv.conv2d_with_stats(a, c1.weight, None)
             return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
-        a = fused.bn_act(conv.conv2d(x, c0.weight, None), c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
+        y = conv.conv2d(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None)
+        a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
         return fused.bn_act(conv.conv2d(a, c1.weight, None), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
 
 
@@ -83,6 +86,8 @@ class UpBlock(nn.Module):
         if not coarse.is_cuda:
             return self.conv(torch.cat([skip, self.up(self.conv1x1(coarse))], dim=1))
         low = conv.conv2d(coarse, self.conv1x1.weight, self.conv1x1.bias)
+        if _VIRTUAL_CAT and skip.shape[1] % 16 == 0:
+            return self.conv(skip, fused.upsample2x(low))     # the conv kernels read [skip | up] as two tensors
         return self.conv(fused.up_cat(skip, low))     # bilinear x2 written straight into the concat buffer
 
 
