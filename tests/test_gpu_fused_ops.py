@@ -116,7 +116,9 @@ def test_up_cat_vs_torch(B, Cs, Cl, h, w):
     torch.testing.assert_close(low.grad, lr.grad, rtol=1e-4, atol=1e-5)
 
 
-def test_forward_pair_equals_two_forwards():
+@pytest.mark.parametrize("in_chns,C,n_aux,H,W", [(3, 4, 3, 32, 32), (1, 7, 3, 48, 80), (1, 2, 5, 64, 64)],
+                         ids=["neu", "dagm_7class_partial_tiles", "k5_2class"])
+def test_forward_pair_equals_two_forwards(in_chns, C, n_aux, H, W):
     """UNet_UAPS.forward_pair (one pass over labelled+unlabelled, 2 BatchNorm statistics groups) must compute what
     the reference's two forwards compute (UAPS_train.py:177,185): same logits, same running statistics after the
     two successive updates, same loss and parameter gradients.  Randomness is switched off (dropout 0, identity
@@ -126,20 +128,20 @@ def test_forward_pair_equals_two_forwards():
     from uaps_amd import losses
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
-    m1 = uaps_amd.UNet_UAPS(3, 4, dropout=(0.0,) * 5).to(dev).train()
+    m1 = uaps_amd.UNet_UAPS(in_chns, C, n_aux=n_aux, dropout=(0.0,) * 5).to(dev).train()
     m2 = copy.deepcopy(m1)
-    B, H, W = 2, 32, 32
-    xa, xb = torch.randn(B, 3, H, W, device=dev), torch.randn(B, 3, H, W, device=dev) * 1.7 + 0.3
-    y = torch.randint(0, 4, (B, H, W), device=dev)
-    ident = [lambda f: f] * 3
-    w = np.array([0.1, 0.2, 0.3, 0.4])
+    B = 2
+    xa, xb = torch.randn(B, in_chns, H, W, device=dev), torch.randn(B, in_chns, H, W, device=dev) * 1.7 + 0.3
+    y = torch.randint(0, C, (B, H, W), device=dev)
+    ident = [lambda f: f] * n_aux
+    w = np.random.default_rng(5).dirichlet(np.ones(n_aux + 1))
     la, lb = m1(xa, ident), m1(xb, ident)
     out1 = losses.uaps_step_loss(la, y, lb, w, 0.07, 0.05)
     out1.loss.backward()
     both = m2.forward_pair(xa, xb, ident)
     out2 = losses.uaps_pair_loss(both, y, w, 0.07, 0.05)
     out2.loss.backward()
-    for k in range(4):
+    for k in range(n_aux + 1):
         assert torch.equal(both[k][:B], la[k]) and torch.equal(both[k][B:], lb[k]), f"head {k} logits differ"
     assert torch.equal(out1.pseudo, out2.pseudo)
     assert abs(float(out1.loss) - float(out2.loss)) < 1e-6

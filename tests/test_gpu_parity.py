@@ -387,3 +387,25 @@ def test_error_behaviour():
     s = uaps_amd.uaps_sup_loss(z, y)
     assert float(uaps_amd.sup_scalars(s.scalars, 4, 4)["bad_labels"]) == 64
     assert uaps_amd.net_factory("something_else") is None
+
+
+@pytest.mark.parametrize("in_chns,C,n_aux,H,W,b", [(1, 2, 5, 512, 512, 2), (3, 2, 3, 256, 512, 2)], ids=["config4_k5_dagm512", "kosdd2_256x512"])
+def test_training_step_runs_at_other_baseline_configs(in_chns, C, n_aux, H, W, b):
+    """BASELINE.json configs[3] (K=5 -> 6 heads, 2 classes, 1-channel 512x512) and the reference's KoSDD2 shape
+    (2 classes, 256x512): whole steps through the product path; the loss must be finite, go down on a fixed batch,
+    and every parameter must receive a finite gradient."""
+    import uaps_amd
+    torch.manual_seed(0)
+    model = uaps_amd.net_factory("unet_uaps", in_chns, C, n_aux=n_aux)
+    tr = uaps_amd.UAPSTrainer(model, base_lr=1e-3)
+    data = uaps_amd.data.SyntheticBatches(b, in_chns, C, H, W, n_batches=1, device=DEV)
+    xl, yl, xu = data.next()
+    grads = {}
+    hooks = [p.register_hook(lambda g, n=n: grads.__setitem__(n, bool(torch.isfinite(g).all()))) for n, p in model.named_parameters()]
+    losses_seen = [float(tr.train_step(xl, yl, xu)["loss"]) for _ in range(6)]
+    for h in hooks:
+        h.remove()
+    assert all(np.isfinite(losses_seen)), losses_seen
+    assert losses_seen[-1] < losses_seen[0], losses_seen
+    assert len(grads) == len(list(model.parameters())) and all(grads.values())
+    assert tr.last["w"].shape == (n_aux + 1,)

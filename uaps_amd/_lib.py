@@ -11,7 +11,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libuaps_hip.so")
+# UAPS_HIP_LIB selects another build of the same ABI (tools/ab_bench.sh compares two kernel builds on one GPU box)
+LIB_PATH = os.environ.get("UAPS_HIP_LIB") or os.path.join(_HERE, "lib", "libuaps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()
