@@ -261,6 +261,29 @@ int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, float* dbia
                          int W, int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Sibling consistency terms on two [B,C,H,W] tensors (C in [2,8]): the formulations the reference keeps beside
+ * the UAPS block (utilities/losses_1.py, losses_2.py; star-imported at UAPS_train.py:21-22) and its evaluation
+ * notebook uses (UAPS-Testing.ipynb cell 24).  a = input logits (receives the gradient), b = target logits.
+ *   mse_map [B,C,H,W] = (softmax(a) - softmax(b))^2                      losses_1.py:9-26  softmax_mse_loss
+ *   kl_map  [B,H,W]   = sum_c KLDivLoss('none')(log_softmax(a), softmax(b))   notebook cell 24 uncertainty map
+ *   kl_mean [1]       = F.kl_div(log_softmax(a), softmax(b), reduction='mean')  losses_1.py:29-48 softmax_kl_loss
+ * Any of the three outputs may be NULL.  With probs != 0 the inputs are probabilities, not logits, and kl_mean is
+ * F.kl_div(log(a), b, reduction='mean') = kl_loss(pr=a, gt=b) of losses_2.py:201-213.
+ * workspace: uaps_pair_workspace_bytes() (needed for kl_mean only).
+ * ------------------------------------------------------------------------------------------- */
+int uaps_pair_workspace_bytes(size_t* out_host);
+int uaps_softmax_pair_fwd(const float* a, const float* b, int probs, int B, int C, int H, int W, float* mse_map,
+                          float* kl_map, float* kl_mean, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+/* d(sum(grad_map * mse_map)) / da   and   d(g * kl_mean) / da  (g = *gscalar, 1 if NULL); b gets no gradient. */
+int uaps_softmax_mse_bwd(const float* a, const float* b, const float* grad_map, int B, int C, int H, int W, float* da,
+                         uaps_stream_t stream);
+int uaps_softmax_kl_bwd(const float* a, const float* b, const float* gscalar, int B, int C, int H, int W, float* da,
+                        uaps_stream_t stream);
+/* entropy_map(p) = -sum_c p log(p + 1e-6) as [B,1,H,W] and/or its mean (entropy_minmization), losses_1.py:139-149. */
+int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map, float* ent_mean, void* workspace,
+                     size_t workspace_bytes, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Metrics: utilities/metrics.py:8-61 (pixel_accuracy, mIoU, mDice) need only the C x C confusion
  * matrix of arg-max(logits) against the labels: counts[t*C + p], int64, overwritten.
  * ------------------------------------------------------------------------------------------- */

@@ -6,16 +6,19 @@ Public surface (mirrors the names the reference's UAPS_train.py imports):
   sigmoid_rampup, get_current_consistency_weight    (utilities/ramps.py, UAPS_train.py:81-87)
   FeatureNoise, Dropout, FeatureDropout             (utilities/UAPS_unet.py:156-185)
   mIoU, mDice, pixel_accuracy, seg_confusion        (utilities/metrics.py)
+  softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization   (utilities/losses_1.py, losses_2.py)
+  uncertainty_map                                   (UAPS-Testing.ipynb cell 24)
   UAPSTrainer                                       (UAPS_train.py:109-450 step/optimizer/checkpoint)
 """
 from .ramps import sigmoid_rampup, get_current_consistency_weight
 from .losses import (dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_step_loss, uaps_pair_loss, unsup_scalars,
                      sup_scalars)
 from .perturb import FeatureNoise, Dropout, FeatureDropout, manual_seed as perturb_manual_seed
-from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, metrics_from_confusion
+from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, seg_confusion_per_image, metrics_from_confusion
 from .unet import UNet, UNet_UAPS
 from .net_factory import net_factory
+from .consistency import (softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization, uncertainty_map)
 from .trainer import UAPSTrainer
-from . import conv, data, dist
+from . import conv, data, dist, inference
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,221 @@
+// Two-tensor softmax consistency terms for gfx950: the sibling formulations of the UAPS uncertainty/consistency
+// block that the reference ships next to it and its comparison methods use on the same [B,C,H,W] logits --
+//   utilities/losses_1.py:9-26   softmax_mse_loss   (softmax(a) - softmax(b))^2, elementwise
+//   utilities/losses_1.py:29-48  softmax_kl_loss    F.kl_div(log_softmax(a), softmax(b), reduction='mean')
+//   utilities/losses_1.py:139-149 entropy_minmization / entropy_map   -sum_c p log(p + 1e-6)
+//   utilities/losses_2.py:201-213 kl_loss           F.kl_div(log(pr), gt, reduction='mean')
+//   UAPS-Testing.ipynb cell 24   test-time uncertainty map  sum_c KLDivLoss('none')(log_softmax(main), softmax(aux))
+// One streaming pass each: a lane owns 4 horizontally adjacent pixels and all C classes of both tensors in
+// registers (NCHW: a class plane is contiguous over pixels -> 16-byte coalesced loads), the class softmax is
+// register-local.  Sums are block partials + a fixed-order double finalize (deterministic, no float atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/uaps_hip.h"
+
+namespace {
+constexpr int kThreads = 256;
+constexpr int kMaxBlocks = 1024;
+
+template <int C> __device__ __forceinline__ void softmax_c(const float (&z)[C], float (&p)[C], float (&lp)[C]) {
+    float mx = z[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = __expf(z[c] - mx); s += p[c]; }
+    const float inv = __builtin_amdgcn_rcpf(s), lse = mx + __logf(s);
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] *= inv; lp[c] = z[c] - lse; }
+}
+
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float red[kThreads / 64];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// mode bits: 1 = write mse map [B,C,H,W], 2 = write per-pixel KL map [B,H,W], 4 = KL block partials.
+// PROBS: the inputs are already probabilities (kl_loss of losses_2.py: input log(pr), target gt).
+template <int C, bool PROBS>
+__global__ __launch_bounds__(kThreads) void pair_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long HW, long N,
+                                                            float* __restrict__ mse, float* __restrict__ klmap,
+                                                            float* __restrict__ partials) {
+    float acc = 0.f;
+    for (long n = (long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long)gridDim.x * kThreads) {
+        const long img = n / HW, hw = n - img * HW, base = img * C * HW + hw;
+        float za[C], zb[C], p[C], lp[C], t[C], lt[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { za[c] = a[base + (long)c * HW]; zb[c] = b[base + (long)c * HW]; }
+        if (PROBS) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { p[c] = za[c]; lp[c] = __logf(za[c]); t[c] = zb[c]; }
+        } else {
+            softmax_c<C>(za, p, lp);
+            softmax_c<C>(zb, t, lt);
+        }
+        float kl = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (mse) { const float d = p[c] - t[c]; mse[base + (long)c * HW] = d * d; }
+            kl += (t[c] > 0.f ? t[c] * __logf(t[c]) : 0.f) - t[c] * lp[c];      // xlogy(t,t) - t*log p  (torch kl_div)
+        }
+        if (klmap) klmap[n] = kl;
+        acc += kl;
+    }
+    if (partials) {
+        const float s = block_sum(acc);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
+}
+
+// out[0] = sum(partials) / denom
+__global__ __launch_bounds__(64) void pair_finalize(const float* __restrict__ partials, int n, double denom, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += (double)partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) out[0] = (float)(s / denom);
+}
+
+// Gradient w.r.t. the input logits a (the target b gets none, as in the reference):
+//   MSE : da_j = 2 p_j [ G_j (p_j - t_j) - sum_c G_c (p_c - t_c) p_c ]         G = upstream gradient of the map
+//   KL  : da_j = g (p_j - t_j) / numel                                           g = upstream scalar, 'mean' reduction
+template <int C, bool MSE>
+__global__ __launch_bounds__(kThreads) void pair_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            const float* __restrict__ gmap, const float* __restrict__ gscalar,
+                                                            float scale, long HW, long N, float* __restrict__ da) {
+    const float g = MSE ? 1.f : (gscalar ? gscalar[0] : 1.f) * scale;
+    for (long n = (long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long)gridDim.x * kThreads) {
+        const long img = n / HW, hw = n - img * HW, base = img * C * HW + hw;
+        float za[C], zb[C], p[C], lp[C], t[C], lt[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { za[c] = a[base + (long)c * HW]; zb[c] = b[base + (long)c * HW]; }
+        softmax_c<C>(za, p, lp);
+        softmax_c<C>(zb, t, lt);
+        if (MSE) {
+            float G[C], dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { G[c] = gmap[base + (long)c * HW] * (p[c] - t[c]); dot += G[c] * p[c]; }
+#pragma unroll
+            for (int c = 0; c < C; ++c) da[base + (long)c * HW] = 2.f * p[c] * (G[c] - dot);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) da[base + (long)c * HW] = g * (p[c] - t[c]);
+        }
+    }
+}
+
+// ent[b,hw] = -sum_c p log(p + 1e-6)
+template <int C>
+__global__ __launch_bounds__(kThreads) void entropy_kernel(const float* __restrict__ p, long HW, long N, float* __restrict__ ent,
+                                                           float* __restrict__ partials) {
+    float acc = 0.f;
+    for (long n = (long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long)gridDim.x * kThreads) {
+        const long img = n / HW, hw = n - img * HW, base = img * C * HW + hw;
+        float e = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { const float v = p[base + (long)c * HW]; e -= v * __logf(v + 1e-6f); }
+        if (ent) ent[n] = e;
+        acc += e;
+    }
+    if (partials) {
+        const float s = block_sum(acc);
+        if (threadIdx.x == 0) partials[blockIdx.x] = s;
+    }
+}
+
+inline int grid_for(long n) { long g = (n + kThreads - 1) / kThreads; return (int)(g > kMaxBlocks ? kMaxBlocks : (g < 1 ? 1 : g)); }
+
+template <int C> int run_fwd(bool probs, const float* a, const float* b, long HW, long N, float* mse, float* klmap, float* partials,
+                             int grid, hipStream_t s) {
+    if (probs) hipLaunchKernelGGL((pair_fwd_kernel<C, true>), dim3(grid), dim3(kThreads), 0, s, a, b, HW, N, mse, klmap, partials);
+    else hipLaunchKernelGGL((pair_fwd_kernel<C, false>), dim3(grid), dim3(kThreads), 0, s, a, b, HW, N, mse, klmap, partials);
+    return (int)hipGetLastError();
+}
+template <int C> int run_bwd(bool mse, const float* a, const float* b, const float* gmap, const float* gs, float scale, long HW, long N,
+                             float* da, int grid, hipStream_t s) {
+    if (mse) hipLaunchKernelGGL((pair_bwd_kernel<C, true>), dim3(grid), dim3(kThreads), 0, s, a, b, gmap, gs, scale, HW, N, da);
+    else hipLaunchKernelGGL((pair_bwd_kernel<C, false>), dim3(grid), dim3(kThreads), 0, s, a, b, gmap, gs, scale, HW, N, da);
+    return (int)hipGetLastError();
+}
+template <int C> int run_ent(const float* p, long HW, long N, float* ent, float* partials, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((entropy_kernel<C>), dim3(grid), dim3(kThreads), 0, s, p, HW, N, ent, partials);
+    return (int)hipGetLastError();
+}
+#define UAPS_BY_C(C, CALL) \
+    switch (C) { case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4); case 5: return CALL(5); \
+                 case 6: return CALL(6); case 7: return CALL(7); case 8: return CALL(8); default: return UAPS_ERANGE; }
+}  // namespace
+
+extern "C" int uaps_pair_workspace_bytes(size_t* out) {
+    if (!out) return UAPS_EINVAL;
+    *out = (size_t)kMaxBlocks * sizeof(float);
+    return UAPS_OK;
+}
+
+static int pair_fwd_dispatch(int C, bool probs, const float* a, const float* b, long HW, long N, float* mse, float* klmap, float* partials,
+                             int grid, hipStream_t s) {
+#define CALL(K) run_fwd<K>(probs, a, b, HW, N, mse, klmap, partials, grid, s)
+    UAPS_BY_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int uaps_softmax_pair_fwd(const float* a, const float* b, int probs, int B, int C, int H, int W, float* mse_map,
+                                     float* kl_map, float* kl_mean, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    if (!a || !b || B <= 0 || H <= 0 || W <= 0 || (!mse_map && !kl_map && !kl_mean)) return UAPS_EINVAL;
+    if (C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    if (kl_mean && (!ws || ws_bytes < (size_t)kMaxBlocks * sizeof(float))) return UAPS_EWORKSPACE;
+    const long HW = (long)H * W, N = (long)B * HW;
+    const int grid = grid_for(N);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = pair_fwd_dispatch(C, probs != 0, a, b, HW, N, mse_map, kl_map, kl_mean ? (float*)ws : nullptr, grid, s);
+    if (rc || !kl_mean) return rc;
+    hipLaunchKernelGGL(pair_finalize, dim3(1), dim3(64), 0, s, (const float*)ws, grid, (double)N * C, kl_mean);   // reduction='mean': all elements
+    return (int)hipGetLastError();
+}
+
+static int pair_bwd_dispatch(int C, bool mse, const float* a, const float* b, const float* gmap, const float* gs, float scale, long HW,
+                             long N, float* da, int grid, hipStream_t s) {
+#define CALL(K) run_bwd<K>(mse, a, b, gmap, gs, scale, HW, N, da, grid, s)
+    UAPS_BY_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int uaps_softmax_mse_bwd(const float* a, const float* b, const float* grad_map, int B, int C, int H, int W, float* da,
+                                    uaps_stream_t stream) {
+    if (!a || !b || !grad_map || !da || B <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    const long HW = (long)H * W, N = (long)B * HW;
+    return pair_bwd_dispatch(C, true, a, b, grad_map, nullptr, 1.f, HW, N, da, grid_for(N), (hipStream_t)stream);
+}
+
+extern "C" int uaps_softmax_kl_bwd(const float* a, const float* b, const float* gscalar, int B, int C, int H, int W, float* da,
+                                   uaps_stream_t stream) {
+    if (!a || !b || !da || B <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    const long HW = (long)H * W, N = (long)B * HW;
+    return pair_bwd_dispatch(C, false, a, b, nullptr, gscalar, (float)(1.0 / ((double)N * C)), HW, N, da, grid_for(N), (hipStream_t)stream);
+}
+
+static int ent_dispatch(int C, const float* p, long HW, long N, float* ent, float* partials, int grid, hipStream_t s) {
+#define CALL(K) run_ent<K>(p, HW, N, ent, partials, grid, s)
+    UAPS_BY_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map, float* ent_mean, void* ws, size_t ws_bytes,
+                                uaps_stream_t stream) {
+    if (!p || B <= 0 || H <= 0 || W <= 0 || (!ent_map && !ent_mean)) return UAPS_EINVAL;
+    if (C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    if (ent_mean && (!ws || ws_bytes < (size_t)kMaxBlocks * sizeof(float))) return UAPS_EWORKSPACE;
+    const long HW = (long)H * W, N = (long)B * HW;
+    const int grid = grid_for(N);
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = ent_dispatch(C, p, HW, N, ent_map, ent_mean ? (float*)ws : nullptr, grid, s);
+    if (rc || !ent_mean) return rc;
+    hipLaunchKernelGGL(pair_finalize, dim3(1), dim3(64), 0, s, (const float*)ws, grid, (double)N, ent_mean);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,67 @@
+"""Evaluation path of the reference (UAPS-Testing.ipynb, the only consumer of the checkpoints UAPS_train.py writes):
+main-head prediction, the all-heads ensemble of the paper's decoder study, the test-time uncertainty map, and the
+per-image score table.  Everything runs on the HIP kernels of this package; nothing here trains."""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import consistency, metrics
+
+
+@torch.no_grad()
+def predict(model: torch.nn.Module, images: torch.Tensor) -> Tuple[torch.Tensor, Tuple[torch.Tensor, ...]]:
+    """model.eval(); main-head arg-max mask [B,H,W] and the raw head logits (notebook cells 11-13: `output, ax1, _, _ =
+    model(image); masked = torch.argmax(output, dim=1)`).  As in the reference, the auxiliary decoders stay perturbed
+    in eval mode (Dropout is called with training=True unconditionally, UAPS_unet.py:156-158)."""
+    model.eval()
+    out = model(images)
+    heads = out if isinstance(out, (tuple, list)) else (out,)
+    return torch.argmax(heads[0], dim=1), tuple(heads)
+
+
+@torch.no_grad()
+def predict_ensemble(model: torch.nn.Module, images: torch.Tensor) -> torch.Tensor:
+    """Arg-max of the mean softmax over all heads (the "ensemble" rows of the paper's decoder study, README.md:107-111)."""
+    _, heads = predict(model, images)
+    prob = torch.softmax(heads[0], dim=1)
+    for h in heads[1:]:
+        prob = prob + torch.softmax(h, dim=1)
+    return torch.argmax(prob, dim=1)
+
+
+@torch.no_grad()
+def predict_with_uncertainty(model: torch.nn.Module, images: torch.Tensor):
+    """(mask, uncertainty, confidence): notebook cell 24 -- uncertainty = sum_c KLDivLoss('none')(log_softmax(main),
+    softmax(aux1)) per pixel, confidence = 1 - uncertainty."""
+    mask, heads = predict(model, images)
+    if len(heads) < 2:
+        raise ValueError("the uncertainty map needs an auxiliary head")
+    var1 = consistency.uncertainty_map(heads[0], heads[1])
+    return mask, var1, 1.0 - var1
+
+
+@torch.no_grad()
+def evaluate(model: torch.nn.Module, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]]) -> Dict[str, float]:
+    """The score table of notebook cell 25: mIoU, mDice and pixel accuracy of the main head computed image by image
+    (utilities/metrics.py conventions) and averaged over the images, in percent."""
+    miou, mdice, acc = [], [], []
+    for x, y in batches:
+        _, heads = predict(model, x)
+        cms = metrics.seg_confusion_per_image(heads[0], y).cpu().numpy()
+        for cm in cms:
+            m = metrics.metrics_from_confusion(cm)
+            miou.append(m["miou"]); mdice.append(m["mdice"]); acc.append(m["acc"])
+    return {"mIoU(%)": float(np.mean(miou) * 100), "mDice(%)": float(np.mean(mdice) * 100), "Accuracy(%)": float(np.mean(acc) * 100),
+            "images": len(acc)}
+
+
+def load_for_inference(model: torch.nn.Module, checkpoint_path: str, device: Optional[torch.device] = None) -> Dict:
+    """Notebook cell 4: `checkpoint = torch.load(path); model.load_state_dict(checkpoint['state_dict'])` -- accepts the
+    `module.`-prefixed keys of the reference's nn.DataParallel checkpoints (UAPS_train.py:443-450) and plain ones."""
+    from .trainer import load_state_dict_any_prefix
+    ck = torch.load(checkpoint_path, map_location=device or "cpu", weights_only=False)
+    load_state_dict_any_prefix(model, ck["state_dict"] if "state_dict" in ck else ck)
+    return ck

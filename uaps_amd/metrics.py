@@ -30,6 +30,28 @@ def seg_confusion(logits: torch.Tensor, labels: torch.Tensor, out: torch.Tensor 
     return counts
 
 
+def seg_confusion_per_image(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """One confusion matrix per image, int64 [B,C,C] (the evaluation notebooks score image by image and average the
+    scores, UAPS-Testing.ipynb cells 11-19, 25)."""
+    _lib.require_device(logits, "seg_confusion_per_image")
+    if logits.dtype != torch.float32 or logits.dim() != 4:
+        raise TypeError("logits must be float32 [B,C,H,W]")
+    B, C, H, W = logits.shape
+    if labels.shape != (B, H, W):
+        raise ValueError("labels must be [B,H,W]")
+    z = logits.detach().contiguous()
+    y = labels.to(torch.int64).contiguous()
+    counts = torch.empty((B, C, C), dtype=torch.int64, device=z.device)
+    L = _lib.lib()
+    with torch.cuda.device(z.device):
+        st = _lib.current_stream(z.device)
+        for b in range(B):
+            rc = L.uaps_seg_confusion(z.data_ptr() + 4 * b * C * H * W, y.data_ptr() + 8 * b * H * W, 1, C, H, W,
+                                      counts.data_ptr() + 8 * b * C * C, st)
+            _lib.check(rc, "uaps_seg_confusion")
+    return counts
+
+
 def metrics_from_confusion(cm, smooth: float = 1e-10):
     """{'miou','mdice','acc'} with the reference's conventions: classes 1..C-1 only, NaN for classes
     without ground-truth pixels, nanmean over classes (metrics.py:23-37, 47-61); accuracy over all
