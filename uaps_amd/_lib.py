@@ -125,8 +125,36 @@ def ptr_array(tensors):
 
 
 def current_stream(device=None) -> int:
+    """Raw hipStream_t of torch's current stream on `device` (fast path: no Stream object is built)."""
     import torch
-    return torch.cuda.current_stream(device).cuda_stream
+    if device is None:
+        idx = torch.cuda.current_device()
+    else:
+        idx = device.index if isinstance(device, torch.device) else int(device)
+        if idx is None:
+            idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+class device_guard:
+    """`with device_guard(dev):` = torch.cuda.device(dev), skipped when dev already is the current device (the usual
+    case: one process per GPU), which saves a few microseconds on each of the ~700 launches of a step."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        import torch
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*a)
+        return False
 
 
 def require_device(t, what: str):

@@ -45,7 +45,7 @@ def _fwd(a, b, probs, want_mse, want_map, want_mean):
     klm = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_map else None
     mean = torch.empty((), dtype=torch.float32, device=dev) if want_mean else None
     ws = _workspace(dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.lib().uaps_softmax_pair_fwd(a.data_ptr(), b.data_ptr(), int(probs), B, Cc, H, W,
                                               mse.data_ptr() if want_mse else None, klm.data_ptr() if want_map else None,
                                               mean.data_ptr() if want_mean else None, ws.data_ptr(), ws.numel(),
@@ -67,7 +67,7 @@ class _SoftmaxMse(torch.autograd.Function):
         g = g.contiguous()
         da = torch.empty_like(a)
         B, Cc, H, W = a.shape
-        with torch.cuda.device(a.device):
+        with _lib.device_guard(a.device):
             rc = _lib.lib().uaps_softmax_mse_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), B, Cc, H, W, da.data_ptr(),
                                                  _lib.current_stream(a.device))
         _lib.check(rc, "uaps_softmax_mse_bwd")
@@ -87,7 +87,7 @@ class _SoftmaxKl(torch.autograd.Function):
         g = g.contiguous().to(torch.float32)
         da = torch.empty_like(a)
         B, Cc, H, W = a.shape
-        with torch.cuda.device(a.device):
+        with _lib.device_guard(a.device):
             rc = _lib.lib().uaps_softmax_kl_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), B, Cc, H, W, da.data_ptr(),
                                                 _lib.current_stream(a.device))
         _lib.check(rc, "uaps_softmax_kl_bwd")
@@ -131,7 +131,7 @@ def _entropy(p: torch.Tensor, want_map: bool, want_mean: bool):
     ent = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_map else None
     mean = torch.empty((), dtype=torch.float32, device=dev) if want_mean else None
     ws = _workspace(dev)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = _lib.lib().uaps_entropy_map(p.data_ptr(), B, Cc, H, W, ent.data_ptr() if want_map else None,
                                          mean.data_ptr() if want_mean else None, ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
     _lib.check(rc, "uaps_entropy_map")

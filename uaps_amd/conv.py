@@ -112,7 +112,7 @@ def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
     wf = torch.empty(nf.value, dtype=torch.float32, device=dev)
     wb = torch.empty(nb.value, dtype=torch.float32, device=dev) if need_bwd else None
     w = weight.detach().contiguous()
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = L.uaps_conv_pack_weights(w.data_ptr(), Cout, Cin, ks, wf.data_ptr(), wb.data_ptr() if need_bwd else None,
                                       _lib.current_stream(dev))
     _lib.check(rc, "uaps_conv_pack_weights")
@@ -168,7 +168,7 @@ def pack_all(weights) -> None:
         bufs.append((wt.detach().contiguous(), wf, wb))
     arr = lambda vals: (C.c_void_p * n)(*vals)
     ints = lambda vals: (C.c_int * n)(*vals)
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         rc = L.uaps_conv_pack_weights_batch(arr([b[0].data_ptr() for b in bufs]), arr([b[1].data_ptr() for b in bufs]),
                                             arr([b[2].data_ptr() for b in bufs]), ints([t.shape[0] for t in todo]),
                                             ints([t.shape[1] for t in todo]), ints([t.shape[2] for t in todo]), n,
@@ -189,7 +189,7 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     if want_stats:
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg):
+    with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg):
         if want_stats:
             rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
                                        _lib.current_stream(x.device))
@@ -203,7 +203,7 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
 def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0):
     B, Cout, H, W = dy.shape
     dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
-    with torch.cuda.device(dy.device), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg):
+    with _lib.device_guard(dy.device), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg):
         rc = _lib.lib().uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
                                            _lib.current_stream(dy.device))
     _lib.check(rc, "uaps_conv_bwd_data")
@@ -220,7 +220,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     ws = _workspace(dev, n.value)
     dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=dev)
     db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_bias else None
-    with torch.cuda.device(dev):
+    with _lib.device_guard(dev):
         st = _lib.current_stream(dev)
         with _timed("wrw", B, Cin, Cout, H, W, ks, cfg):
             rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
@@ -300,7 +300,7 @@ class _Conv2dCat(torch.autograd.Function):
         stats = None
         if want_stats:
             stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0):
+        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0):
             rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
                                               bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                               stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, 0, _lib.current_stream(dev))
@@ -324,7 +324,7 @@ class _Conv2dCat(torch.autograd.Function):
         L = _lib.lib()
         st = _lib.current_stream(dev)
         dx1 = dx2 = dw = db = None
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx1 = torch.empty_like(x1)
                 dx2 = torch.empty_like(x2)

@@ -73,7 +73,7 @@ class _BnActTrain(torch.autograd.Function):
             fn, head = _lib.lib().uaps_bn_act_fwd_train_partials, (stats_partials.data_ptr(), int(stats_partials.shape[2]))
         else:
             fn, head = _lib.lib().uaps_bn_act_fwd_train_grouped, ()
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = fn(
                 *head, y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
@@ -96,7 +96,7 @@ class _BnActTrain(torch.autograd.Function):
         dy = torch.empty_like(y)
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
         ws = _bn_ws(dev, B, Cc, H, W)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.lib().uaps_bn_act_bwd_grouped(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                     stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B,
                                                     Cc, H, W, groups, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
@@ -117,7 +117,7 @@ class _BnActEval(torch.autograd.Function):
         out = torch.empty_like(y)
         mean_eff = torch.empty(Cc, dtype=torch.float32, device=dev)
         ws = _bn_ws(dev, B, Cc, H, W)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             rc = _lib.lib().uaps_bn_act_fwd_eval(y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None,
                                                  gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(),
                                                  running_var.data_ptr(), float(eps), float(slope), B, Cc, H, W,
@@ -136,7 +136,7 @@ class _BnActEval(torch.autograd.Function):
         B, Cc, H, W = y.shape
         dy = torch.empty_like(y)
         ws = _bn_ws(y.device, B, Cc, H, W)
-        with torch.cuda.device(y.device):
+        with _lib.device_guard(y.device):
             rc = _lib.lib().uaps_bn_act_bwd_eval(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                  mean_eff.data_ptr(), rv.data_ptr(), eps, slope, B, Cc, H, W, dy.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _lib.current_stream(y.device))
@@ -168,7 +168,7 @@ class _UpCat(torch.autograd.Function):
         if skip.shape != (B, Cs, 2 * h, 2 * w):
             raise ValueError(f"skip {tuple(skip.shape)} is not twice the size of low {tuple(low.shape)}")
         out = torch.empty((B, Cs + Cl, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
-        with torch.cuda.device(low.device):
+        with _lib.device_guard(low.device):
             rc = _lib.lib().uaps_up_cat_fwd(skip.data_ptr(), low.data_ptr(), out.data_ptr(), B, Cs, Cl, h, w,
                                             _lib.current_stream(low.device))
         _lib.check(rc, "uaps_up_cat_fwd")
@@ -182,7 +182,7 @@ class _UpCat(torch.autograd.Function):
         need_skip = ctx.needs_input_grad[0]
         dskip = torch.empty((B, Cs, 2 * h, 2 * w), dtype=torch.float32, device=dout.device) if need_skip else None
         dlow = torch.empty((B, Cl, h, w), dtype=torch.float32, device=dout.device)
-        with torch.cuda.device(dout.device):
+        with _lib.device_guard(dout.device):
             rc = _lib.lib().uaps_up_cat_bwd(dout.data_ptr(), dskip.data_ptr() if need_skip else None, dlow.data_ptr(), B, Cs,
                                             Cl, h, w, _lib.current_stream(dout.device))
         _lib.check(rc, "uaps_up_cat_bwd")
@@ -215,7 +215,7 @@ class _FanOut(torch.autograd.Function):
         while len(acc) > 1:                     # the kernel takes up to 4 operands
             chunk, acc = acc[:4], acc[4:]
             ptrs = (C.c_void_p * len(chunk))(*[g.data_ptr() for g in chunk])
-            with torch.cuda.device(out.device):
+            with _lib.device_guard(out.device):
                 rc = _lib.lib().uaps_sum_tensors(ptrs, len(chunk), out.data_ptr(), out.numel(), _lib.current_stream(out.device))
             _lib.check(rc, "uaps_sum_tensors")
             acc = [out] + acc
@@ -238,7 +238,7 @@ class _Up2x(torch.autograd.Function):
         low = low.contiguous()
         B, Cl, h, w = low.shape
         out = torch.empty((B, Cl, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
-        with torch.cuda.device(low.device):
+        with _lib.device_guard(low.device):
             rc = _lib.lib().uaps_up_cat_fwd(low.data_ptr(), low.data_ptr(), out.data_ptr(), B, 0, Cl, h, w,
                                             _lib.current_stream(low.device))
         _lib.check(rc, "uaps_up_cat_fwd")
@@ -250,7 +250,7 @@ class _Up2x(torch.autograd.Function):
         B, Cl, h, w = ctx.meta
         dout = dout.contiguous()
         dlow = torch.empty((B, Cl, h, w), dtype=torch.float32, device=dout.device)
-        with torch.cuda.device(dout.device):
+        with _lib.device_guard(dout.device):
             rc = _lib.lib().uaps_up_cat_bwd(dout.data_ptr(), None, dlow.data_ptr(), B, 0, Cl, h, w, _lib.current_stream(dout.device))
         _lib.check(rc, "uaps_up_cat_bwd")
         return dlow

@@ -109,7 +109,7 @@ class _UnsupLoss(torch.autograd.Function):
         var = torch.empty((D, B, H, W), dtype=torch.float32, device=dev) if want_var else None
         scalars = torch.empty(off["n"], dtype=torch.float32, device=dev)
         w64 = (C.c_double * D)(*[float(x) for x in w])
-        with torch.cuda.device(dev), _timed("uaps_unsup_fwd"):
+        with _lib.device_guard(dev), _timed("uaps_unsup_fwd"):
             rc = L.uaps_unsup_fwd(_lib.ptr_array(zs), w64, D, B, Cc, H, W, float(cw1), float(cw2), float(eps),
                                   pseudo.data_ptr(), var.data_ptr() if want_var else None, scalars.data_ptr(),
                                   ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
@@ -132,7 +132,7 @@ class _UnsupLoss(torch.autograd.Function):
         dev = zs[0].device
         g = g_loss.contiguous().to(torch.float32)
         dz = [torch.empty_like(z) for z in zs]
-        with torch.cuda.device(dev), _timed("uaps_unsup_bwd"):
+        with _lib.device_guard(dev), _timed("uaps_unsup_bwd"):
             rc = _lib.lib().uaps_unsup_bwd(_lib.ptr_array(zs), pseudo.data_ptr(), scalars.data_ptr(), cw1, cw2,
                                            g.data_ptr(), D, B, Cc, H, W, _lib.ptr_array(dz), _lib.current_stream(dev))
         _lib.check(rc, "uaps_unsup_bwd")
@@ -188,7 +188,7 @@ class _SupLoss(torch.autograd.Function):
         _lib.check(L.uaps_loss_workspace_bytes(D, B, Cc, H, W, C.byref(need)), "uaps_loss_workspace_bytes")
         ws = _workspace(dev, need.value)
         scalars = torch.empty(off["n"], dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev), _timed("uaps_sup_fwd"):
+        with _lib.device_guard(dev), _timed("uaps_sup_fwd"):
             rc = L.uaps_sup_fwd(_lib.ptr_array(zs), y.data_ptr(), D, B, Cc, H, W, float(ce_coef), float(dice_coef),
                                 float(eps), scalars.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
         _lib.check(rc, "uaps_sup_fwd")
@@ -206,7 +206,7 @@ class _SupLoss(torch.autograd.Function):
         dev = zs[0].device
         g = g_loss.contiguous().to(torch.float32)
         dz = [torch.empty_like(z) for z in zs]
-        with torch.cuda.device(dev), _timed("uaps_sup_bwd"):
+        with _lib.device_guard(dev), _timed("uaps_sup_bwd"):
             rc = _lib.lib().uaps_sup_bwd(_lib.ptr_array(zs), y.data_ptr(), scalars.data_ptr(), ce_coef, dice_coef,
                                          g.data_ptr(), D, B, Cc, H, W, _lib.ptr_array(dz), _lib.current_stream(dev))
         _lib.check(rc, "uaps_sup_bwd")
@@ -273,7 +273,7 @@ class _PairLoss(torch.autograd.Function):
         var = torch.empty((D, B, H, W), dtype=torch.float32, device=dev) if want_var else None
         w64 = (C.c_double * D)(*[float(x) for x in w])
         st = _lib.current_stream(dev)
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             with _timed("uaps_sup_fwd"):
                 rc = L.uaps_sup_fwd(lab_p, y.data_ptr(), D, B, Cc, H, W, 0.5 / D, 0.5 / D, float(eps), sscal.data_ptr(),
                                     ws.data_ptr(), ws.numel(), st)
@@ -305,7 +305,7 @@ class _PairLoss(torch.autograd.Function):
         un_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in zs])
         dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz])
         dun_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in dz])
-        with torch.cuda.device(dev):
+        with _lib.device_guard(dev):
             with _timed("uaps_sup_bwd"):
                 rc = L.uaps_sup_bwd(lab_p, y.data_ptr(), sscal.data_ptr(), 0.5 / D, 0.5 / D, g.data_ptr(), D, B, Cc, H, W, dlab_p, st)
             _lib.check(rc, "uaps_sup_bwd")

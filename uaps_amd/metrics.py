@@ -23,7 +23,7 @@ def seg_confusion(logits: torch.Tensor, labels: torch.Tensor, out: torch.Tensor 
     z = logits.detach().contiguous()
     y = labels.to(torch.int64).contiguous()
     counts = out if out is not None else torch.empty((C, C), dtype=torch.int64, device=z.device)
-    with torch.cuda.device(z.device):
+    with _lib.device_guard(z.device):
         rc = _lib.lib().uaps_seg_confusion(z.data_ptr(), y.data_ptr(), B, C, H, W, counts.data_ptr(),
                                            _lib.current_stream(z.device))
     _lib.check(rc, "uaps_seg_confusion")
@@ -43,7 +43,7 @@ def seg_confusion_per_image(logits: torch.Tensor, labels: torch.Tensor) -> torch
     y = labels.to(torch.int64).contiguous()
     counts = torch.empty((B, C, C), dtype=torch.int64, device=z.device)
     L = _lib.lib()
-    with torch.cuda.device(z.device):
+    with _lib.device_guard(z.device):
         st = _lib.current_stream(z.device)
         for b in range(B):
             rc = L.uaps_seg_confusion(z.data_ptr() + 4 * b * C * H * W, y.data_ptr() + 8 * b * H * W, 1, C, H, W,

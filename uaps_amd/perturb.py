@@ -71,7 +71,7 @@ class _NoiseRng(torch.autograd.Function):
         Bg, chw = B // G, Cc * H * W
         y = torch.empty_like(x)
         noise = torch.empty((G, Cc, H, W), dtype=torch.float32, device=x.device) if want_noise else None
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             for g, off in enumerate(offsets):
                 rc = _lib.lib().uaps_feat_noise(x.data_ptr() + 4 * g * Bg * chw, y.data_ptr() + 4 * g * Bg * chw, Bg, Cc, H, W,
                                                 seed, off, float(rng), noise[g].data_ptr() if want_noise else None,
@@ -93,7 +93,7 @@ class _NoiseRng(torch.autograd.Function):
         B, Cc, H, W = gy.shape
         Bg, chw = B // len(offsets), Cc * H * W
         gx = torch.empty_like(gy)
-        with torch.cuda.device(gy.device):
+        with _lib.device_guard(gy.device):
             for g, off in enumerate(offsets):
                 rc = _lib.lib().uaps_feat_noise(gy.data_ptr() + 4 * g * Bg * chw, gx.data_ptr() + 4 * g * Bg * chw, Bg, Cc, H, W,
                                                 seed, off, rng, None, _lib.current_stream(gy.device))
@@ -109,7 +109,7 @@ class _NoiseApply(torch.autograd.Function):
         if tuple(noise.shape) != tuple(x.shape[1:]):
             raise ValueError("noise must have the per-sample shape [C,H,W]")
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             rc = _lib.lib().uaps_feat_noise_apply(x.data_ptr(), noise.data_ptr(), y.data_ptr(), x.shape[0],
                                                   noise.numel(), _lib.current_stream(x.device))
         _lib.check(rc, "uaps_feat_noise_apply")
@@ -121,7 +121,7 @@ class _NoiseApply(torch.autograd.Function):
         (noise,) = ctx.saved_tensors
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        with torch.cuda.device(gy.device):
+        with _lib.device_guard(gy.device):
             rc = _lib.lib().uaps_feat_noise_apply(gy.data_ptr(), noise.data_ptr(), gx.data_ptr(), gy.shape[0],
                                                   noise.numel(), _lib.current_stream(gy.device))
         _lib.check(rc, "uaps_feat_noise_apply (backward)")
@@ -157,7 +157,7 @@ class _Bernoulli(torch.autograd.Function):
         x = _prep(x, "Dropout")
         y = torch.empty_like(x)
         keep = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_keep else None
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             rc = _lib.lib().uaps_feat_bernoulli(x.data_ptr(), y.data_ptr(), x.numel(), seed, offset, float(p),
                                                 keep.data_ptr() if want_keep else None, _lib.current_stream(x.device))
         _lib.check(rc, "uaps_feat_bernoulli")
@@ -174,7 +174,7 @@ class _Bernoulli(torch.autograd.Function):
             return None, None, None, None, None
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        with torch.cuda.device(gy.device):
+        with _lib.device_guard(gy.device):
             rc = _lib.lib().uaps_feat_bernoulli(gy.data_ptr(), gx.data_ptr(), gy.numel(), seed, offset, p, None,
                                                 _lib.current_stream(gy.device))
         _lib.check(rc, "uaps_feat_bernoulli (backward)")
@@ -189,7 +189,7 @@ class _MaskApply(torch.autograd.Function):
         if keep.shape != x.shape:
             raise ValueError("keep mask must have the shape of x")
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             rc = _lib.lib().uaps_feat_mask_apply(x.data_ptr(), keep.data_ptr(), float(scale), y.data_ptr(), x.numel(),
                                                  _lib.current_stream(x.device))
         _lib.check(rc, "uaps_feat_mask_apply")
@@ -202,7 +202,7 @@ class _MaskApply(torch.autograd.Function):
         (keep,) = ctx.saved_tensors
         gy = gy.contiguous()
         gx = torch.empty_like(gy)
-        with torch.cuda.device(gy.device):
+        with _lib.device_guard(gy.device):
             rc = _lib.lib().uaps_feat_mask_apply(gy.data_ptr(), keep.data_ptr(), ctx.scale, gx.data_ptr(), gy.numel(),
                                                  _lib.current_stream(gy.device))
         _lib.check(rc, "uaps_feat_mask_apply (backward)")
@@ -248,7 +248,7 @@ class _FeatDrop(torch.autograd.Function):
             _fd_ws[key] = ws
         y = torch.empty_like(x)
         keep = torch.empty((B, H, W), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.device_guard(x.device):
             for g, ug in enumerate(us):
                 o = g * Bg * Cc * H * W * 4
                 rc = L.uaps_feat_dropout_fwd(x.data_ptr() + o, y.data_ptr() + o, Bg, Cc, H, W, float(ug),
@@ -267,7 +267,7 @@ class _FeatDrop(torch.autograd.Function):
         gy = gy.contiguous()
         B, Cc, H, W = gy.shape
         gx = torch.empty_like(gy)
-        with torch.cuda.device(gy.device):
+        with _lib.device_guard(gy.device):
             rc = _lib.lib().uaps_feat_dropout_bwd(gy.data_ptr(), keep.data_ptr(), gx.data_ptr(), B, Cc, H, W,
                                                   _lib.current_stream(gy.device))
         _lib.check(rc, "uaps_feat_dropout_bwd")

@@ -55,7 +55,8 @@ class UAPSTrainer:
 
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u: torch.Tensor, w=None) -> Dict[str, torch.Tensor]:
         """Returns device scalars (loss, sup, unsup); nothing here synchronises with the host."""
-        self.model.train()
+        if not self.model.training:                      # model.train() walks ~2600 modules: only when the mode changes
+            self.model.train()
         cw1, cw2 = self.consistency_weights()
         if self.pair_forward and x_l.shape == x_u.shape:
             both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
