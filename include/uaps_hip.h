@@ -138,6 +138,14 @@ int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float* dx, int B
 /* Gradient fan-in of an encoder feature map that feeds several decoders (UAPS_unet.py:226-232 use each
  * feature list once per decoder): out = in[0] + ... + in[n-1], left to right, n in [1,4], `count` floats. */
 int uaps_sum_tensors(const float* const* in_host, int n, float* out, long count, uaps_stream_t stream);
+/* The same fan-in with the backward of the perturbations folded in: out = sum_k P_k(g_k), where P_k re-applies the
+ * perturbation in front of decoder k to its incoming gradient (all three are diagonal, so backward = forward on the
+ * gradient): mode 0 identity (main decoder), 1 FeatureNoise (Philox offsets per statistics group, `range`),
+ * 2 Dropout (one offset, `p`), 3 FeatureDropout (keep mask uint8 [B,H,W] from the forward).  Host arrays of n <= 8
+ * entries; offsets is [n][groups]; groups <= 4; needs H*W % 4 == 0 and 16-byte aligned tensors. */
+int uaps_fanin_perturbed(const float* const* g_host, const int* mode_host, const uint8_t* const* keep_host,
+                         const uint64_t* offsets_host, int n, int groups, uint64_t seed, float range, float p, int B,
+                         int C, int H, int W, float* out, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ConvBlock / UpBlock glue between the convolutions (utilities/UAPS_unet.py:36-44, 81-86).

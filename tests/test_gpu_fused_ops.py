@@ -170,3 +170,30 @@ def test_grouped_perturbations_draw_per_group():
     r0 = perturb.feature_dropout_with(z[:2].contiguous(), 0.7)
     r1 = perturb.feature_dropout_with(z[2:].contiguous(), 0.9)
     assert torch.equal(out[:2], r0) and torch.equal(out[2:], r1)
+
+
+@pytest.mark.parametrize("B,C,H,W,groups", [(4, 16, 32, 32, 2), (2, 8, 16, 24, 1), (2, 5, 7, 9, 2)])
+def test_perturbed_fan_out_backward_equals_separate_kernels(B, C, H, W, groups):
+    """perturb.perturbed_fan_out: same forward kernels as FeatureNoise / Dropout / FeatureDropout, and a fused backward
+    (one kernel re-applying the three perturbations to the incoming gradients and summing) that must equal the
+    per-perturbation backward kernels + fan-in sum; (2,5,7,9) has H*W % 4 != 0 and takes the unfused path."""
+    from uaps_amd import perturb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    f = torch.rand(B, C, H, W, device=dev).requires_grad_(True)
+    gs = [torch.randn(B, C, H, W, device=dev) for _ in range(4)]
+    kinds = ["noise", "dropout", "feature_dropout"]
+    perturb.manual_seed(7); np.random.seed(7)
+    outs = perturb.perturbed_fan_out(f, kinds, groups)
+    torch.autograd.backward(outs, gs)
+    g_fused = f.grad.clone(); f.grad = None
+    # reference route: the individual ops with the same RNG state
+    perturb.manual_seed(7); np.random.seed(7)
+    n_out = perturb.FeatureNoise()(f, groups=groups)
+    d_out = perturb.Dropout(f)
+    fd_out = perturb.FeatureDropout(f, groups=groups)
+    for a, b in zip(outs[1:], (n_out, d_out, fd_out)):
+        assert torch.equal(a.detach(), b.detach())
+    assert torch.equal(outs[0].detach(), f.detach())
+    torch.autograd.backward([f * 1.0, n_out, d_out, fd_out], gs)
+    np.testing.assert_allclose(g_fused.cpu().numpy(), f.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)

@@ -217,6 +217,55 @@ __global__ __launch_bounds__(kThreads) void sum_n_kernel(SumPtrs in, int n, floa
         }
 }
 
+// ---- gradient fan-in through the feature perturbations --------------------------------------------------
+// An encoder feature map feeds the main decoder as is and every auxiliary decoder through a perturbation
+// (UAPS_unet.py:226-232).  Its gradient is  g_main + sum_k P_k^T(g_k); the P_k are diagonal, so one pass can re-apply
+// them to the incoming gradients and add, instead of one backward kernel per perturbation plus a sum:
+//   mode 0 identity | 1 FeatureNoise: g*n + g, n from Philox(seed, off[group] + element/4) as in noise_rng_vec4
+//   mode 2 Dropout: keep from Philox(seed, off[0] + element/4), g * keep / (1-p) | 3 FeatureDropout: g * keep[b,h,w]
+// Summation order = input order, the same association the separate kernels + uaps_sum_tensors produced.
+constexpr int kFanMax = 8, kFanGroups = 4;
+struct FanInArgs {
+    const float4* g[kFanMax];
+    const uchar4* keep[kFanMax];
+    uint64_t off[kFanMax][kFanGroups];
+    int mode[kFanMax];
+    uint64_t seed;
+    float range, p, scale;
+    int n, B, Bg;
+    long chw4, hw4;
+};
+__global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, float4* __restrict__ out) {
+    const long total = (long)a.B * a.chw4;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+        const long b = e / a.chw4, ce = e - b * a.chw4;
+        const int grp = (int)(b / a.Bg);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kFanMax; ++k) {
+            if (k >= a.n) break;
+            float4 v = a.g[k][e];
+            if (a.mode[k] == 1) {
+                const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, a.seed);
+                const float n0 = (2.f * u01(r.x) - 1.f) * a.range, n1 = (2.f * u01(r.y) - 1.f) * a.range;
+                const float n2 = (2.f * u01(r.z) - 1.f) * a.range, n3 = (2.f * u01(r.w) - 1.f) * a.range;
+                v.x = add_rn(mul_rn(v.x, n0), v.x); v.y = add_rn(mul_rn(v.y, n1), v.y);
+                v.z = add_rn(mul_rn(v.z, n2), v.z); v.w = add_rn(mul_rn(v.w, n3), v.w);
+            } else if (a.mode[k] == 2) {
+                const U4 r = philox4x32_10(a.off[k][0] + (uint64_t)e, a.seed);
+                v.x = u01(r.x) >= a.p ? v.x * a.scale : 0.f; v.y = u01(r.y) >= a.p ? v.y * a.scale : 0.f;
+                v.z = u01(r.z) >= a.p ? v.z * a.scale : 0.f; v.w = u01(r.w) >= a.p ? v.w * a.scale : 0.f;
+            } else if (a.mode[k] == 3) {
+                const uchar4 m = a.keep[k][b * a.hw4 + ce % a.hw4];
+                v.x = m.x ? v.x : 0.f; v.y = m.y ? v.y : 0.f; v.z = m.z ? v.z : 0.f; v.w = m.w ? v.w : 0.f;
+            }
+            if (k == 0) acc = v;
+            else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        }
+        out[e] = acc;
+    }
+}
+
 // ---- confusion matrix ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void confusion_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels, int C,
                                                              long HW, long N, unsigned long long* __restrict__ counts) {
@@ -329,6 +378,32 @@ extern "C" int uaps_sum_tensors(const float* const* in, int n, float* out, long 
     for (int k = 0; k < n; ++k) { if (!in[k]) return UAPS_EINVAL; sp.p[k] = in[k]; al = al && (reinterpret_cast<uintptr_t>(in[k]) & 15) == 0; }
     const long n4 = al ? count / 4 : 0;
     hipLaunchKernelGGL(sum_n_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, sp, n, out, n4, count);
+    return (int)hipGetLastError();
+}
+
+// out[B,C,H,W] = sum_k P_k(g_k), k < n <= 8 (see fanin_perturbed_kernel).  Host arrays of n entries: g (device
+// pointers), mode, keep (device uint8 [B,H,W] for mode 3, else NULL), offsets (n x groups, row-major; mode 1 uses one
+// Philox offset per statistics group of B/groups images, mode 2 uses offsets[k*groups]).  Needs H*W % 4 == 0 and
+// 16-byte aligned tensors (returns UAPS_EINVAL otherwise: use the separate kernels), groups <= 4.
+extern "C" int uaps_fanin_perturbed(const float* const* g, const int* mode, const uint8_t* const* keep, const uint64_t* offsets,
+                                    int n, int groups, uint64_t seed, float range, float p, int B, int C, int H, int W, float* out,
+                                    uaps_stream_t stream) {
+    if (!g || !mode || !out || n < 1 || n > kFanMax || groups < 1 || groups > kFanGroups || B <= 0 || C <= 0 || H <= 0 || W <= 0 ||
+        B % groups)
+        return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (HW % 4 || !al16(out)) return UAPS_EINVAL;
+    FanInArgs a{};
+    for (int k = 0; k < n; ++k) {
+        if (!g[k] || !al16(g[k]) || mode[k] < 0 || mode[k] > 3) return UAPS_EINVAL;
+        if (mode[k] == 3 && (!keep || !keep[k] || (reinterpret_cast<uintptr_t>(keep[k]) & 3))) return UAPS_EINVAL;
+        if (mode[k] != 0 && mode[k] != 3 && !offsets) return UAPS_EINVAL;
+        a.g[k] = (const float4*)g[k]; a.mode[k] = mode[k]; a.keep[k] = keep ? (const uchar4*)keep[k] : nullptr;
+        for (int q = 0; q < groups; ++q) a.off[k][q] = offsets ? offsets[(size_t)k * groups + q] : 0;
+    }
+    a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
+    a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4;
+    hipLaunchKernelGGL(fanin_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, a, (float4*)out);
     return (int)hipGetLastError();
 }
 

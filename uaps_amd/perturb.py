@@ -286,3 +286,115 @@ def FeatureDropout(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
     if groups == 1:
         return feature_dropout_with(x, np.random.uniform(0.7, 0.9))
     return feature_dropout_with(x, tuple(np.random.uniform(0.7, 0.9) for _ in range(groups)))
+
+
+# ---- all decoders' views of one encoder feature map, with a fused backward ---------------------------------
+
+_KIND_MODE = {"noise": 1, "dropout": 2, "feature_dropout": 3}
+
+
+class _PerturbFan(torch.autograd.Function):
+    """(f, kinds) -> (f, P_1(f), ..., P_n(f)): the clean feature map for the main decoder and one perturbed copy per
+    auxiliary decoder (UAPS_unet.py:226-232).  The forward launches the same kernels as FeatureNoise / Dropout /
+    FeatureDropout; the backward is ONE kernel (uaps_fanin_perturbed) that re-applies each perturbation to its
+    incoming gradient and sums, instead of a backward kernel per perturbation plus a fan-in sum."""
+
+    @staticmethod
+    def forward(ctx, f, kinds, groups, noise_range, drop_p):
+        ctx.set_materialize_grads(False)
+        f = _prep(f, "perturbed feature fan-out")
+        B, Cc, H, W = f.shape
+        if B % groups:
+            raise ValueError(f"batch {B} is not divisible into {groups} groups")
+        Bg, chw, dev = B // groups, Cc * H * W, f.device
+        L = _lib.lib()
+        outs, offsets, keeps = [f.view_as(f)], [[0] * groups], [None]
+        seed = _RngState.seed
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            for kind in kinds:
+                y = torch.empty_like(f)
+                if kind == "noise":
+                    offs = [_RngState.reserve(chw)[1] for _ in range(groups)]
+                    for g, off in enumerate(offs):
+                        _lib.check(L.uaps_feat_noise(f.data_ptr() + 4 * g * Bg * chw, y.data_ptr() + 4 * g * Bg * chw, Bg, Cc, H, W, seed,
+                                                     off, float(noise_range), None, st), "uaps_feat_noise")
+                    offsets.append(offs); keeps.append(None)
+                elif kind == "dropout":
+                    off = _RngState.reserve(f.numel())[1]
+                    _lib.check(L.uaps_feat_bernoulli(f.data_ptr(), y.data_ptr(), f.numel(), seed, off, float(drop_p), None, st),
+                               "uaps_feat_bernoulli")
+                    offsets.append([off] * groups); keeps.append(None)
+                elif kind == "feature_dropout":
+                    need = C.c_size_t()
+                    _lib.check(L.uaps_feat_dropout_workspace_bytes(Bg, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
+                    key = (dev.index, st)
+                    ws = _fd_ws.get(key)
+                    if ws is None or ws.numel() < need.value:
+                        ws = _fd_ws[key] = torch.empty(need.value, dtype=torch.uint8, device=dev)
+                    keep = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+                    for g in range(groups):
+                        o = g * Bg * chw * 4
+                        _lib.check(L.uaps_feat_dropout_fwd(f.data_ptr() + o, y.data_ptr() + o, Bg, Cc, H, W, float(np.random.uniform(0.7, 0.9)),
+                                                           keep.data_ptr() + g * Bg * H * W, ws.data_ptr(), ws.numel(), st),
+                                   "uaps_feat_dropout_fwd")
+                    offsets.append([0] * groups); keeps.append(keep)
+                else:
+                    raise ValueError(f"unknown perturbation {kind!r}")
+                outs.append(y)
+        ctx.meta = (tuple(kinds), groups, seed, float(noise_range), float(drop_p), offsets, (B, Cc, H, W))
+        ctx.keeps = keeps
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        kinds, groups, seed, rng, p, offsets, (B, Cc, H, W) = ctx.meta
+        modes = [0] + [_KIND_MODE[k] for k in kinds]
+        live = [(g.contiguous(), modes[i], offsets[i], ctx.keeps[i]) for i, g in enumerate(grads) if g is not None]
+        if not live:
+            return None, None, None, None, None
+        dev = live[0][0].device
+        out = torch.empty_like(live[0][0])
+        n = len(live)
+        L = _lib.lib()
+        fused_ok = (H * W) % 4 == 0 and groups <= 4 and n <= 8 and all(t[0].data_ptr() % 16 == 0 for t in live)
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            if fused_ok:
+                gp = (C.c_void_p * n)(*[t[0].data_ptr() for t in live])
+                md = (C.c_int * n)(*[t[1] for t in live])
+                kp = (C.c_void_p * n)(*[(t[3].data_ptr() if t[3] is not None else None) for t in live])
+                of = (C.c_uint64 * (n * groups))(*[o for t in live for o in t[2]])
+                _lib.check(L.uaps_fanin_perturbed(gp, md, kp, of, n, groups, seed, rng, p, B, Cc, H, W, out.data_ptr(), st),
+                           "uaps_fanin_perturbed")
+                return out, None, None, None, None
+            # general shapes: one backward kernel per perturbation, then the plain fan-in sum
+            Bg, chw = B // groups, Cc * H * W
+            parts = []
+            for g, mode, offs, keep in live:
+                if mode == 0:
+                    parts.append(g)
+                    continue
+                d = torch.empty_like(g)
+                if mode == 1:
+                    for q, off in enumerate(offs):
+                        _lib.check(L.uaps_feat_noise(g.data_ptr() + 4 * q * Bg * chw, d.data_ptr() + 4 * q * Bg * chw, Bg, Cc, H, W, seed, off,
+                                                     rng, None, st), "uaps_feat_noise (backward)")
+                elif mode == 2:
+                    _lib.check(L.uaps_feat_bernoulli(g.data_ptr(), d.data_ptr(), g.numel(), seed, offs[0], p, None, st),
+                               "uaps_feat_bernoulli (backward)")
+                else:
+                    _lib.check(L.uaps_feat_dropout_bwd(g.data_ptr(), keep.data_ptr(), d.data_ptr(), B, Cc, H, W, st), "uaps_feat_dropout_bwd")
+                parts.append(d)
+            acc = parts
+            while len(acc) > 1:
+                chunk, acc = acc[:4], acc[4:]
+                ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
+                _lib.check(L.uaps_sum_tensors(ptrs, len(chunk), out.data_ptr(), out.numel(), st), "uaps_sum_tensors")
+                acc = [out] + acc
+            return (out if len(parts) > 1 else parts[0]), None, None, None, None
+
+
+def perturbed_fan_out(f: torch.Tensor, kinds, groups: int = 1, noise_range: float = 0.3, drop_p: float = 0.5):
+    """[f, P_1(f), ..., P_n(f)] for kinds in {"noise", "dropout", "feature_dropout"} (one entry per auxiliary decoder)."""
+    return _PerturbFan.apply(f, tuple(kinds), int(groups), noise_range, drop_p)
