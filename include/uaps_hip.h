@@ -141,11 +141,17 @@ int uaps_sum_tensors(const float* const* in_host, int n, float* out, long count,
 /* The same fan-in with the backward of the perturbations folded in: out = sum_k P_k(g_k), where P_k re-applies the
  * perturbation in front of decoder k to its incoming gradient (all three are diagonal, so backward = forward on the
  * gradient): mode 0 identity (main decoder), 1 FeatureNoise (Philox offsets per statistics group, `range`),
- * 2 Dropout (one offset, `p`), 3 FeatureDropout (keep mask uint8 [B,H,W] from the forward).  Host arrays of n <= 8
+ * 2 Dropout (one offset, `p`), 3 FeatureDropout (keep mask uint8 [B,H,W] from the forward), 4 the MaxPool2d(2) that
+ * feeds the next encoder level (g is [B,C,H/2,W/2], keep = the arg-max positions of uaps_maxpool2x2_fwd).  Host arrays of n <= 8
  * entries; offsets is [n][groups]; groups <= 4; needs H*W % 4 == 0 and 16-byte aligned tensors. */
 int uaps_fanin_perturbed(const float* const* g_host, const int* mode_host, const uint8_t* const* keep_host,
                          const uint64_t* offsets_host, int n, int groups, uint64_t seed, float range, float p, int B,
                          int C, int H, int W, float* out, uaps_stream_t stream);
+
+/* nn.MaxPool2d(2) of DownBlock (UAPS_unet.py:55-58): out [B,C,H/2,W/2] plus the arg-max position (dy*2+dx) per output
+ * as uint8 (first maximum wins, NaN propagates).  Needs H even, W % 8 == 0, 16-byte aligned x/out.  Its backward is
+ * mode 4 of uaps_fanin_perturbed (no zero fill, no scatter, no separate accumulation). */
+int uaps_maxpool2x2_fwd(const float* x, int B, int C, int H, int W, float* out, uint8_t* idx, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ConvBlock / UpBlock glue between the convolutions (utilities/UAPS_unet.py:36-44, 81-86).

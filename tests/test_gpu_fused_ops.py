@@ -197,3 +197,27 @@ def test_perturbed_fan_out_backward_equals_separate_kernels(B, C, H, W, groups):
     assert torch.equal(outs[0].detach(), f.detach())
     torch.autograd.backward([f * 1.0, n_out, d_out, fd_out], gs)
     np.testing.assert_allclose(g_fused.cpu().numpy(), f.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 32, 32), (1, 8, 6, 24)])
+def test_fused_maxpool_in_fan_out_equals_torch_maxpool(B, C, H, W):
+    """perturbed_fan_out(..., with_pool=True): the appended MaxPool2d(2) output and its gradient (routed to the arg-max
+    by the fused fan-in kernel, mode 4) must equal torch.nn.functional.max_pool2d and its autograd, ties included."""
+    from uaps_amd import perturb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    f = torch.randn(B, C, H, W, device=dev)
+    f[:, :, ::4, ::4] = f[:, :, 1::4, 1::4]                      # plant ties inside pooling windows
+    f.requires_grad_(True)
+    g_main, g_noise, g_pool = torch.randn_like(f), torch.randn_like(f), torch.randn(B, C, H // 2, W // 2, device=dev)
+    perturb.manual_seed(5)
+    outs = perturb.perturbed_fan_out(f, ["noise"], 1, with_pool=True)
+    assert len(outs) == 3
+    ref_pool = F.max_pool2d(f.detach(), 2)
+    assert torch.equal(outs[2], ref_pool)
+    torch.autograd.backward(outs, [g_main, g_noise, g_pool])
+    got = f.grad.clone(); f.grad = None
+    perturb.manual_seed(5)
+    n_out = perturb.FeatureNoise()(f)
+    torch.autograd.backward([f * 1.0, n_out, F.max_pool2d(f, 2)], [g_main, g_noise, g_pool])
+    np.testing.assert_allclose(got.cpu().numpy(), f.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)

@@ -217,12 +217,43 @@ __global__ __launch_bounds__(kThreads) void sum_n_kernel(SumPtrs in, int n, floa
         }
 }
 
+// ---- MaxPool2d(2) of DownBlock (UAPS_unet.py:55-58): out [P,H/2,W/2] and the arg-max position (dy*2+dx, first maximum in
+// scan order wins as in ATen's kernel, NaN propagates) as uint8, for the scatter-free backward in the fan-in kernel ------
+__global__ __launch_bounds__(kThreads) void maxpool2x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                  uint8_t* __restrict__ idx, long planes, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2, Wq = Wo / 4;                 // 4 outputs per thread: 2 x 8 inputs
+    const long total = planes * Ho * Wq;
+    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < total; g += (long)gridDim.x * kThreads) {
+        const int xq = (int)(g % Wq);
+        const long t = g / Wq;
+        const int yo = (int)(t % Ho);
+        const long pl = t / Ho;
+        const float* r0 = x + (pl * H + 2 * yo) * (long)W + xq * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(r0 + W), b1 = *reinterpret_cast<const float4*>(r0 + W + 4);
+        const float t0[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, t1[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[4]; uint8_t ix[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float m = t0[2 * k]; int w = 0;
+            if (t0[2 * k + 1] > m || t0[2 * k + 1] != t0[2 * k + 1]) { m = t0[2 * k + 1]; w = 1; }
+            if (t1[2 * k] > m || t1[2 * k] != t1[2 * k]) { m = t1[2 * k]; w = 2; }
+            if (t1[2 * k + 1] > m || t1[2 * k + 1] != t1[2 * k + 1]) { m = t1[2 * k + 1]; w = 3; }
+            o[k] = m; ix[k] = (uint8_t)w;
+        }
+        const long oo = (pl * Ho + yo) * (long)Wo + xq * 4;
+        *reinterpret_cast<float4*>(out + oo) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uchar4*>(idx + oo) = make_uchar4(ix[0], ix[1], ix[2], ix[3]);
+    }
+}
+
 // ---- gradient fan-in through the feature perturbations --------------------------------------------------
 // An encoder feature map feeds the main decoder as is and every auxiliary decoder through a perturbation
 // (UAPS_unet.py:226-232).  Its gradient is  g_main + sum_k P_k^T(g_k); the P_k are diagonal, so one pass can re-apply
 // them to the incoming gradients and add, instead of one backward kernel per perturbation plus a sum:
 //   mode 0 identity | 1 FeatureNoise: g*n + g, n from Philox(seed, off[group] + element/4) as in noise_rng_vec4
 //   mode 2 Dropout: keep from Philox(seed, off[0] + element/4), g * keep / (1-p) | 3 FeatureDropout: g * keep[b,h,w]
+//   mode 4 MaxPool2d(2) of the next encoder level: g is [B,C,H/2,W/2], routed to the arg-max position kept in `keep`
 // Summation order = input order, the same association the separate kernels + uaps_sum_tensors produced.
 constexpr int kFanMax = 8, kFanGroups = 4;
 struct FanInArgs {
@@ -234,6 +265,7 @@ struct FanInArgs {
     float range, p, scale;
     int n, B, Bg;
     long chw4, hw4;
+    int W;
 };
 __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, float4* __restrict__ out) {
     const long total = (long)a.B * a.chw4;
@@ -244,7 +276,19 @@ __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, 
 #pragma unroll
         for (int k = 0; k < kFanMax; ++k) {
             if (k >= a.n) break;
-            float4 v = a.g[k][e];
+            float4 v;
+            if (a.mode[k] == 4) {               // 4 consecutive pixels of row h <- 2 pooled pixels of row h/2
+                const long pl = e / a.hw4, pe = (e - pl * a.hw4) * 4;
+                const int h = (int)(pe / a.W), w = (int)(pe - (long)h * a.W), Wo = a.W / 2;
+                const long po = (pl * (a.hw4 * 4 / a.W / 2) + h / 2) * (long)Wo + w / 2;
+                const float2 gp = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(a.g[k]) + po);
+                const uchar2 ix = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(a.keep[k]) + po);
+                const int base = (h & 1) * 2;
+                v.x = ix.x == base ? gp.x : 0.f; v.y = ix.x == base + 1 ? gp.x : 0.f;
+                v.z = ix.y == base ? gp.y : 0.f; v.w = ix.y == base + 1 ? gp.y : 0.f;
+            } else {
+                v = a.g[k][e];
+            }
             if (a.mode[k] == 1) {
                 const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, a.seed);
                 const float n0 = (2.f * u01(r.x) - 1.f) * a.range, n1 = (2.f * u01(r.y) - 1.f) * a.range;
@@ -395,15 +439,28 @@ extern "C" int uaps_fanin_perturbed(const float* const* g, const int* mode, cons
     if (HW % 4 || !al16(out)) return UAPS_EINVAL;
     FanInArgs a{};
     for (int k = 0; k < n; ++k) {
-        if (!g[k] || !al16(g[k]) || mode[k] < 0 || mode[k] > 3) return UAPS_EINVAL;
-        if (mode[k] == 3 && (!keep || !keep[k] || (reinterpret_cast<uintptr_t>(keep[k]) & 3))) return UAPS_EINVAL;
-        if (mode[k] != 0 && mode[k] != 3 && !offsets) return UAPS_EINVAL;
+        if (!g[k] || !al16(g[k]) || mode[k] < 0 || mode[k] > 4) return UAPS_EINVAL;
+        if ((mode[k] == 3 || mode[k] == 4) && (!keep || !keep[k] || (reinterpret_cast<uintptr_t>(keep[k]) & 3))) return UAPS_EINVAL;
+        if (mode[k] == 4 && (H % 2 || W % 4)) return UAPS_EINVAL;
+        if ((mode[k] == 1 || mode[k] == 2) && !offsets) return UAPS_EINVAL;
         a.g[k] = (const float4*)g[k]; a.mode[k] = mode[k]; a.keep[k] = keep ? (const uchar4*)keep[k] : nullptr;
         for (int q = 0; q < groups; ++q) a.off[k][q] = offsets ? offsets[(size_t)k * groups + q] : 0;
     }
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
-    a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4;
+    a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4; a.W = W;
     hipLaunchKernelGGL(fanin_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, a, (float4*)out);
+    return (int)hipGetLastError();
+}
+
+// MaxPool2d(kernel 2, stride 2) on [B,C,H,W] (H even, W % 8 == 0, 16-byte aligned): out [B,C,H/2,W/2] and idx uint8 of the
+// same shape (position dy*2+dx of the maximum; first maximum wins, NaN propagates, as torch.nn.MaxPool2d).  The backward is
+// mode 4 of uaps_fanin_perturbed.
+extern "C" int uaps_maxpool2x2_fwd(const float* x, int B, int C, int H, int W, float* out, uint8_t* idx, uaps_stream_t stream) {
+    if (!x || !out || !idx || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (H % 2 || W % 8 || !al16(x) || !al16(out) || (reinterpret_cast<uintptr_t>(idx) & 3)) return UAPS_EINVAL;
+    const long planes = (long)B * C;
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(grid_for(planes * (H / 2) * (W / 8))), dim3(kThreads), 0, (hipStream_t)stream, x, out,
+                       idx, planes, H, W);
     return (int)hipGetLastError();
 }
 

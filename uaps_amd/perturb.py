@@ -300,7 +300,7 @@ class _PerturbFan(torch.autograd.Function):
     incoming gradient and sums, instead of a backward kernel per perturbation plus a fan-in sum."""
 
     @staticmethod
-    def forward(ctx, f, kinds, groups, noise_range, drop_p):
+    def forward(ctx, f, kinds, groups, noise_range, drop_p, with_pool=False):
         ctx.set_materialize_grads(False)
         f = _prep(f, "perturbed feature fan-out")
         B, Cc, H, W = f.shape
@@ -342,17 +342,24 @@ class _PerturbFan(torch.autograd.Function):
                 else:
                     raise ValueError(f"unknown perturbation {kind!r}")
                 outs.append(y)
-        ctx.meta = (tuple(kinds), groups, seed, float(noise_range), float(drop_p), offsets, (B, Cc, H, W))
+            if with_pool:                    # MaxPool2d(2) of the next DownBlock (UAPS_unet.py:55-58), arg-max kept for the backward
+                pooled = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=dev)
+                idx = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.uint8, device=dev)
+                _lib.check(L.uaps_maxpool2x2_fwd(f.data_ptr(), B, Cc, H, W, pooled.data_ptr(), idx.data_ptr(), st), "uaps_maxpool2x2_fwd")
+                outs.append(pooled); offsets.append([0] * groups); keeps.append(idx)
+        ctx.meta = (tuple(kinds), groups, seed, float(noise_range), float(drop_p), offsets, (B, Cc, H, W), bool(with_pool))
         ctx.keeps = keeps
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        kinds, groups, seed, rng, p, offsets, (B, Cc, H, W) = ctx.meta
-        modes = [0] + [_KIND_MODE[k] for k in kinds]
+        kinds, groups, seed, rng, p, offsets, (B, Cc, H, W), with_pool = ctx.meta
+        modes = [0] + [_KIND_MODE[k] for k in kinds] + ([4] if with_pool else [])
         live = [(g.contiguous(), modes[i], offsets[i], ctx.keeps[i]) for i, g in enumerate(grads) if g is not None]
         if not live:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
+        if live[0][1] == 4:                 # the output buffer takes its shape from the first entry: keep a full-size one first
+            live.append(live.pop(0))
         dev = live[0][0].device
         out = torch.empty_like(live[0][0])
         n = len(live)
@@ -367,7 +374,9 @@ class _PerturbFan(torch.autograd.Function):
                 of = (C.c_uint64 * (n * groups))(*[o for t in live for o in t[2]])
                 _lib.check(L.uaps_fanin_perturbed(gp, md, kp, of, n, groups, seed, rng, p, B, Cc, H, W, out.data_ptr(), st),
                            "uaps_fanin_perturbed")
-                return out, None, None, None, None
+                return out, None, None, None, None, None
+            if any(t[1] == 4 for t in live):
+                raise _lib.UapsHipError("fused max-pool backward needs H*W % 4 == 0 and 16-byte aligned gradients")
             # general shapes: one backward kernel per perturbation, then the plain fan-in sum
             Bg, chw = B // groups, Cc * H * W
             parts = []
@@ -392,9 +401,13 @@ class _PerturbFan(torch.autograd.Function):
                 ptrs = (C.c_void_p * len(chunk))(*[t.data_ptr() for t in chunk])
                 _lib.check(L.uaps_sum_tensors(ptrs, len(chunk), out.data_ptr(), out.numel(), st), "uaps_sum_tensors")
                 acc = [out] + acc
-            return (out if len(parts) > 1 else parts[0]), None, None, None, None
+            return (out if len(parts) > 1 else parts[0]), None, None, None, None, None
 
 
-def perturbed_fan_out(f: torch.Tensor, kinds, groups: int = 1, noise_range: float = 0.3, drop_p: float = 0.5):
-    """[f, P_1(f), ..., P_n(f)] for kinds in {"noise", "dropout", "feature_dropout"} (one entry per auxiliary decoder)."""
-    return _PerturbFan.apply(f, tuple(kinds), int(groups), noise_range, drop_p)
+def perturbed_fan_out(f: torch.Tensor, kinds, groups: int = 1, noise_range: float = 0.3, drop_p: float = 0.5,
+                      with_pool: bool = False):
+    """[f, P_1(f), ..., P_n(f)] for kinds in {"noise", "dropout", "feature_dropout"} (one entry per auxiliary decoder);
+    with_pool appends MaxPool2d(2)(f), whose gradient returns through the same fused backward kernel."""
+    if with_pool and (f.shape[2] % 2 or f.shape[3] % 8):
+        raise ValueError("with_pool needs an even height and a width that is a multiple of 8")
+    return _PerturbFan.apply(f, tuple(kinds), int(groups), noise_range, drop_p, bool(with_pool))

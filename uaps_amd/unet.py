@@ -30,6 +30,7 @@ LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
 _EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switches for tools/ab_bench.sh
 _VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 _FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
+_FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
 
 
 class ConvBlock(nn.Module):
@@ -202,15 +203,23 @@ class UNet_UAPS(nn.Module):
             if self._conv_weights is None:
                 self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
             conv.pack_all(self._conv_weights)
-        feats = self.encoder(x)
         if x.is_cuda and perturbations is None and self.n_aux > 0 and _FUSED_FAN:
-            # per feature map: the clean handle + one perturbed copy per auxiliary decoder; their gradients come back
-            # through ONE kernel that re-applies the perturbations and sums (perturb._PerturbFan)
+            # per feature map: the clean handle + one perturbed copy per auxiliary decoder (+ the 2x2 max-pool that feeds
+            # the next encoder level); all their gradients come back through ONE kernel that re-applies the perturbations,
+            # routes the pooled gradient to its arg-max positions and sums (perturb._PerturbFan)
             kinds = [_PERTURBATIONS[i % 3] for i in range(self.n_aux)]
-            fans = [perturb.perturbed_fan_out(f, kinds, _groups, self._noise.uniform_range) for f in feats]
+            enc = self.encoder
+            fans, f = [], enc.in_conv(x)
+            for blk in (enc.down1, enc.down2, enc.down3, enc.down4, None):
+                pool = blk is not None and _FUSED_POOL and f.shape[2] % 2 == 0 and f.shape[3] % 8 == 0
+                fan = perturb.perturbed_fan_out(f, kinds, _groups, self._noise.uniform_range, with_pool=pool)
+                fans.append(fan)
+                if blk is not None:
+                    f = blk.maxpool_conv[1](fan[-1]) if pool else blk(f)
             per_dec = [[fan[d] for fan in fans] for d in range(1 + self.n_aux)]
             outs = [self.main_decoder(per_dec[0])] + [dec(per_dec[i + 1]) for i, dec in enumerate(self.aux_decoders())]
             return tuple(outs)
+        feats = self.encoder(x)
         if x.is_cuda and torch.is_grad_enabled() and self.n_aux > 0:
             # every decoder gets its own handle on each feature map: the 1 + n_aux gradients are summed by one kernel
             handles = [fused.fan_out(f, 1 + self.n_aux) if f.requires_grad else (f,) * (1 + self.n_aux) for f in feats]
