@@ -298,6 +298,16 @@ int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map,
                      size_t workspace_bytes, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Optimizer: torch.optim.Adam(model.parameters(), lr) of UAPS_train.py:112, stepped at :292 -- one multi-tensor
+ * launch per 48 tensors instead of PyTorch's per-chunk foreach kernels.  Host arrays of n device pointers / sizes;
+ * `step` is the 1-based step count (bias corrections 1 - beta^step are computed on the host in double).
+ * weight_decay is the L2 form of torch.optim.Adam (added to the gradient); amsgrad / maximize are not supported.
+ * ------------------------------------------------------------------------------------------- */
+int uaps_adam_step(float* const* params_host, const float* const* grads_host, float* const* exp_avg_host,
+                   float* const* exp_avg_sq_host, const long* numel_host, int n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, long step, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Metrics: utilities/metrics.py:8-61 (pixel_accuracy, mIoU, mDice) need only the C x C confusion
  * matrix of arg-max(logits) against the labels: counts[t*C + p], int64, overwritten.
  * ------------------------------------------------------------------------------------------- */

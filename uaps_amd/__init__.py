@@ -19,6 +19,6 @@ from .unet import UNet, UNet_UAPS
 from .net_factory import net_factory
 from .consistency import (softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization, uncertainty_map)
 from .trainer import UAPSTrainer
-from . import conv, data, dist, inference
+from . import conv, data, dist, inference, optim
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,60 @@
+"""torch.optim.Adam with the step executed by one hand-written multi-tensor HIP kernel (csrc/adam.hip).
+
+Drop-in for the reference's `torch.optim.Adam(model.parameters(), lr=args.base_lr)` (UAPS_train.py:112): same
+constructor, same `state_dict()` layout (`step`, `exp_avg`, `exp_avg_sq` per parameter; the checkpoint dict of
+UAPS_train.py:443-448 stores it), same arithmetic order as PyTorch's single-tensor Adam, so a checkpoint written by
+either loads into the other.  amsgrad / maximize / capturable / differentiable are refused (the reference uses none)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **kw):
+        if amsgrad or kw.get("maximize") or kw.get("capturable") or kw.get("differentiable"):
+            raise ValueError("uaps_amd.optim.Adam: amsgrad / maximize / capturable / differentiable are not supported")
+        kw.pop("fused", None); kw.pop("foreach", None)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False, fused=False, **kw)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            dev = ps[0].device
+            _lib.require_device(ps[0], "uaps_amd.optim.Adam")
+            grads, ms, vs, steps = [], [], [], []
+            for p in ps:
+                if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous():
+                    raise TypeError("uaps_amd.optim.Adam: contiguous float32 parameters on one device expected")
+                st = self.state[p]
+                if len(st) == 0:                                  # same lazy state as torch.optim.Adam (fused=False)
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                grads.append(g); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); steps.append(st["step"])
+            torch._foreach_add_(steps, 1)                         # host-resident step counters, one call
+            step = int(steps[0])
+            if int(steps[-1]) != step:
+                raise RuntimeError("uaps_amd.optim.Adam: parameters of one group must share the step count")
+            n = len(ps)
+            arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            sizes = (C.c_long * n)(*[p.numel() for p in ps])
+            b1, b2 = group["betas"]
+            lr = float(group["lr"])
+            with _lib.device_guard(dev):
+                rc = L.uaps_adam_step(arr(ps), arr(grads), arr(ms), arr(vs), sizes, n, lr, float(b1), float(b2), float(group["eps"]),
+                                      float(group["weight_decay"]), step, _lib.current_stream(dev))
+            _lib.check(rc, "uaps_adam_step")
+        return loss

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import dist as udist
-from . import losses, metrics, perturb
+from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
 
 
@@ -29,7 +29,8 @@ class UAPSTrainer:
         self.device = params[0].device
         on_gpu = self.device.type == "cuda"
         # UAPS_train.py:112-113
-        self.optimizer = torch.optim.Adam(params, lr=base_lr, **({"fused": True} if on_gpu else {}))
+        # same class contract and state_dict as torch.optim.Adam; on the GPU the step is one hand-written multi-tensor kernel
+        self.optimizer = optim.Adam(params, lr=base_lr) if on_gpu else torch.optim.Adam(params, lr=base_lr)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="max", min_lr=1e-8, patience=50)
         self.c1, self.c2, self.rampup, self.ramp_divisor = consistency1, consistency2, consistency_rampup, ramp_divisor
         self.iter_num = 0
