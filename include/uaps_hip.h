@@ -226,7 +226,9 @@ int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs,
  *   wb [ks*ks][Kpad(Cout)][Npad(Cin)]   (transposed, taps flipped) for the input gradient,
  * sizes (in floats) from uaps_conv_pack_floats.  `cfg` = 0 selects the tiling automatically; other
  * values are tuning overrides used by tools/bench_conv.py (low byte: output channels per workgroup,
- * 16/32/64; bits 8-9: 1 = 8x32 pixel tile, 2 = 16x16; for bwd_weight: number of pixel splits).
+ * 16/32/64; bits 8-9: 1 = 8x32 pixel tile, 2 = 16x16; for bwd_weight the low 24 bits: number of pixel splits).
+ * Bits 24-27 of `cfg` are functional: the dilation of a 3x3 kernel, 0/1 (none), 2 or 4, with padding = dilation
+ * (the dilated stages of utilities/resnet.py:8-10, 201-203); pass the same value to all three directions.
  * ------------------------------------------------------------------------------------------- */
 int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);
 int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream);

@@ -232,9 +232,15 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     return dw, db
 
 
+def _dil_cfg(dilation: int) -> int:
+    if dilation not in (1, 2, 4):
+        raise ValueError("conv2d: dilation 1, 2 or 4")
+    return 0 if dilation == 1 else dilation << 24
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, want_stats=False):
+    def forward(ctx, x, weight, bias, want_stats=False, dilation=1):
         _lib.require_device(x, "conv2d")
         ctx.set_materialize_grads(False)          # no zero tensors for the unused gradient of `stats`
         if x.dtype != torch.float32 or weight.dtype != torch.float32:
@@ -245,37 +251,39 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError(f"conv2d: input has {x.shape[1]} channels, weight expects {Cin}")
         need_bwd = ctx.needs_input_grad[0]
         wf, wb = pack_weights(weight, need_bwd=True)
+        cfg = _dil_cfg(dilation)
         ctx.save_for_backward(x, wb)
-        ctx.meta = (Cin, Cout, ks, bias is not None)
+        ctx.meta = (Cin, Cout, ks, bias is not None, cfg)
         if want_stats:
-            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, want_stats=True)
+            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True)
             ctx.mark_non_differentiable(stats)
             return y, stats
-        return conv_fwd_raw(x, wf, bias, Cout, ks)
+        return conv_fwd_raw(x, wf, bias, Cout, ks, cfg)
 
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         x, wb = ctx.saved_tensors
-        Cin, Cout, ks, has_bias = ctx.meta
+        Cin, Cout, ks, has_bias, cfg = ctx.meta
         dy = dy.contiguous()
-        dx = conv_bwd_data_raw(dy, wb, Cin, ks) if ctx.needs_input_grad[0] else None
+        dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None
+            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg)
+        return dx, dw, db, None, None
 
 
-def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """F.conv2d(x, weight, bias, stride=1, padding=weight.shape[-1] // 2) for 3x3 and 1x1 kernels."""
-    return _Conv2d.apply(x, weight, bias, False)
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1) -> torch.Tensor:
+    """F.conv2d(x, weight, bias, stride=1, padding=dilation * (k // 2), dilation=dilation) for 3x3 (dilation 1, 2, 4) and
+    1x1 kernels."""
+    return _Conv2d.apply(x, weight, bias, False, dilation)
 
 
-def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None):
+def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1):
     """conv2d that also returns the per-tile (sum, sum of squares) of its output, float32 [Cout, B, parts, 2], for
     fused.bn_act(..., stats=...): the BatchNorm statistics pass rides in the convolution's epilogue."""
-    return _Conv2d.apply(x, weight, bias, True)
+    return _Conv2d.apply(x, weight, bias, True, dilation)
 
 
 class _Conv2dCat(torch.autograd.Function):

@@ -11,7 +11,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline int kdim_pad(int c, int ks) { return (ks == 3 && c <= 4) ? 4 : round_up(c, 8); }   // K (contraction) channels: chunk of 4 or 8
 inline int ndim_pad(int c) { return round_up(c, 16); }              // N (output) channels: 16-wide MFMA tiles
 
-template <int KS, int TH, int TW, int BN, int CK>
+template <int KS, int TH, int TW, int BN, int CK, int DIL = 1>
 int launch_fwd(ConvFwdArgs a, bool vec, int extra_lds, hipStream_t s) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
@@ -19,8 +19,8 @@ int launch_fwd(ConvFwdArgs a, bool vec, int extra_lds, hipStream_t s) {
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;   // multiple of 8 for the XCD swizzle
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     // extra_lds: unused dynamic LDS, requested only to cap the number of co-resident workgroups per CU
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+    else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -34,19 +34,29 @@ int dispatch_bn_ck(const ConvFwdArgs& a, int bn, int ck, bool vec, int xl, hipSt
     return launch_fwd<KS, TH, TW, 64, 8>(a, vec, xl, s);
 }
 
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds; };
+// dilated 3x3 (ResNet stages with stride replaced by dilation): 8x32 tiles, 8-channel chunks
+template <int DIL>
+int dispatch_dilated(const ConvFwdArgs& a, int bn, bool vec, int xl, hipStream_t s) {
+    if (bn == 16) return launch_fwd<3, 8, 32, 16, 8, DIL>(a, vec, xl, s);
+    if (bn == 32) return launch_fwd<3, 8, 32, 32, 8, DIL>(a, vec, xl, s);
+    return launch_fwd<3, 8, 32, 64, 8, DIL>(a, vec, xl, s);
+}
+
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
     if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     p->CinP = kdim_pad(Cin, ks); p->CoutP = ndim_pad(Cout);
-    p->ck = (ks == 3 && Cin <= 4) ? 4 : 8;
+    p->ck = (ks == 3 && Cin <= 4 && ((cfg >> 24) & 0xf) <= 1) ? 4 : 8;
     // 16-byte loads/stores need rows that start 16-byte aligned
     p->vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     // pixel tile: 8 rows x 32 columns, or 16 x 16 for narrow maps (both 256 pixels = 16 M tiles)
-    const bool wide = ((cfg >> 8) & 3) ? (((cfg >> 8) & 3) == 1) : (W >= 32);
+    const bool wide = ((cfg >> 24) & 0xf) > 1 ? true : (((cfg >> 8) & 3) ? (((cfg >> 8) & 3) == 1) : (W >= 32));
     p->extra_lds = ((cfg >> 16) & 0xff) * 1024;
+    p->dil = ((cfg >> 24) & 0xf) ? ((cfg >> 24) & 0xf) : 1;
+    if (p->dil != 1 && (ks != 3 || (p->dil != 2 && p->dil != 4) || Cin <= 4)) return UAPS_ERANGE;
     p->th = wide ? 8 : 16; p->tw = wide ? 32 : 16;
     int bn = (p->CoutP % 64 == 0) ? 64 : (p->CoutP % 32 == 0 ? 32 : 16);
     const long tiles = (long)B * ((H + p->th - 1) / p->th) * ((W + p->tw - 1) / p->tw);
@@ -75,6 +85,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     const bool wide = p.tw == 32;
+    if (p.dil == 2) return dispatch_dilated<2>(a, p.bn, p.vec, p.extra_lds, s);
+    if (p.dil == 4) return dispatch_dilated<4>(a, p.bn, p.vec, p.extra_lds, s);
     if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
     return wide ? dispatch_bn_ck<1, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<1, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
 }
@@ -175,6 +187,6 @@ extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int
     const int rc = plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
     if (!buf || buflen < 64) return UAPS_EINVAL;
-    snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1);
+    snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);
     return UAPS_OK;
 }

@@ -41,8 +41,11 @@ constexpr int pad_to_mod32(int n, int r) { return n + ((r - n % 32) + 32) % 32; 
 
 // Geometry of a staged (haloed) pixel tile: rows start XOFF floats left of the tile so that the row
 // base is 16-byte aligned in global memory (tile origins are multiples of 16 pixels).
-template <int KS, int TH, int TW> struct TileGeom {
-    static constexpr int PAD = KS / 2;
+// DIL = dilation of a 3x3 kernel (padding = DIL, the "same" form of the reference's dilated ResNet stages,
+// utilities/resnet.py:8-10, 201-203); the halo then is DIL rows / columns (DIL <= 4 keeps the 4-float left margin).
+template <int KS, int TH, int TW, int DIL = 1> struct TileGeom {
+    static_assert(DIL >= 1 && DIL <= 4, "dilation 1..4");
+    static constexpr int PAD = (KS / 2) * DIL;
     static constexpr int XOFF = PAD ? 4 : 0;
     static constexpr int IH = TH + 2 * PAD;
     static constexpr int IW = TW + 2 * XOFF;
@@ -127,9 +130,9 @@ struct ConvFwdArgs {
     int tiles_x, tiles_y, nblk;
 };
 
-template <int KS, int TH, int TW, int BN, int CK, int VEC>
+template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL = 1>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a) {
-    using G = TileGeom<KS, TH, TW>;
+    using G = TileGeom<KS, TH, TW, DIL>;
     constexpr int TAPS = KS * KS, IW = G::IW, XS = G::XOFF - G::PAD;
     constexpr int PS = pad_to_mod32(G::PLANE, 16);     // input plane stride in LDS (dwords)
     constexpr int BNS = pad_to_mod32(BN, 16);           // weight row stride in LDS (dwords)
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
 #pragma unroll
             for (int n = 0; n < NW; ++n) b_[n] = sW[boff + (tap * CK + c4 * 4) * BNS + n * 16];
 #pragma unroll
-            for (int m = 0; m < MW; ++m) a_[m] = sIn[aoff[m] + c4 * 4 * PS + (tap / KS) * IW + tap % KS];
+            for (int m = 0; m < MW; ++m) a_[m] = sIn[aoff[m] + c4 * 4 * PS + (tap / KS) * DIL * IW + (tap % KS) * DIL];
         };
         read_frags(0, af[0], bf[0]);
 #pragma unroll
@@ -318,8 +321,8 @@ struct ConvWrwArgs {
     int tiles_x, tiles_y, ncob, ncib, nsplit;
 };
 
-template <int KS, int TH, int TW, int WCO, int WCI, int VEC> struct WrwCfg {
-    using G = TileGeom<KS, TH, TW>;
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1> struct WrwCfg {
+    using G = TileGeom<KS, TH, TW, DIL>;
     using GD = TileGeom<1, TH, TW>;
     static constexpr int WK = 4 / (WCO * WCI);
     static constexpr int TAPS = KS * KS;
@@ -331,9 +334,9 @@ template <int KS, int TH, int TW, int WCO, int WCI, int VEC> struct WrwCfg {
     static constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
 };
 
-template <int KS, int TH, int TW, int WCO, int WCI, int VEC>
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a) {
-    using Cfg = WrwCfg<KS, TH, TW, WCO, WCI, VEC>;
+    using Cfg = WrwCfg<KS, TH, TW, WCO, WCI, VEC, DIL>;
     using G = typename Cfg::G;
     using GD = typename Cfg::GD;
     constexpr int WK = Cfg::WK, TAPS = Cfg::TAPS, IW = G::IW, XS = G::XOFF - G::PAD;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
             const int row = wk + (s / (TW / 4)) * WK, x4 = s % (TW / 4);
             a_ = pa0[row * TW + x4 * 4];
 #pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) b_[tap] = pb0[(row + tap / KS) * IW + x4 * 4 + tap % KS];
+            for (int tap = 0; tap < TAPS; ++tap) b_[tap] = pb0[(row + (tap / KS) * DIL) * IW + x4 * 4 + (tap % KS) * DIL];
         };
         read_frags(0, af[0], bf[0]);
 #pragma unroll

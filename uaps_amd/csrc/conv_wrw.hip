@@ -7,13 +7,16 @@ using namespace uaps;
 namespace {
 
 // wave arrangement: (WCO, WCI) 16-channel blocks per workgroup, the remaining factor of 4 splits the tile rows
-struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS; long tiles; };
+struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; };
 
 WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
     WrwPlan p{};
+    p.dil = ((cfg >> 24) & 0xf) ? ((cfg >> 24) & 0xf) : 1;       // bits 24-27: dilation; low bits: pixel splits override
+    cfg &= 0xffffff;
     p.wco = Cout > 16 ? 2 : 1;
     p.wci = Cin > 16 ? 2 : 1;
-    const bool wide = W >= 32, big = p.wco * p.wci == 4;     // 32x32 channel blocks stage half-height tiles (LDS)
+    if (p.dil > 1) p.wco = p.wci = 2;                             // dilated variants exist for 32 x 32 channel blocks only
+    const bool wide = W >= 32 || p.dil > 1, big = p.wco * p.wci == 4;     // 32x32 channel blocks stage half-height tiles (LDS)
     p.TW = wide ? 32 : 16;
     p.TH = wide ? (big ? 4 : 8) : (big ? 8 : 16);
     p.ncob = (Cout + 16 * p.wco - 1) / (16 * p.wco);
@@ -33,18 +36,22 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
 
 size_t wrw_ws_floats(const WrwPlan& p, int taps) { return (size_t)p.nsplit * ((size_t)taps * p.CoutS * p.CinS + p.CoutS); }
 
-template <int KS, int TH, int TW, int WCO, int WCI>
+template <int KS, int TH, int TW, int WCO, int WCI, int DIL = 1>
 int launch_wrw(const ConvWrwArgs& a, bool vec, hipStream_t s) {
     const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;      // multiple of 8 for the XCD swizzle
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
-    if (vec) hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (vec) hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 
 template <int KS>
 int dispatch_wrw(const ConvWrwArgs& a, const WrwPlan& p, bool vec, hipStream_t s) {
     const bool wide = p.TW == 32;
+    if constexpr (KS == 3) {
+        if (p.dil == 2) return launch_wrw<3, 4, 32, 2, 2, 2>(a, vec, s);
+        if (p.dil == 4) return launch_wrw<3, 4, 32, 2, 2, 4>(a, vec, s);
+    }
     if (p.wco == 2 && p.wci == 2) return wide ? launch_wrw<KS, 4, 32, 2, 2>(a, vec, s) : launch_wrw<KS, 8, 16, 2, 2>(a, vec, s);
     if (p.wco == 2) return wide ? launch_wrw<KS, 8, 32, 2, 1>(a, vec, s) : launch_wrw<KS, 16, 16, 2, 1>(a, vec, s);
     if (p.wci == 2) return wide ? launch_wrw<KS, 8, 32, 1, 2>(a, vec, s) : launch_wrw<KS, 16, 16, 1, 2>(a, vec, s);
@@ -69,6 +76,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     const int taps = ks * ks;
     const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
+    if (p.dil != 1 && (ks != 3 || (p.dil != 2 && p.dil != 4))) return UAPS_ERANGE;
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
     ConvWrwArgs a{};
     a.dout = dy; a.in = x; a.in2 = x2; a.Csplit = Csplit; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
@@ -124,6 +132,6 @@ extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, 
 extern "C" int uaps_conv_wrw_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf, size_t buflen) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || !buf || buflen < 64) return UAPS_EINVAL;
     const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
-    snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1);
+    snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1, p.dil);
     return UAPS_OK;
 }
