@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--classes", type=int, default=4)
     ap.add_argument("--aux", type=int, default=3)
+    ap.add_argument("--net", default="unet_uaps", help="unet_uaps (BASELINE.json configs[1], the reported metric) or resnet50_uaps (configs[4] shape study)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -84,7 +85,7 @@ def main():
 
     torch.manual_seed(1337)
     D, C, H, W, b = args.aux + 1, args.classes, args.size, args.size, args.batch
-    model = uaps_amd.net_factory("unet_uaps", 3, C, n_aux=args.aux)
+    model = uaps_amd.net_factory(args.net, 3, C, n_aux=args.aux)
     uaps_amd.dist.broadcast_model(model)
     trainer = uaps_amd.UAPSTrainer(model, seed=1337)
     data = uaps_amd.data.SyntheticBatches(b, 3, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
@@ -184,7 +185,9 @@ def main():
                "config": {"workload": f"UAPS K={args.aux} decoders, NEU-Seg-shaped {H}x{W} {C}-class, batch {b}+{b} per GPU (BASELINE.json configs[1])",
                           "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5)},
                "roofline": roof, "kernels": kern}
-        if world == 1 and not args.no_cpu_baseline:
+        if args.net != "unet_uaps":
+            res["config"]["workload"] = f"{args.net} K={args.aux}, {H}x{W} {C}-class, batch {b}+{b} per GPU (not the BASELINE metric config)"
+        if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
             res["cpu_baseline"] = cpu_baseline(4, H, W)
         print(json.dumps(res), flush=True)
     if world > 1:

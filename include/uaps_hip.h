@@ -299,6 +299,11 @@ int uaps_softmax_kl_bwd(const float* a, const float* b, const float* gscalar, in
 int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map, float* ent_mean, void* workspace,
                      size_t workspace_bytes, uaps_stream_t stream);
 
+/* Residual join of the ResNet blocks (utilities/resnet.py:47-50, 88-91): out = relu(a + b) over n floats; the
+ * backward of both addends is dx = dout * (out > 0). */
+int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream);
+int uaps_relu_bwd(const float* dout, const float* out, float* dx, long n, uaps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam(model.parameters(), lr) of UAPS_train.py:112, stepped at :292 -- one multi-tensor
  * launch per 48 tensors instead of PyTorch's per-chunk foreach kernels.  Host arrays of n device pointers / sizes;

@@ -372,6 +372,30 @@ def g6():
     print("g6 loss", float(out["loss"]), "sup", float(out["sup"]))
 
 
+def g7():
+    """ResNet-50 backbone of utilities/resnet.py (dilated layer3/layer4): outputs of base_forward for RNG-free formula
+    weights (tests/formula_weights.py) in eval and train mode, plus the ordered state_dict keys and shapes."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from formula_weights import formula_state_dict, formula_input
+    import utilities.resnet as R_res
+    torch.manual_seed(0)
+    net = R_res.resnet50()
+    net.load_state_dict(formula_state_dict(net.state_dict()))
+    x = formula_input((2, 3, 48, 48))
+    out = {"x": x.numpy(), "keys": np.array(list(net.state_dict().keys())),
+           "shapes": np.array([str(tuple(v.shape)) for v in net.state_dict().values()])}
+    net.eval()
+    with torch.no_grad():
+        for i, c in enumerate(net.base_forward(x)):
+            out[f"eval_c{i + 1}"] = c.numpy()
+    net.train()
+    with torch.no_grad():
+        cs = net.base_forward(x)
+    out["train_c1"], out["train_c4"] = cs[0].numpy(), cs[3].numpy()
+    out["train_rm_layer4_2_bn3"] = net.layer4[2].bn3.running_mean.numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_resnet.npz"), **out)
+
+
 def main():
     torch.set_num_threads(4)
     g1_case("neu", 4, 2, 4, 16, 16, seed=0)
@@ -389,6 +413,7 @@ def main():
     g4()
     g5()
     g6()
+    g7()
 
 
 if __name__ == "__main__":

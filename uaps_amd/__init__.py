@@ -16,6 +16,7 @@ from .losses import (dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_st
 from .perturb import FeatureNoise, Dropout, FeatureDropout, manual_seed as perturb_manual_seed
 from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, seg_confusion_per_image, metrics_from_confusion
 from .unet import UNet, UNet_UAPS
+from .res_uaps import ResUAPS, ResNet, resnet50
 from .net_factory import net_factory
 from .consistency import (softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization, uncertainty_map)
 from .trainer import UAPSTrainer

@@ -73,6 +73,8 @@ SIGNATURES = {
     "uaps_fanin_perturbed": (C.c_int, [_PTR] * 4 + [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_float] + [C.c_int] * 4 + [_PTR, _PTR]),
     "uaps_maxpool2x2_fwd": (C.c_int, [_PTR] + [C.c_int] * 4 + [_PTR, _PTR, _PTR]),
     "uaps_adam_step": (C.c_int, [_PTR] * 5 + [C.c_int] + [C.c_double] * 5 + [C.c_long, _PTR]),
+    "uaps_add_relu": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
+    "uaps_relu_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 

@@ -219,3 +219,41 @@ extern "C" int uaps_entropy_map(const float* p, int B, int C, int H, int W, floa
     hipLaunchKernelGGL(pair_finalize, dim3(1), dim3(64), 0, s, (const float*)ws, grid, (double)N, ent_mean);
     return (int)hipGetLastError();
 }
+
+// ---- residual join of the ResNet blocks (utilities/resnet.py:47-50, 88-91): out = relu(a + b), and its backward
+// da = db = dout * (out > 0), each one 16-byte-per-lane streaming pass -------------------------------------------------
+namespace {
+__global__ __launch_bounds__(kThreads) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ out, long n4, long n) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kThreads) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+    }
+    if (blockIdx.x == 0)
+        for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) out[i] = fmaxf(a[i] + b[i], 0.f);
+}
+__global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                            float* __restrict__ dx, long n4, long n) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kThreads) {
+        const float4 g = reinterpret_cast<const float4*>(dout)[i], o = reinterpret_cast<const float4*>(out)[i];
+        reinterpret_cast<float4*>(dx)[i] = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    }
+    if (blockIdx.x == 0)
+        for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) dx[i] = out[i] > 0.f ? dout[i] : 0.f;
+}
+inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+extern "C" int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
+    if (!a || !b || !out || n <= 0) return UAPS_EINVAL;
+    const long n4 = (al16p(a) && al16p(b) && al16p(out)) ? n / 4 : 0;
+    hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, a, b, out, n4, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_relu_bwd(const float* dout, const float* out, float* dx, long n, uaps_stream_t stream) {
+    if (!dout || !out || !dx || n <= 0) return UAPS_EINVAL;
+    const long n4 = (al16p(dout) && al16p(out) && al16p(dx)) ? n / 4 : 0;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, dout, out, dx, n4, n);
+    return (int)hipGetLastError();
+}
