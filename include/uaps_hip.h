@@ -268,6 +268,24 @@ int uaps_conv_bwd_data_cat(const float* dy, const float* wb, float* dx1, int C1,
 int uaps_conv_bwd_weight_partial_cat(const float* dy, const float* x1, int C1, const float* x2, int C2, int want_bias,
                                      int B, int Cout, int H, int W, int ks, int cfg, void* workspace,
                                      size_t workspace_bytes, uaps_stream_t stream);
+/* conv -> BatchNorm(train) -> LeakyReLU -> conv without the activated tensor in between (the two convs of a ConvBlock,
+ * UAPS_unet.py:37-41; an UpBlock's conv1x1 / Decoder.out_conv after a ConvBlock, :73, :138).  uaps_bn_finalize_train turns
+ * the first conv's epilogue partials into batch statistics (running statistics updated as nn.BatchNorm2d does) and
+ * xf [groups][C] float2 = (scale, shift) = (gamma*invstd, beta - mean*scale); the second conv reads the RAW output y of the
+ * first and applies leaky_relu(fma(y, scale, shift)) (0 <= slope <= 1) while staging, in the forward (uaps_conv_fwd_bn) and in its weight gradient
+ * (uaps_conv_bwd_weight_partial_bn, finished by uaps_conv_bwd_weight_reduce).  Its input gradient is uaps_conv_bwd_data,
+ * followed by uaps_bn_act_bwd_grouped(drop_p = 0) on (that gradient, y).  W % 4 == 0, 16-byte aligned tensors, no
+ * dilation, Cin > 4; otherwise UAPS_ERANGE (use the unfused calls). */
+int uaps_bn_finalize_train(const void* partials, int parts_per_image, const float* conv_bias, const float* gamma,
+                           const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float momentum, float eps, int B, int C, int H, int W, int groups, float* save_mean,
+                           float* save_invstd, void* xf, uaps_stream_t stream);
+int uaps_conv_fwd_bn(const float* x_raw, const void* xf, float slope, int groups, const float* wf, const float* bias,
+                     float* y, void* stats_or_null, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
+                     uaps_stream_t stream);
+int uaps_conv_bwd_weight_partial_bn(const float* dy, const float* x_raw, const void* xf, float slope, int groups,
+                                    int want_bias, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
+                                    void* workspace, size_t workspace_bytes, uaps_stream_t stream);
 /* Name (as rocprofv3 prints it, without namespace) of the kernel instantiation the calls above launch
  * for these dimensions; buf_host needs >= 64 bytes.  For uaps_conv_bwd_data pass Cin and Cout swapped
  * to uaps_conv_fwd_variant.  Used by bench.py to group its per-launch HIP-event timings. */

@@ -246,3 +246,67 @@ def test_hip_adam_matches_torch_adam_and_shares_its_state_dict():
                 o_ref.load_state_dict(sd_mine); o_mine.load_state_dict(sd_ref)
         for a, b in zip(ref, mine):
             np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,groups", [(4, 16, 16, 64, 64, 3, 2), (2, 32, 24, 16, 32, 3, 1), (4, 64, 32, 8, 8, 1, 2),
+                                                      (2, 16, 4, 48, 80, 3, 1), (6, 40, 48, 20, 12, 3, 3), (2, 128, 64, 32, 32, 1, 1)])
+def test_bn_act_conv_equals_bn_act_then_conv_and_torch(B, Cin, Cout, H, W, ks, groups):
+    """conv2(leaky_relu(bn_train(conv1(x)))) with the normalisation applied while conv2 stages its input
+    (fused.bn_act_conv: uaps_bn_finalize_train + uaps_conv_fwd_bn + uaps_conv_bwd_weight_partial_bn) against
+    (a) the materialising kernels of this package and (b) torch modules on the CPU in fp64, per statistics group."""
+    from uaps_amd import conv, fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + Cin * 10 + ks)
+    x = torch.randn(B, 8, H, W, generator=g)
+    c1 = nn.Conv2d(8, Cin, 3, padding=1)
+    c2 = nn.Conv2d(Cin, Cout, ks, padding=ks // 2)
+    bn = nn.BatchNorm2d(Cin)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.uniform_(-0.5, 0.5, generator=g)
+    gout = torch.randn(B, Cout, H, W, generator=g)
+
+    # (b) fp64 CPU reference, one BatchNorm call per group like the reference's two forwards
+    c1d, c2d, bnd = (copy_double(m) for m in (c1, c2, bn))
+    xd = x.double().requires_grad_(True)
+    yd = c1d(xd)
+    Bg = B // groups
+    ad = torch.cat([F.leaky_relu(bnd(yd[i * Bg:(i + 1) * Bg]), 0.01) for i in range(groups)], 0)
+    zd = c2d(ad)
+    zd.backward(gout.double())
+
+    def run(fusedpath):
+        m1, m2, mb = (copy_to(m, dev) for m in (c1, c2, bn))
+        xg = x.to(dev).requires_grad_(True)
+        with fused.stat_groups(groups):
+            y, st = conv.conv2d_with_stats(xg, m1.weight, None)
+            if fusedpath:
+                z, zst = fused.bn_act_conv(y, st, m1.bias, mb, 0.01, m2.weight, m2.bias, want_stats=True)
+            else:
+                a = fused.bn_act(y, m1.bias, mb, 0.01, 0.0, True, st)
+                z, zst = conv.conv2d_with_stats(a, m2.weight, m2.bias)
+        z.backward(gout.to(dev))
+        return (z, zst, xg.grad, m1.weight.grad, m2.weight.grad, m2.bias.grad, mb.weight.grad, mb.bias.grad, mb.running_mean,
+                mb.running_var, mb.num_batches_tracked)
+
+    fu, un = run(True), run(False)
+    names = ["z", "zstats", "dx", "dw1", "dw2", "db2", "dgamma", "dbeta", "running_mean", "running_var", "nbt"]
+    for n_, a_, b_ in zip(names, fu, un):
+        scale = float(b_.abs().max()) + 1e-6
+        assert float((a_.float() - b_.float()).abs().max()) <= 2e-5 * scale + 1e-6, n_
+    refs = [zd, None, xd.grad, c1d.weight.grad, c2d.weight.grad, c2d.bias.grad, bnd.weight.grad, bnd.bias.grad, bnd.running_mean,
+            bnd.running_var, bnd.num_batches_tracked]
+    for n_, a_, r_ in zip(names, fu, refs):
+        if r_ is None:
+            continue
+        scale = float(r_.abs().max()) + 1e-6
+        assert float((a_.cpu().double() - r_.double()).abs().max()) <= 3e-4 * scale + 1e-6, n_
+
+
+def copy_double(m):
+    import copy
+    return copy.deepcopy(m).double()
+
+
+def copy_to(m, dev):
+    import copy
+    return copy.deepcopy(m).to(dev)

@@ -61,6 +61,9 @@ SIGNATURES = {
     "uaps_conv_fwd_cat": (C.c_int, [_PTR, C.c_int, _PTR, C.c_int] + [_PTR] * 4 + [C.c_int] * 6 + [_PTR]),
     "uaps_conv_bwd_data_cat": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, C.c_int] + [C.c_int] * 6 + [_PTR]),
     "uaps_conv_bwd_weight_partial_cat": (C.c_int, [_PTR, _PTR, C.c_int, _PTR, C.c_int] + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
+    "uaps_bn_finalize_train": (C.c_int, [_PTR, C.c_int] + [_PTR] * 6 + [C.c_float] * 2 + [C.c_int] * 5 + [_PTR] * 4),
+    "uaps_conv_fwd_bn": (C.c_int, [_PTR, _PTR, C.c_float, C.c_int] + [_PTR] * 4 + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_bwd_weight_partial_bn": (C.c_int, [_PTR, _PTR, _PTR, C.c_float, C.c_int] + [C.c_int] * 8 + [_PTR, C.c_size_t, _PTR]),
     "uaps_conv_fwd_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_wrw_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),

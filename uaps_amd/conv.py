@@ -51,14 +51,17 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
     if name is None:
         buf = C.create_string_buffer(96)
         L = _lib.lib()
-        if kind == "wrw":
+        if kind in ("wrw", "wrw_bn"):
             rc = L.uaps_conv_wrw_variant(B, Cin, Cout, H, W, ks, cfg, buf, 96)
         elif kind == "bwd_data":
             rc = L.uaps_conv_fwd_variant(B, Cout, Cin, H, W, ks, cfg, buf, 96)
         else:
             rc = L.uaps_conv_fwd_variant(B, Cin, Cout, H, W, ks, cfg, buf, 96)
         _lib.check(rc, "uaps_conv_*_variant")
-        name = _variant_cache[key] = buf.value.decode()
+        name = buf.value.decode()
+        if kind.endswith("_bn"):      # the variants that apply BatchNorm + LeakyReLU while staging (fused._BnActConv)
+            name = name.replace("conv_fwd_kernel", "conv_fwd_bn_kernel").replace("conv_wrw_kernel", "conv_wrw_bn_kernel")
+        _variant_cache[key] = name
     return name
 
 

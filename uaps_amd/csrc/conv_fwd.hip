@@ -19,6 +19,15 @@ int launch_fwd(ConvFwdArgs a, bool vec, int extra_lds, hipStream_t s) {
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;   // multiple of 8 for the XCD swizzle
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     // extra_lds: unused dynamic LDS, requested only to cap the number of co-resident workgroups per CU
+    if (a.xf) {                  // BatchNorm + LeakyReLU of the input applied while staging: 16-byte form, 8-channel chunks, no dilation
+        if constexpr (DIL == 1 && CK == 8) {
+            if (!vec) return UAPS_ERANGE;
+            hipLaunchKernelGGL((conv_fwd_bn_kernel<KS, TH, TW, BN, CK, 4, 1>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+            return (int)hipGetLastError();
+        } else {
+            return UAPS_ERANGE;
+        }
+    }
     if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
     else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
     return (int)hipGetLastError();
@@ -71,8 +80,10 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
 // x2 / Csplit: optional second input tensor holding channels [Csplit, Cin); y2 / Osplit likewise for the output
 int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
                  int cfg, hipStream_t s, float2* stats = nullptr, const float* x2 = nullptr, int Csplit = -1,
-                 float* y2 = nullptr, int Osplit = -1) {
+                 float* y2 = nullptr, int Osplit = -1, const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
     if (!x || !wp || !y) return UAPS_EINVAL;
+    if (xf && (x2 || groups < 1 || B % groups || (uintptr_t)xf % 8)) return UAPS_EINVAL;
+    if (xf && !(xf_slope >= 0.f && xf_slope <= 1.f)) return UAPS_ERANGE;      // leaky_relu is evaluated as max(z, slope * z)
     if (Csplit < 0 || !x2) Csplit = Cin;
     if (Osplit < 0 || !y2) Osplit = Cout;
     if (Csplit > Cin || Osplit > Cout || (Csplit < Cin && (Csplit % 8 || Csplit == 0)) || (Osplit < Cout && Osplit == 0)) return UAPS_EINVAL;
@@ -84,6 +95,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
+    a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool wide = p.tw == 32;
     if (p.dil == 2) return dispatch_dilated<2>(a, p.bn, p.vec, p.extra_lds, s);
     if (p.dil == 4) return dispatch_dilated<4>(a, p.bn, p.vec, p.extra_lds, s);
@@ -148,6 +160,16 @@ extern "C" int uaps_conv_fwd_stats(const float* x, const float* wf, const float*
                                    int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
     if (!stats) return UAPS_EINVAL;
     return conv_fwd_any(x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats);
+}
+
+// y = conv(leaky_relu(batch_norm_train(x_raw))) where x_raw is a previous conv's raw output and the normalisation
+// coefficients xf [groups][Cin] float2 (scale, shift) come from uaps_bn_finalize_train: the activated
+// tensor between the two convs of a ConvBlock (UAPS_unet.py:38-41) is never written.  stats may be NULL.
+extern "C" int uaps_conv_fwd_bn(const float* x_raw, const void* xf, float slope, int groups, const float* wf, const float* bias,
+                                float* y, void* stats, int B, int Cin, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    if (!xf) return UAPS_EINVAL;
+    return conv_fwd_any(x_raw, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, nullptr, -1, nullptr, -1,
+                        xf, slope, groups);
 }
 
 extern "C" int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W, int ks, int cfg, int* parts_per_image) {

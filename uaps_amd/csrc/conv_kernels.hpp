@@ -34,6 +34,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kConvThreads = 256;
+#ifndef UAPS_XF_S0
+#define UAPS_XF_S0 2      // the staging-time BatchNorm work starts after UAPS_XF_S0 / 4 of a chunk's k-steps
+#endif
 constexpr uint32_t kOob = 0x80000000u;   // byte offset no tensor of < 2 GiB reaches: buffer loads return 0
 
 // smallest s >= n with s % 32 == r
@@ -128,10 +131,17 @@ struct ConvFwdArgs {
     int B, Cin, Cout, H, W;
     int CinP, CoutP;
     int tiles_x, tiles_y, nblk;
+    // conv_fwd_bn_kernel only: the input is the raw output y of a previous conv and this kernel applies the train-mode
+    // BatchNorm + LeakyReLU that sits between the two (UAPS_unet.py:38-39) while staging, so the activated tensor is
+    // never written: xf[g][c] = (scale, shift) = (gamma*invstd, beta - mean*gamma*invstd) per statistics group
+    // g = image / xf_Bg and channel c; the staged value is leaky_relu(fma(y, scale, shift))
+    const float2* xf;
+    float xf_slope;
+    int xf_Bg;
 };
 
-template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL = 1>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a) {
+template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL, bool XF>
+__device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
     using G = TileGeom<KS, TH, TW, DIL>;
     constexpr int TAPS = KS * KS, IW = G::IW, XS = G::XOFF - G::PAD;
     constexpr int PS = pad_to_mod32(G::PLANE, 16);     // input plane stride in LDS (dwords)
@@ -179,6 +189,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
 
     float rin[Plan::NT][VEC];
     float rw[NWT_T][4];
+    f32x2 rxf[XF ? Plan::NT : 1];                // XF: (scale, shift) of each staged unit's channel, (0, 0) for padding
+    const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u)
+                                            : make_rsrc(a.wp, 0);
 
     auto load_chunk = [&](int ci0) {
         // the chunk lies in one of the two sources (Csplit % CK == 0); channels past the source's end read as zero
@@ -188,9 +201,33 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
             : make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Csplit - ci0) * HW * 4u);
 #pragma unroll
         for (int n = 0; n < Plan::NT; ++n) buf_load<VEC>(rs_in, plan.goff[n], rin[n]);
+        if constexpr (XF) {                          // padding pixels and channels past Cin read (0, 0): the unit stays zero
+#pragma unroll
+            for (int n = 0; n < Plan::NT; ++n)
+                rxf[n] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                    rs_xf, plan.goff[n] != kOob ? (int)((uint32_t)(ci0 + (plan.pos[n] >> 20)) * 8u) : (int)kOob, 0, 0));
+        }
         const uint32_t wbase = (uint32_t)ci0 * a.CoutP * 4u;
 #pragma unroll
         for (int n = 0; n < NWT_T; ++n) buf_load<4>(rs_w, wgoff[n] + wbase, rw[n]);
+    };
+    // XF: leaky_relu((y - mean) * scale + shift) on the fetched registers, padding stays zero.  Called BEFORE the barrier
+    // that ends a chunk's MFMA phase, so the VALU work overlaps the matrix pipe instead of sitting between two barriers.
+    auto transform_unit = [&](int n) {           // leaky_relu(z) = max(z, slope * z) for 0 <= slope <= 1
+#ifdef UAPS_XF_DEBUG
+        rxf[n] = f32x2{1.1f, 0.05f};
+#endif
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float z = __builtin_fmaf(rin[n][k], rxf[n].x, rxf[n].y);
+            rin[n][k] = __builtin_fmaxf(z, z * a.xf_slope);
+        }
+    };
+    auto transform_chunk = [&]() {
+        if constexpr (XF) {
+#pragma unroll
+            for (int n = 0; n < Plan::NT; ++n) transform_unit(n);
+        }
     };
     auto store_chunk = [&]() {
 #pragma unroll
@@ -218,6 +255,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
 
     const int nchunks = a.CinP / CK;
     load_chunk(0);
+    transform_chunk();
     store_chunk();
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -244,6 +282,14 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][m], bf[s & 1][n], acc[m][n], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, MW + NW, 0);   // next step's DS reads first ...
             __builtin_amdgcn_sched_group_barrier(0x008, MW * NW, 0);   // ... then this step's MFMAs
+            if constexpr (XF) {      // the next chunk's units are normalised one per k-step in the second half of the
+                                     // MFMA phase (the loads were issued NSTEP/2 steps ago): VALU work in the matrix pipe's shadow
+                constexpr int S0 = NSTEP * UAPS_XF_S0 / 4;
+#pragma unroll
+                for (int n = 0; n < Plan::NT; ++n)
+                    if (s == S0 + n * (NSTEP - S0) / Plan::NT) transform_unit(n);   // unconditional (stale registers when
+                                                                                     // there is no next chunk): straight-line code
+            }
         }
         __syncthreads();
         if (more) store_chunk();
@@ -300,6 +346,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a
     }
 }
 
+template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL = 1>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(ConvFwdArgs a) {
+    conv_fwd_body<KS, TH, TW, BN, CK, VEC, DIL, false>(a);
+}
+// the same with BatchNorm(train) + LeakyReLU of the (single) input applied while staging
+template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL = 1>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_bn_kernel(ConvFwdArgs a) {
+    conv_fwd_body<KS, TH, TW, BN, CK, VEC, DIL, true>(a);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Weight gradient.  dw[co][ci][tap] = sum_{b,y,x} dout[b][co][y][x] * in[b][ci][y+ky-PAD][x+kx-PAD].
 // A workgroup owns a (16*WCO x 16*WCI) channel block and every `nsplit`-th pixel tile.  Its 4 waves
@@ -319,7 +375,13 @@ struct ConvWrwArgs {
     int B, Cin, Cout, H, W;
     int CoutS, CinS;
     int tiles_x, tiles_y, ncob, ncib, nsplit;
+    // conv_wrw_bn_kernel only: `in` is the raw conv output y in front of BatchNorm(train) + LeakyReLU; the activation
+    // is recomputed while staging (see ConvFwdArgs::xf)
+    const float2* xf;
+    float xf_slope;
+    int xf_Bg;
 };
+constexpr int kWrwMaxGroups = 8;     // statistics groups a conv_wrw_bn_kernel keeps coefficients for (norm_act.hip kMaxGroups)
 
 template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1> struct WrwCfg {
     using G = TileGeom<KS, TH, TW, DIL>;
@@ -334,8 +396,8 @@ template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1> struct
     static constexpr int LDS_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
 };
 
-template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a) {
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL, bool XF>
+__device__ __forceinline__ void conv_wrw_body(const ConvWrwArgs& a) {
     using Cfg = WrwCfg<KS, TH, TW, WCO, WCI, VEC, DIL>;
     using G = typename Cfg::G;
     using GD = typename Cfg::GD;
@@ -347,9 +409,13 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
     using PlanD = StagePlan<GD, 16, VEC, PSD>;
     using PlanI = StagePlan<G, 16, VEC, PSI>;
 
-    __shared__ __attribute__((aligned(16))) float smem[Cfg::LDS_FLOATS];
+    constexpr int LDSF = (Cfg::LDS_FLOATS + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) float smem[LDSF + (XF ? (kWrwMaxGroups * BCI + 1) * 2 : 0)];
     float* sD = smem;
     float* sI = smem + BCO * PSD;
+    // XF: [group][BCI] (scale, shift) of this block's input channels, then one (0, 0) entry that padding units read
+    f32x2* sXf = reinterpret_cast<f32x2*>(smem + LDSF);
+    constexpr int XF_ZERO = kWrwMaxGroups * BCI;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -380,9 +446,23 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
     float rd[WCO][PlanD::NT][VEC];
     float ri[WCI][PlanI::NT][VEC];
 
+    int gs_loaded = 0;                       // statistics group of the tile held in ri (XF)
+    if constexpr (XF) {
+        const int G = a.B / a.xf_Bg;
+        for (int i = tid; i < G * BCI; i += kConvThreads) {
+            const int g = i / BCI, ch = ci0 + i % BCI;
+            f32x2 v = f32x2{0.f, 0.f};               // channels past Cin stay zero
+            if (ch < a.Cin) { const float2 t = a.xf[(size_t)g * a.Cin + ch]; v = f32x2{t.x, t.y}; }
+            sXf[i] = v;
+        }
+        if (tid == 0) sXf[XF_ZERO] = f32x2{0.f, 0.f};
+        __syncthreads();
+    }
+
     auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
         const int y0 = (tt / a.tiles_x) * TH, x0 = (tt % a.tiles_x) * TW;
+        if constexpr (XF) gs_loaded = b / a.xf_Bg;
         pd.place(y0, x0, a.H, a.W);
         pi.place(y0, x0, a.H, a.W);
 #pragma unroll
@@ -410,6 +490,30 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
 #pragma unroll
             for (int n = 0; n < PlanD::NT; ++n)
                 if (pd.loff[n] >= 0) lds_store<VEC, false>(&sD[g * 16 * PSD + pd.loff[n]], rd[g][n]);
+    };
+    // XF: leaky_relu((y - mean) * scale + shift) on the fetched registers, padding stays zero; called before the barrier
+    // that ends a tile's MFMA phase so that the VALU work overlaps the matrix pipe
+    auto transform_unit = [&](int g, int n) {    // leaky_relu(z) = max(z, slope * z) for 0 <= slope <= 1
+#ifdef UAPS_XF_DEBUG
+        const f32x2 cf = f32x2{1.1f, 0.05f};
+#else
+        const f32x2 cf = sXf[pi.goff[n] == kOob ? XF_ZERO : gs_loaded * BCI + g * 16 + (pi.pos[n] >> 20)];
+#endif
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float z = __builtin_fmaf(ri[g][n][k], cf.x, cf.y);
+            ri[g][n][k] = __builtin_fmaxf(z, z * a.xf_slope);
+        }
+    };
+    auto transform_tile = [&]() {
+        if constexpr (XF) {
+#pragma unroll
+            for (int g = 0; g < WCI; ++g)
+#pragma unroll
+                for (int n = 0; n < PlanI::NT; ++n) transform_unit(g, n);
+        }
+    };
+    auto store_tile_in = [&]() {
 #pragma unroll
         for (int g = 0; g < WCI; ++g)
 #pragma unroll
@@ -422,7 +526,9 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
 
     if (t_begin < t_end) {
         load_tile(t_begin);
+        transform_tile();
         store_tile();
+        store_tile_in();
     }
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
@@ -448,9 +554,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
                 acc[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1], bf[s & 1][tap], acc[tap], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);   // next step's DS reads first ...
             __builtin_amdgcn_sched_group_barrier(0x008, TAPS, 0);       // ... then this step's MFMAs
+            if constexpr (XF) {      // the next tile's input units are normalised a few per k-step in the second half of
+                                     // the MFMA phase: VALU work in the matrix pipe's shadow
+                constexpr int S0 = NSTEP * UAPS_XF_S0 / 4, U = WCI * PlanI::NT;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (s == S0 + u * (NSTEP - S0) / U) transform_unit(u / PlanI::NT, u % PlanI::NT);   // also when no tile follows
+            }
         }
         __syncthreads();
-        if (more) store_tile();
+        if (more) { store_tile(); store_tile_in(); }
         __syncthreads();
     }
 
@@ -495,6 +608,16 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = accb[r];
     }
+}
+
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_kernel(ConvWrwArgs a) {
+    conv_wrw_body<KS, TH, TW, WCO, WCI, VEC, DIL, false>(a);
+}
+// the same with BatchNorm(train) + LeakyReLU of the input recomputed while staging
+template <int KS, int TH, int TW, int WCO, int WCI, int VEC, int DIL = 1>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_wrw_bn_kernel(ConvWrwArgs a) {
+    conv_wrw_body<KS, TH, TW, WCO, WCI, VEC, DIL, true>(a);
 }
 
 // dw[co][ci][tap] = sum_s slab[s][tap][co][ci]; db[co] = sum_s bslab[s][co].  A block owns EL consecutive

@@ -40,6 +40,15 @@ template <int KS, int TH, int TW, int WCO, int WCI, int DIL = 1>
 int launch_wrw(const ConvWrwArgs& a, bool vec, hipStream_t s) {
     const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;      // multiple of 8 for the XCD swizzle
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.xf) {                  // BatchNorm + LeakyReLU of the input recomputed while staging: 16-byte form, no dilation
+        if constexpr (DIL == 1) {
+            if (!vec) return UAPS_ERANGE;
+            hipLaunchKernelGGL((conv_wrw_bn_kernel<KS, TH, TW, WCO, WCI, 4, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+            return (int)hipGetLastError();
+        } else {
+            return UAPS_ERANGE;
+        }
+    }
     if (vec) hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     else hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
@@ -68,8 +77,11 @@ extern "C" int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, in
 
 // Step 1: per-split partial gradients into the workspace (the MFMA kernel).
 static int wrw_partial_impl(const float* dy, const float* x, const float* x2, int Csplit, int want_bias, int B, int Cin, int Cout,
-                            int H, int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+                            int H, int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream,
+                            const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
     if (!dy || !x || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (xf && (x2 || groups < 1 || groups > kWrwMaxGroups || B % groups || (uintptr_t)xf % 8)) return UAPS_EINVAL;
+    if (xf && !(xf_slope >= 0.f && xf_slope <= 1.f)) return UAPS_ERANGE;      // leaky_relu is evaluated as max(z, slope * z)
     if (!x2) Csplit = Cin;
     if (Csplit > Cin || (Csplit < Cin && (Csplit % 16 || Csplit == 0))) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
@@ -83,6 +95,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
     a.bslab = want_bias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
+    a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!x2 || (uintptr_t)x2 % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
     return ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
@@ -91,6 +104,16 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
 extern "C" int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias, int B, int Cin, int Cout, int H, int W,
                                             int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
     return wrw_partial_impl(dy, x, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+}
+
+// Weight gradient of a convolution whose input is leaky_relu(batch_norm_train(y)) of a previous conv's raw output y
+// (ConvBlock, UAPS_unet.py:38-41): the activation is recomputed while staging from xf [groups][Cin] float2
+// (scale, shift) as uaps_bn_finalize_train wrote it.  W % 4 == 0, 16-byte aligned tensors.
+extern "C" int uaps_conv_bwd_weight_partial_bn(const float* dy, const float* y, const void* xf, float slope, int groups,
+                                               int want_bias, int B, int Cin, int Cout, int H, int W, int ks, int cfg, void* ws,
+                                               size_t ws_bytes, uaps_stream_t stream) {
+    if (!xf) return UAPS_EINVAL;
+    return wrw_partial_impl(dy, y, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream, xf, slope, groups);
 }
 
 // Weight gradient of a convolution whose input is the never-materialised concatenation of x1 [B,C1,H,W] and

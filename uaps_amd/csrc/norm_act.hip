@@ -77,7 +77,8 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_fwd(const float2* __rest
                                                             const float* __restrict__ beta, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                             float momentum, float eps, float* __restrict__ save_mean,
-                                                            float* __restrict__ save_invstd, float* __restrict__ coef, int C) {
+                                                            float* __restrict__ save_invstd, float* __restrict__ coef, int C,
+                                                            float2* __restrict__ xf = nullptr) {
     __shared__ double red[2][kThreads / 64];
     const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int G = B / Bg, nparts = Bg * nch;      // nparts reaches a few thousand when the partials come per conv tile
@@ -100,8 +101,14 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_fwd(const float2* __rest
             const float invstd = (float)(1.0 / sqrt(var + (double)eps));
             save_mean[g * C + c] = (float)mean;
             save_invstd[g * C + c] = invstd;
-            coef[(g * 4 + 0) * C + c] = gamma[c] * invstd;       // scale
-            coef[(g * 4 + 1) * C + c] = beta[c];                 // shift applied after (y - mean) * scale
+            if (coef) {
+                coef[(g * 4 + 0) * C + c] = gamma[c] * invstd;   // scale
+                coef[(g * 4 + 1) * C + c] = beta[c];             // shift applied after (y - mean) * scale
+            }
+            if (xf) {                                            // for the convs that apply it as fma(y, scale, shift)
+                const float sc = gamma[c] * invstd;
+                xf[g * C + c] = make_float2(sc, beta[c] - (float)mean * sc);
+            }
             if (running_mean) {
                 const double bias = conv_bias ? (double)conv_bias[c] : 0.0;
                 const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
@@ -381,6 +388,21 @@ extern "C" int uaps_bn_act_fwd_train_partials(const void* partials, int parts_pe
     return bn_fwd_train_impl((const float2*)partials, parts_per_image, y, conv_bias, gamma, beta, running_mean, running_var,
                              num_batches_tracked, momentum, eps, slope, drop_p, seed, offset, B, C, H, W, groups, out, save_mean,
                              save_invstd, ws, ws_bytes, stream);
+}
+
+// Statistics finalize only (no apply pass): per group and channel the batch mean / inverse std from the conv
+// epilogue's partials, the running-statistics update, and xf [groups][C] float2 = (scale, shift) = (gamma*invstd, beta - mean*scale),
+// the coefficients uaps_conv_fwd_bn / uaps_conv_bwd_weight_partial_bn apply while staging their input.
+extern "C" int uaps_bn_finalize_train(const void* partials, int parts_per_image, const float* conv_bias, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      float momentum, float eps, int B, int C, int H, int W, int groups, float* save_mean,
+                                      float* save_invstd, void* xf, uaps_stream_t stream) {
+    if (!partials || parts_per_image <= 0 || !gamma || !beta || !save_mean || !save_invstd || !xf || ((uintptr_t)xf % 8)) return UAPS_EINVAL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads), 0, (hipStream_t)stream, (const float2*)partials, B, B / groups,
+                       parts_per_image, (double)H * W, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked,
+                       momentum, eps, save_mean, save_invstd, (float*)nullptr, C, (float2*)xf);
+    return (int)hipGetLastError();
 }
 
 extern "C" int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* gamma, const float* beta,

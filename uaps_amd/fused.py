@@ -158,6 +158,109 @@ def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2
     return _BnActEval.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, slope)
 
 
+class _BnActConv(torch.autograd.Function):
+    """y (raw output of a conv, no bias) -> conv2(leaky_relu(batch_norm_train(y + conv_bias))): the activated tensor
+    between the two convs (UAPS_unet.py:38-41) is never written.  The statistics come from the first conv's epilogue
+    partials; the second conv normalises + activates while it stages its input (forward and weight gradient), and the
+    backward is conv2's input gradient followed by the usual BatchNorm backward on (that gradient, y)."""
+
+    @staticmethod
+    def forward(ctx, y, stats_partials, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, groups,
+                weight, bias, want_stats):
+        from . import conv as _conv
+        _lib.require_device(y, "bn_act_conv")
+        ctx.set_materialize_grads(False)
+        y = y.contiguous()
+        B, Cc, H, W = y.shape
+        Cout, Cin, ks, _ = weight.shape
+        if Cin != Cc:
+            raise ValueError(f"bn_act_conv: weight expects {Cin} input channels, y has {Cc}")
+        if B % groups:
+            raise ValueError(f"bn_act_conv: batch {B} is not divisible into {groups} statistics groups")
+        if stats_partials.shape[:2] != (Cc, B) or stats_partials.shape[-1] != 2 or not stats_partials.is_contiguous():
+            raise ValueError("bn_act_conv: stats must be the [C, B, parts, 2] tensor conv2d_with_stats returned for this y")
+        dev = y.device
+        L = _lib.lib()
+        stats = torch.empty((2, groups * Cc), dtype=torch.float32, device=dev)
+        xf = torch.empty((groups, Cc, 2), dtype=torch.float32, device=dev)
+        wf, wb = _conv.pack_weights(weight, need_bwd=True)
+        z = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        zstats = None
+        if want_stats:
+            zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            rc = L.uaps_bn_finalize_train(stats_partials.data_ptr(), int(stats_partials.shape[2]),
+                                          conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(),
+                                          beta.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
+                                          running_var.data_ptr() if running_var is not None else None,
+                                          nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), B, Cc, H, W,
+                                          groups, stats[0].data_ptr(), stats[1].data_ptr(), xf.data_ptr(), st)
+            _lib.check(rc, "uaps_bn_finalize_train")
+            with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, 0):
+                rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None, z.data_ptr(),
+                                        zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, 0, st)
+            _lib.check(rc, "uaps_conv_fwd_bn")
+        ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
+        ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks)
+        if want_stats:
+            ctx.mark_non_differentiable(zstats)
+            return z, zstats
+        return z
+
+    @staticmethod
+    def backward(ctx, dz, *_unused):
+        from . import conv as _conv
+        if dz is None:
+            return (None,) * 15
+        y, gamma, beta, stats, xf, wb = ctx.saved_tensors
+        slope, groups, has_cbias, has_bias, Cout, ks = ctx.meta
+        dz = dz.contiguous()
+        B, Cc, H, W = y.shape
+        dev = y.device
+        L = _lib.lib()
+        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks)
+        n = C.c_size_t()
+        _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
+        cws = _conv._workspace(dev, n.value)
+        dw = torch.empty((Cout, Cc, ks, ks), dtype=torch.float32, device=dev)
+        want_db = has_bias and ctx.needs_input_grad[13]
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
+        dy = torch.empty_like(y)
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        ws = _bn_ws(dev, B, Cc, H, W)
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, 0):
+                rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
+                                                       Cout, H, W, ks, 0, cws.data_ptr(), cws.numel(), st)
+            _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
+            rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
+                                               ks, 0, st)
+            _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+            rc = L.uaps_bn_act_bwd_grouped(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                                           stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
+                                           dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "uaps_bn_act_bwd_grouped")
+        dcb = torch.zeros_like(gamma) if has_cbias else None
+        return dy, None, dcb, dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None
+
+
+def can_fuse_bn_into_conv(y: torch.Tensor, weight: torch.Tensor) -> bool:
+    """The staging-time BatchNorm of bn_act_conv needs 16-byte rows and the 8-channel-chunk kernels."""
+    return y.is_cuda and y.shape[3] % 4 == 0 and y.shape[1] > 4 and weight.shape[2] in (1, 3) and STAT_GROUPS <= 8
+
+
+def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, slope: float,
+                weight: torch.Tensor, bias: Optional[torch.Tensor], want_stats: bool = False):
+    """conv2d(leaky_relu(bn_train(y + conv_bias)), weight, bias) (+ the epilogue statistics of the result) where `y`,
+    `stats` come from conv2d_with_stats: train-mode only, no dropout between the two (decoder ConvBlocks)."""
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return _BnActConv.apply(y, stats, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                            mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats)
+
+
 class _UpCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, skip, low):

@@ -31,6 +31,7 @@ _EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B swit
 _VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 _FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
 _FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
+_FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
 
 
 class ConvBlock(nn.Module):
@@ -44,8 +45,10 @@ class ConvBlock(nn.Module):
                   nn.LeakyReLU(LEAKY_SLOPE)]
         self.conv_conv = nn.Sequential(*layers)      # indices 0,1,4,5 carry the parameters
 
-    def forward(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x2: second half of a channel concatenation [x, x2] that is not materialised (GPU only)."""
+    def forward(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None, lazy: bool = False):
+        """x2: second half of a channel concatenation [x, x2] that is not materialised (GPU only).
+        lazy: the caller feeds the result to exactly one convolution and can apply the last BatchNorm + LeakyReLU there
+        (fused.bn_act_conv); then a PendingBnAct may come back instead of a tensor (train mode on the GPU only)."""
         if not x.is_cuda:
             return self.conv_conv(x if x2 is None else torch.cat([x, x2], dim=1))   # plain torch modules (CPU tests)
         # GPU: MFMA implicit-GEMM convs (csrc/conv_kernels.hpp) without bias (train-mode BN cancels it; the
@@ -53,12 +56,34 @@ class ConvBlock(nn.Module):
         c0, b0, _, d0, c1, b1, _ = self.conv_conv
         if self.training and _EPILOGUE_STATS:      # batch statistics: their first pass rides in the conv epilogue
             y, st = conv.conv2d_with_stats(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None, True)
+            if d0.p == 0.0 and _FUSED_BN_CONV and fused.can_fuse_bn_into_conv(y, c1.weight):
+                # no dropout in between (decoder blocks): the second conv normalises + activates while staging its input
+                y, st = fused.bn_act_conv(y, st, c0.bias, b0, LEAKY_SLOPE, c1.weight, None, want_stats=True)
+                if lazy and y.shape[1] > 4:
+                    return PendingBnAct(y, st, c1.bias, b1)
+                return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
             a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, True, st)
             y, st = conv.conv2d_with_stats(a, c1.weight, None)
             return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
         y = conv.conv2d(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None)
         a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
         return fused.bn_act(conv.conv2d(a, c1.weight, None), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
+
+
+class PendingBnAct:
+    """Raw output of a ConvBlock's second conv with its epilogue statistics: leaky_relu(bn(y + bias)) still to be applied,
+    by the one convolution that consumes it (`conv`) or explicitly (`materialize`)."""
+
+    def __init__(self, y, stats, conv_bias, bn):
+        self.y, self.stats, self.conv_bias, self.bn = y, stats, conv_bias, bn
+
+    def conv(self, weight, bias):
+        if fused.can_fuse_bn_into_conv(self.y, weight):
+            return fused.bn_act_conv(self.y, self.stats, self.conv_bias, self.bn, LEAKY_SLOPE, weight, bias)
+        return conv.conv2d(self.materialize(), weight, bias)
+
+    def materialize(self):
+        return fused.bn_act(self.y, self.conv_bias, self.bn, LEAKY_SLOPE, 0.0, True, self.stats)
 
 
 class DownBlock(nn.Module):
@@ -84,13 +109,18 @@ class UpBlock(nn.Module):
         self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
         self.conv = ConvBlock(in_channels2 * 2, out_channels, dropout_p)
 
-    def forward(self, coarse, skip):
-        if not coarse.is_cuda:
+    def forward(self, coarse, skip, lazy: bool = False):
+        """coarse: tensor or PendingBnAct (the previous UpBlock's output before its last BatchNorm + LeakyReLU);
+        lazy: the caller accepts a PendingBnAct (see ConvBlock.forward)."""
+        if isinstance(coarse, PendingBnAct):
+            low = coarse.conv(self.conv1x1.weight, self.conv1x1.bias)
+        elif not coarse.is_cuda:
             return self.conv(torch.cat([skip, self.up(self.conv1x1(coarse))], dim=1))
-        low = conv.conv2d(coarse, self.conv1x1.weight, self.conv1x1.bias)
+        else:
+            low = conv.conv2d(coarse, self.conv1x1.weight, self.conv1x1.bias)
         if _VIRTUAL_CAT and skip.shape[1] % 16 == 0:
-            return self.conv(skip, fused.upsample2x(low))     # the conv kernels read [skip | up] as two tensors
-        return self.conv(fused.up_cat(skip, low))     # bilinear x2 written straight into the concat buffer
+            return self.conv(skip, fused.upsample2x(low), lazy=lazy)     # the conv kernels read [skip | up] as two tensors
+        return self.conv(fused.up_cat(skip, low), lazy=lazy)     # bilinear x2 written straight into the concat buffer
 
 
 class Encoder(nn.Module):
@@ -130,10 +160,13 @@ class Decoder(nn.Module):
         self.out_conv = nn.Conv2d(f[0], class_num, kernel_size=3, padding=1)
 
     def forward(self, feats: Sequence[torch.Tensor]) -> torch.Tensor:
-        x = self.up1(feats[4], feats[3])
-        x = self.up2(x, feats[2])
-        x = self.up3(x, feats[1])
-        x = self.up4(x, feats[0])
+        lazy = _FUSED_BN_CONV       # each UpBlock output feeds exactly one conv: the next conv1x1 or out_conv
+        x = self.up1(feats[4], feats[3], lazy)
+        x = self.up2(x, feats[2], lazy)
+        x = self.up3(x, feats[1], lazy)
+        x = self.up4(x, feats[0], lazy)
+        if isinstance(x, PendingBnAct):
+            return x.conv(self.out_conv.weight, self.out_conv.bias)
         if not x.is_cuda:
             return self.out_conv(x)
         return conv.conv2d(x, self.out_conv.weight, self.out_conv.bias)
