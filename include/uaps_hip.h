@@ -192,6 +192,13 @@ int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const float* gamm
                             const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
                             uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
                             float* dbeta, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+/* The same, also writing the gradient of the conv bias in front of the BatchNorm (identically zero: the bias cancels
+ * in train-mode normalisation) into dconv_bias [C], which saves the host a fill launch per layer. */
+int uaps_bn_act_bwd_grouped_bias(const float* dout, const float* y, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float slope, float drop_p,
+                                 uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* dy,
+                                 float* dgamma, float* dbeta, float* dconv_bias, void* workspace, size_t workspace_bytes,
+                                 uaps_stream_t stream);
 /* eval(): running statistics, no dropout.  save_mean receives running_mean - conv_bias (for the backward). */
 int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, const float* gamma, const float* beta,
                          const float* running_mean, const float* running_var, float eps, float slope, int B,

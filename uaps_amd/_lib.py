@@ -43,6 +43,7 @@ SIGNATURES = {
     "uaps_bn_act_fwd_train_grouped": (C.c_int, [_PTR] * 7 + [C.c_float] * 4 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_fwd_train_partials": (C.c_int, [_PTR, C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_bwd_grouped": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
+    "uaps_bn_act_bwd_grouped_bias": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_uint64, C.c_uint64] + [C.c_int] * 5 + [_PTR] * 5 + [C.c_size_t, _PTR]),
     "uaps_bn_act_fwd_eval": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_int] * 4 + [_PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_bwd": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_uint64, C.c_uint64] + [C.c_int] * 4 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_bn_act_bwd_eval": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_int] * 4 + [_PTR, _PTR, C.c_size_t, _PTR]),

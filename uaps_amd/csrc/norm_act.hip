@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sums_kernel(const float* __re
 __global__ __launch_bounds__(64) void bn_finalize_bwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
                                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      float* __restrict__ coef, int C) {
+                                                      float* __restrict__ coef, int C, float* __restrict__ dconv_bias) {
     const int c = blockIdx.x, lane = threadIdx.x;
     const int G = B / Bg, nparts = Bg * nch;
     const double M = (double)Bg * HW;
@@ -247,7 +247,10 @@ __global__ __launch_bounds__(64) void bn_finalize_bwd(const float2* __restrict__
         }
         t1 += s1; t2 += s2;
     }
-    if (lane == 0) { dbeta[c] = (float)t1; dgamma[c] = (float)t2; }
+    if (lane == 0) {
+        dbeta[c] = (float)t1; dgamma[c] = (float)t2;
+        if (dconv_bias) dconv_bias[c] = 0.f;     // a bias in front of a train-mode BatchNorm cancels: d(bias) = sum of dy = 0
+    }
 }
 
 // dy = gamma * invstd * (dpre - mean(dpre) - xhat * mean(dpre * xhat))
@@ -433,10 +436,10 @@ extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, cons
     return (int)hipGetLastError();
 }
 
-extern "C" int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const float* gamma, const float* beta,
+static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, const float* beta,
                                        const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
                                        uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
-                                       float* dbeta, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+                                       float* dbeta, float* dconv_bias, void* ws, size_t ws_bytes, uaps_stream_t stream) {
     int rc = check(dout, dy, B, C, H, W);
     if (rc) return rc;
     if (!y || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
@@ -453,12 +456,32 @@ extern "C" int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const 
 #define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, w.coef, slope, drop_p, dscale, seed, offset, Bg)
     if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
     else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
-    hipLaunchKernelGGL(bn_finalize_bwd, dim3(C), dim3(64), 0, s, w.partials, B, Bg, nch, (double)HW, gamma, save_invstd, dgamma, dbeta, w.coef, C);
+    hipLaunchKernelGGL(bn_finalize_bwd, dim3(C), dim3(64), 0, s, w.partials, B, Bg, nch, (double)HW, gamma, save_invstd, dgamma, dbeta, w.coef, C, dconv_bias);
     if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }
     else { if (drop_p > 0.f) UAPS_DX(false, true); else UAPS_DX(false, false); }
 #undef UAPS_SUMS
 #undef UAPS_DX
     return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const float* gamma, const float* beta,
+                                       const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                                       uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
+                                       float* dbeta, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    return bn_bwd_impl(dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
+                       dbeta, nullptr, ws, ws_bytes, stream);
+}
+
+// The same, also writing the (identically zero) gradient of the bias of the convolution in front of the BatchNorm
+// into dconv_bias [C], so that the host needs no separate fill launch for it.
+extern "C" int uaps_bn_act_bwd_grouped_bias(const float* dout, const float* y, const float* gamma, const float* beta,
+                                            const float* save_mean, const float* save_invstd, float slope, float drop_p,
+                                            uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* dy,
+                                            float* dgamma, float* dbeta, float* dconv_bias, void* ws, size_t ws_bytes,
+                                            uaps_stream_t stream) {
+    if (!dconv_bias) return UAPS_EINVAL;
+    return bn_bwd_impl(dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
+                       dbeta, dconv_bias, ws, ws_bytes, stream);
 }
 
 extern "C" int uaps_bn_act_bwd(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,

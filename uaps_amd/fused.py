@@ -94,17 +94,17 @@ class _BnActTrain(torch.autograd.Function):
         B, Cc, H, W = y.shape
         dev = y.device
         dy = torch.empty_like(y)
-        dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        # rows: dgamma, dbeta, d(conv bias); the conv bias feeds a train-mode BatchNorm, so its gradient (the sum of dy
+        # over a channel) is exactly zero -- written by the same finalize kernel instead of a fill launch
+        dgb = torch.empty((3, Cc), dtype=torch.float32, device=dev)
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
-            rc = _lib.lib().uaps_bn_act_bwd_grouped(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                                    stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B,
-                                                    Cc, H, W, groups, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
-        _lib.check(rc, "uaps_bn_act_bwd_grouped")
-        # the conv bias feeds a train-mode BatchNorm: its gradient is exactly zero (sum of dy over a channel)
-        dbias = torch.zeros_like(gamma) if has_bias else None
-        return dy, dbias, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
+            rc = _lib.lib().uaps_bn_act_bwd_grouped_bias(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                         stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B,
+                                                         Cc, H, W, groups, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                                         dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
+        return dy, (dgb[2] if has_bias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 
 class _BnActEval(torch.autograd.Function):
@@ -228,7 +228,7 @@ class _BnActConv(torch.autograd.Function):
         want_db = has_bias and ctx.needs_input_grad[13]
         db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
         dy = torch.empty_like(y)
-        dgb = torch.empty((2, Cc), dtype=torch.float32, device=dev)
+        dgb = torch.empty((3, Cc), dtype=torch.float32, device=dev)     # dgamma, dbeta, d(conv bias) = 0
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
@@ -239,12 +239,11 @@ class _BnActConv(torch.autograd.Function):
             rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
                                                ks, 0, st)
             _lib.check(rc, "uaps_conv_bwd_weight_reduce")
-            rc = L.uaps_bn_act_bwd_grouped(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
-                                           stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
-                                           dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), st)
-            _lib.check(rc, "uaps_bn_act_bwd_grouped")
-        dcb = torch.zeros_like(gamma) if has_cbias else None
-        return dy, None, dcb, dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None
+            rc = L.uaps_bn_act_bwd_grouped_bias(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                                                stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
+                                                dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), st)
+            _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
+        return dy, None, (dgb[2] if has_cbias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None
 
 
 def can_fuse_bn_into_conv(y: torch.Tensor, weight: torch.Tensor) -> bool:
