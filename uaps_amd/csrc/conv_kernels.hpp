@@ -158,6 +158,9 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
+#ifdef UAPS_CLK_DEBUG      // diagnostic build: shader clock (clock64) against the 100 MHz wall clock over one workgroup's life
+    const long long dbg_c0 = clock64(), dbg_w0 = wall_clock64();
+#endif
 
     int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     if (bid >= a.B * a.tiles_x * a.tiles_y * a.nblk) return;
@@ -344,6 +347,14 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
             a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
         }
     }
+#ifdef UAPS_CLK_DEBUG
+    if (tid == 0 && gridDim.x == 512 && (blockIdx.x % 37 == 0 || blockIdx.x == 511)) {
+        const long long dc = clock64() - dbg_c0, w1 = wall_clock64();
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+        printf("wg %3d xcc %u se %u cu %2u: start %lld end %lld (x10ns) len %lld  %.0f MHz\n", (int)blockIdx.x, xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15,
+               dbg_w0 % 1000000, w1 % 1000000, w1 - dbg_w0, (double)dc / (double)(w1 - dbg_w0) * 100.0);
+    }
+#endif
 }
 
 template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL = 1>
