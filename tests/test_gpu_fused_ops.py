@@ -116,6 +116,25 @@ def test_up_cat_vs_torch(B, Cs, Cl, h, w):
     torch.testing.assert_close(low.grad, lr.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,Cl,h,w", [(2, 4, 5, 6), (32, 16, 128, 128), (3, 5, 1, 1), (2, 8, 2, 3), (4, 128, 16, 16), (2, 3, 24, 40),
+                                      (1, 2, 9, 34), (2, 2, 33, 18), (1, 1, 1, 2)])
+def test_upsample2x_vs_torch_and_gather_kernel(B, Cl, h, w):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (UAPS_unet.py:74-75) as the LDS-tiled kernel
+    (W % 4 == 0) or the gather kernel, against torch and -- bit for bit -- against the up_cat kernel's interpolation."""
+    from uaps_amd import fused
+    torch.manual_seed(B * 100 + h)
+    low = torch.randn(B, Cl, h, w, device=DEV, requires_grad=True)
+    out = fused.upsample2x(low)
+    lr = low.detach().clone().requires_grad_(True)
+    ref = F.interpolate(lr, scale_factor=2, mode="bilinear", align_corners=True)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6)
+    skip = torch.zeros(B, 1, 2 * h, 2 * w, device=DEV)
+    assert torch.equal(out.detach(), fused.up_cat(skip, low.detach())[:, 1:])
+    g = torch.randn_like(out)
+    out.backward(g); ref.backward(g)
+    torch.testing.assert_close(low.grad, lr.grad, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("in_chns,C,n_aux,H,W", [(3, 4, 3, 32, 32), (1, 7, 3, 48, 80), (1, 2, 5, 64, 64)],
                          ids=["neu", "dagm_7class_partial_tiles", "k5_2class"])
 def test_forward_pair_equals_two_forwards(in_chns, C, n_aux, H, W):
