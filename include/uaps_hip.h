@@ -320,6 +320,10 @@ int uaps_softmax_mse_bwd(const float* a, const float* b, const float* grad_map, 
                          uaps_stream_t stream);
 int uaps_softmax_kl_bwd(const float* a, const float* b, const float* gscalar, int B, int C, int H, int W, float* da,
                         uaps_stream_t stream);
+/* d(sum(grad_map * kl_map)) / da and / db (either may be NULL): the per-pixel KL map differentiated w.r.t. both heads,
+ * as UCC weights its pseudo-supervision (UCC/UCC_train.py:213-217, 231-232; neither softmax is detached there). */
+int uaps_softmax_klmap_bwd(const float* a, const float* b, const float* grad_map, int B, int C, int H, int W, float* da,
+                           float* db, uaps_stream_t stream);
 /* entropy_map(p) = -sum_c p log(p + 1e-6) as [B,1,H,W] and/or its mean (entropy_minmization), losses_1.py:139-149. */
 int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map, float* ent_mean, void* workspace,
                      size_t workspace_bytes, uaps_stream_t stream);

@@ -194,3 +194,34 @@ def test_full_step_g6():
     for k in st.sd:
         ref = g["after." + k]
         np.testing.assert_allclose(st.sd[k].detach().numpy(), ref, rtol=0, atol=2.5e-3 if k in st.param_keys else 1e-5)
+
+
+@pytest.mark.parametrize("C", [4, 2])
+def test_sibling_method_terms_g8(C):
+    """CCT / UCC / UAMT unsupervised terms: the oracle's restatements against the fixture composed from the
+    imported reference callees in the training scripts' order (tools/make_golden.py::g8), values and gradients."""
+    g = _load(os.path.join(GOLDEN, "g8_sibling.npz"))
+    t = lambda k: torch.tensor(g[k]).requires_grad_(True)
+    # CCT
+    main, auxs = t(f"cct{C}_main"), [t(f"cct{C}_aux{i}") for i in (1, 2, 3)]
+    loss = O.cct_consistency(main, auxs)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g[f"cct{C}_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(main.grad.numpy(), g[f"cct{C}_dmain"], rtol=1e-5, atol=1e-9)
+    for i, a in enumerate(auxs, 1):
+        np.testing.assert_allclose(a.grad.numpy(), g[f"cct{C}_daux{i}"], rtol=1e-5, atol=1e-9)
+    # UCC
+    u = {k: t(f"ucc{C}_{k}") for k in ("u1wk", "u2wk", "u1st", "u2st")}
+    r = O.ucc_pseudo_supervision(u["u1wk"], u["u2wk"], u["u1st"], u["u2st"])
+    r["ps_loss"].backward()
+    for k in ("ps_loss", "ps_1_wk", "ps_2_st"):
+        np.testing.assert_allclose(float(r[k]), float(g[f"ucc{C}_{k}"]), rtol=1e-6)
+    np.testing.assert_allclose(r["variance_1"].detach().numpy(), g[f"ucc{C}_variance_1"], rtol=1e-5, atol=1e-7)
+    for k, v in u.items():
+        np.testing.assert_allclose(v.grad.numpy(), g[f"ucc{C}_d{k}"], rtol=1e-4, atol=1e-8)
+    # UAMT
+    student = t(f"uamt{C}_student")
+    loss = O.uamt_consistency(student, torch.tensor(g[f"uamt{C}_ema"]), torch.tensor(g[f"uamt{C}_preds"]), float(g[f"uamt{C}_threshold"]))
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g[f"uamt{C}_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(student.grad.numpy(), g[f"uamt{C}_dstudent"], rtol=1e-5, atol=1e-9)

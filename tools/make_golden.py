@@ -396,6 +396,74 @@ def g7():
     np.savez_compressed(os.path.join(OUT, "g7_resnet.npz"), **out)
 
 
+def g8():
+    """Unsupervised terms of the sibling methods: CCT (CCT/CCT_train.py:195-199), UCC
+    (UCC/UCC_train.py:213-238, the shipped 'WITH UNCERTAINTY' branch) and UAMT (UAMT/UA_MT_train.py:199, 210-214),
+    composed in the order of the training scripts from the imported reference callees (dice_loss, softmax_mse_loss) and
+    the torch modules the scripts instantiate (:67-69 of UCC_train.py); the scripts themselves import cv2 /
+    tensorboardX and cannot be imported here.  Values and the gradients w.r.t. every logit tensor."""
+    out = {}
+    rng = np.random.default_rng(23)
+    kl_distance = nn.KLDivLoss(reduction='none')
+    log_sm = torch.nn.LogSoftmax(dim=1)
+    for C in (4, 2):
+        B, H, W = 2, 12, 10
+
+        def t(grad=True):
+            return torch.tensor((rng.standard_normal((B, C, H, W)) * 2).astype(np.float32), requires_grad=grad)
+
+        # ---- CCT
+        un_outputs, a1, a2, a3 = t(), t(), t(), t()
+        un_outputs_soft = torch.softmax(un_outputs, dim=1)
+        c1 = torch.mean((un_outputs_soft - torch.softmax(a1, dim=1)) ** 2)
+        c2 = torch.mean((un_outputs_soft - torch.softmax(a2, dim=1)) ** 2)
+        c3 = torch.mean((un_outputs_soft - torch.softmax(a3, dim=1)) ** 2)
+        consistency_loss = (c1 + c2 + c3) / 3
+        consistency_loss.backward()
+        for k, v in (("main", un_outputs), ("aux1", a1), ("aux2", a2), ("aux3", a3)):
+            out[f"cct{C}_{k}"] = v.detach().numpy(); out[f"cct{C}_d{k}"] = v.grad.numpy()
+        out[f"cct{C}_loss"] = np.float32(consistency_loss.item())
+
+        # ---- UCC
+        un_outputs1_wk, un_outputs2_wk, un_outputs1_st, un_outputs2_st = t(), t(), t(), t()
+        un_outputs1_wk_soft = torch.softmax(un_outputs1_wk, dim=1)
+        un_outputs2_wk_soft = torch.softmax(un_outputs2_wk, dim=1)
+        un_outputs2_st_soft = torch.softmax(un_outputs2_st, dim=1)
+        variance_1 = torch.sum(kl_distance(log_sm(un_outputs1_wk), un_outputs2_st_soft), dim=1)
+        exp_variance_1 = torch.exp(-variance_1)
+        variance_2 = torch.sum(kl_distance(log_sm(un_outputs1_st), un_outputs2_wk_soft), dim=1)
+        exp_variance_2 = torch.exp(-variance_2)
+        pseudo_1 = torch.argmax(un_outputs2_wk_soft.detach(), dim=1, keepdim=False)
+        pseudo_2 = torch.argmax(un_outputs1_wk_soft.detach(), dim=1, keepdim=False)
+        ps_1_wk = torch.mean(0.5 * (ce_loss(un_outputs1_st, pseudo_1) + R_dice(pseudo_1.unsqueeze(1), un_outputs1_st)) * exp_variance_1) + torch.mean(variance_1)
+        ps_2_st = torch.mean(0.5 * (ce_loss(un_outputs2_st, pseudo_2) + R_dice(pseudo_2.unsqueeze(1), un_outputs2_st)) * exp_variance_2) + torch.mean(variance_2)
+        ps_loss = ps_1_wk + ps_2_st
+        ps_loss.backward()
+        for k, v in (("u1wk", un_outputs1_wk), ("u2wk", un_outputs2_wk), ("u1st", un_outputs1_st), ("u2st", un_outputs2_st)):
+            out[f"ucc{C}_{k}"] = v.detach().numpy(); out[f"ucc{C}_d{k}"] = v.grad.numpy()
+        out[f"ucc{C}_ps_loss"] = np.float32(ps_loss.item()); out[f"ucc{C}_ps_1_wk"] = np.float32(ps_1_wk.item()); out[f"ucc{C}_ps_2_st"] = np.float32(ps_2_st.item())
+        out[f"ucc{C}_variance_1"] = variance_1.detach().numpy(); out[f"ucc{C}_variance_2"] = variance_2.detach().numpy()
+
+        # ---- UAMT (T = 4 stand-in teacher passes; the real script uses 8 noisy passes of the EMA model)
+        un_outputs_1, ema_output = t(), t(False)
+        T = 4
+        preds = torch.softmax(torch.stack([t(False) for _ in range(T)]), dim=2)
+        preds = torch.mean(preds, dim=0)
+        uncertainty = -1.0 * torch.sum(preds * torch.log(preds + 1e-6), dim=1, keepdim=True)
+        consistency_weight = {4: 0.3, 2: 0.0}[C]      # puts the threshold inside the range of the entropies (a mixed mask)
+        consistency_dist = R_l1.softmax_mse_loss(un_outputs_1, ema_output)
+        threshold = (0.75 + 2.5 * consistency_weight) * np.log(2)
+        mask = (uncertainty < threshold).float()
+        uamt_loss = torch.sum(mask * consistency_dist) / (2 * torch.sum(mask) + 1e-16)
+        uamt_loss.backward()
+        out[f"uamt{C}_student"] = un_outputs_1.detach().numpy(); out[f"uamt{C}_ema"] = ema_output.numpy()
+        out[f"uamt{C}_preds"] = preds.numpy(); out[f"uamt{C}_threshold"] = np.float64(threshold)
+        out[f"uamt{C}_mask_frac"] = np.float32(mask.mean().item()); out[f"uamt{C}_loss"] = np.float32(uamt_loss.item())
+        out[f"uamt{C}_dstudent"] = un_outputs_1.grad.numpy()
+        print(f"g8 C={C}: cct {float(consistency_loss):.6f} ucc {float(ps_loss):.6f} uamt {float(uamt_loss):.6f} mask {float(mask.mean()):.3f}")
+    np.savez_compressed(os.path.join(OUT, "g8_sibling.npz"), **out)
+
+
 def main():
     torch.set_num_threads(4)
     g1_case("neu", 4, 2, 4, 16, 16, seed=0)
@@ -414,6 +482,7 @@ def main():
     g5()
     g6()
     g7()
+    g8()
 
 
 if __name__ == "__main__":

@@ -8,6 +8,8 @@ Public surface (mirrors the names the reference's UAPS_train.py imports):
   mIoU, mDice, pixel_accuracy, seg_confusion        (utilities/metrics.py)
   softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization   (utilities/losses_1.py, losses_2.py)
   uncertainty_map                                   (UAPS-Testing.ipynb cell 24)
+  sibling.cct_consistency_loss / ucc_pseudo_supervision / uamt_consistency_loss   (CCT_train.py:195-199,
+                                                    UCC_train.py:213-238, UA_MT_train.py:188-214)
   UAPSTrainer                                       (UAPS_train.py:109-450 step/optimizer/checkpoint)
 """
 from .ramps import sigmoid_rampup, get_current_consistency_weight
@@ -20,6 +22,6 @@ from .res_uaps import ResUAPS, ResNet, resnet50
 from .net_factory import net_factory
 from .consistency import (softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization, uncertainty_map)
 from .trainer import UAPSTrainer
-from . import conv, data, dist, inference, optim
+from . import conv, data, dist, inference, optim, sibling
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -108,6 +108,32 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(const float* __restr
     }
 }
 
+// Gradient of the per-pixel KL map v = sum_c KLDivLoss('none')(log_softmax(a), softmax(b)) w.r.t. BOTH logit tensors
+// (UCC's uncertainty, UCC/UCC_train.py:213-217: neither head is detached).  With p = softmax(a), q = softmax(b) and G the
+// upstream gradient of the map:   da_j = G (p_j - q_j)      db_j = G q_j ((log q_j - log p_j) - v)
+template <int C>
+__global__ __launch_bounds__(kThreads) void pair_klmap_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                  const float* __restrict__ gmap, long HW, long N,
+                                                                  float* __restrict__ da, float* __restrict__ db) {
+    for (long n = (long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long)gridDim.x * kThreads) {
+        const long img = n / HW, hw = n - img * HW, base = img * C * HW + hw;
+        float za[C], zb[C], p[C], lp[C], q[C], lq[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { za[c] = a[base + (long)c * HW]; zb[c] = b[base + (long)c * HW]; }
+        softmax_c<C>(za, p, lp);
+        softmax_c<C>(zb, q, lq);
+        const float g = gmap[n];
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) v += q[c] * (lq[c] - lp[c]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (da) da[base + (long)c * HW] = g * (p[c] - q[c]);
+            if (db) db[base + (long)c * HW] = g * q[c] * ((lq[c] - lp[c]) - v);
+        }
+    }
+}
+
 // ent[b,hw] = -sum_c p log(p + 1e-6)
 template <int C>
 __global__ __launch_bounds__(kThreads) void entropy_kernel(const float* __restrict__ p, long HW, long N, float* __restrict__ ent,
@@ -139,6 +165,11 @@ template <int C> int run_bwd(bool mse, const float* a, const float* b, const flo
                              float* da, int grid, hipStream_t s) {
     if (mse) hipLaunchKernelGGL((pair_bwd_kernel<C, true>), dim3(grid), dim3(kThreads), 0, s, a, b, gmap, gs, scale, HW, N, da);
     else hipLaunchKernelGGL((pair_bwd_kernel<C, false>), dim3(grid), dim3(kThreads), 0, s, a, b, gmap, gs, scale, HW, N, da);
+    return (int)hipGetLastError();
+}
+template <int C> int run_klmap_bwd(const float* a, const float* b, const float* gmap, long HW, long N, float* da, float* db, int grid,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL((pair_klmap_bwd_kernel<C>), dim3(grid), dim3(kThreads), 0, s, a, b, gmap, HW, N, da, db);
     return (int)hipGetLastError();
 }
 template <int C> int run_ent(const float* p, long HW, long N, float* ent, float* partials, int grid, hipStream_t s) {
@@ -198,6 +229,21 @@ extern "C" int uaps_softmax_kl_bwd(const float* a, const float* b, const float* 
     if (C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
     const long HW = (long)H * W, N = (long)B * HW;
     return pair_bwd_dispatch(C, false, a, b, nullptr, gscalar, (float)(1.0 / ((double)N * C)), HW, N, da, grid_for(N), (hipStream_t)stream);
+}
+
+static int klmap_bwd_dispatch(int C, const float* a, const float* b, const float* gmap, long HW, long N, float* da, float* db, int grid,
+                              hipStream_t s) {
+#define CALL(K) run_klmap_bwd<K>(a, b, gmap, HW, N, da, db, grid, s)
+    UAPS_BY_C(C, CALL)
+#undef CALL
+}
+
+extern "C" int uaps_softmax_klmap_bwd(const float* a, const float* b, const float* grad_map, int B, int C, int H, int W, float* da,
+                                      float* db, uaps_stream_t stream) {
+    if (!a || !b || !grad_map || (!da && !db) || B <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    const long HW = (long)H * W, N = (long)B * HW;
+    return klmap_bwd_dispatch(C, a, b, grad_map, HW, N, da, db, grid_for(N), (hipStream_t)stream);
 }
 
 static int ent_dispatch(int C, const float* p, long HW, long N, float* ent, float* partials, int grid, hipStream_t s) {
