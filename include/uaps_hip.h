@@ -334,6 +334,21 @@ int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_strea
 int uaps_relu_bwd(const float* dout, const float* out, float* dx, long n, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input pipeline: the per-sample work of the reference's training loader (utilities/dataloaders.py:60-119: albumentations
+ * Resize(nearest) / flips / RandomBrightnessContrast / Blur / RandomRotate90 / GaussNoise, then ToTensor + Normalize; the
+ * mask follows the geometry and becomes int64) on a decoded uint8 batch in device memory.
+ *   images_hwc [B][Hs][Ws][3] uint8 (RGB, as cv2.cvtColor leaves it), masks [B][Hs][Ws] uint8 or NULL
+ *   params_i   [B][8] int32 : hflip, vflip, rot_k (np.rot90 count), blur_k (0 / 3 / 5 / 7), noise_on, reserved x3
+ *   params_f   [B][4] float : alpha (contrast factor), beta (brightness shift / 255), sigma (noise std, grey levels), reserved
+ *   noise      [B][3][Ho][Wo] float already scaled by sigma, or NULL: drawn in the kernel (Philox, Box-Muller) from `seed`
+ *   out        [B][3][Ho][Wo] float normalised with mean3_host / std3_host; out_mask [B][Ho][Wo] int64 (NULL with masks)
+ * rot_k odd needs Ho == Wo.  Parity unpinned (cv2 / albumentations are not in the build image): see csrc/augment.hip.
+ * ------------------------------------------------------------------------------------------- */
+int uaps_augment_batch(const uint8_t* images_hwc, const uint8_t* masks, const int* params_i, const float* params_f,
+                       const float* noise, uint64_t seed, int B, int Hs, int Ws, int Ho, int Wo, const float* mean3_host,
+                       const float* std3_host, float* out, int64_t* out_mask, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimizer: torch.optim.Adam(model.parameters(), lr) of UAPS_train.py:112, stepped at :292 -- one multi-tensor
  * launch per 48 tensors instead of PyTorch's per-chunk foreach kernels.  Host arrays of n device pointers / sizes;
  * `step` is the 1-based step count (bias corrections 1 - beta^step are computed on the host in double).
