@@ -217,9 +217,6 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
     // XF: leaky_relu((y - mean) * scale + shift) on the fetched registers, padding stays zero.  Called BEFORE the barrier
     // that ends a chunk's MFMA phase, so the VALU work overlaps the matrix pipe instead of sitting between two barriers.
     auto transform_unit = [&](int n) {           // leaky_relu(z) = max(z, slope * z) for 0 <= slope <= 1
-#ifdef UAPS_XF_DEBUG
-        rxf[n] = f32x2{1.1f, 0.05f};
-#endif
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const float z = __builtin_fmaf(rin[n][k], rxf[n].x, rxf[n].y);
@@ -505,11 +502,7 @@ __device__ __forceinline__ void conv_wrw_body(const ConvWrwArgs& a) {
     // XF: leaky_relu((y - mean) * scale + shift) on the fetched registers, padding stays zero; called before the barrier
     // that ends a tile's MFMA phase so that the VALU work overlaps the matrix pipe
     auto transform_unit = [&](int g, int n) {    // leaky_relu(z) = max(z, slope * z) for 0 <= slope <= 1
-#ifdef UAPS_XF_DEBUG
-        const f32x2 cf = f32x2{1.1f, 0.05f};
-#else
         const f32x2 cf = sXf[pi.goff[n] == kOob ? XF_ZERO : gs_loaded * BCI + g * 16 + (pi.pos[n] >> 20)];
-#endif
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const float z = __builtin_fmaf(ri[g][n][k], cf.x, cf.y);
