@@ -173,7 +173,8 @@ def main():
                     "launches_per_step": v["calls"] / args.steps,
                     "note": "kernel instantiation with the largest share of the step (found in the last warm-up step); algorithmic "
                             "flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time; "
-                            "traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes)"}
+                            "traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); peak is the "
+                            "nominal 2.4 GHz figure -- under this kernel the shader clock measured 2.03-2.14 GHz (DESIGN.md section 5)"}
         else:
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
