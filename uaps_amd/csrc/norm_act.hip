@@ -72,48 +72,58 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restr
 // ---- forward finalize: one wave per channel, looping over the G = B / Bg statistics groups in order -------
 // (a group = the images of one reference forward call: the labelled and the unlabelled batch are normalised
 // separately, UAPS_train.py:177,185, and update the running statistics one after the other)
-__global__ __launch_bounds__(kThreads) void bn_finalize_fwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
-                                                            const float* __restrict__ conv_bias, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                            float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                            float momentum, float eps, float* __restrict__ save_mean,
-                                                            float* __restrict__ save_invstd, float* __restrict__ coef, int C,
-                                                            float2* __restrict__ xf = nullptr) {
-    __shared__ double red[2][kThreads / 64];
-    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// blockDim = kThreads * GP: GP statistics groups are reduced side by side (one 256-thread slice each), then thread 0
+// finishes them in group order (the running statistics are updated group after group, like the reference's successive
+// forward calls); groups beyond GP take further rounds.
+__global__ __launch_bounds__(1024) void bn_finalize_fwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
+                                                        const float* __restrict__ conv_bias, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                        float momentum, float eps, float* __restrict__ save_mean,
+                                                        float* __restrict__ save_invstd, float* __restrict__ coef, int C,
+                                                        float2* __restrict__ xf = nullptr) {
+    __shared__ double red[4][2][kThreads / 64];
+    const int c = blockIdx.x, GP = blockDim.x / kThreads;
+    const int slice = threadIdx.x / kThreads, t = threadIdx.x % kThreads, lane = t & 63, wave = t >> 6;
     const int G = B / Bg, nparts = Bg * nch;      // nparts reaches a few thousand when the partials come per conv tile
     const double M = (double)Bg * HW;
-    for (int g = 0; g < G; ++g) {
-        const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
+    for (int g0 = 0; g0 < G; g0 += GP) {
+        const int g = g0 + slice;
         double s = 0.0, ss = 0.0;
-        for (int i = threadIdx.x; i < nparts; i += kThreads) { const float2 v = pp[i]; s += v.x; ss += v.y; }
+        if (g < G) {
+            const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
+            for (int i = t; i < nparts; i += kThreads) { const float2 v = pp[i]; s += v.x; ss += v.y; }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
-        __syncthreads();                           // red[] of the previous group has been consumed
-        if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+        __syncthreads();                           // red[] of the previous round has been consumed
+        if (lane == 0) { red[slice][0][wave] = s; red[slice][1][wave] = ss; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-            ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-            const double mean = s / M;
-            double var = ss / M - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            save_mean[g * C + c] = (float)mean;
-            save_invstd[g * C + c] = invstd;
-            if (coef) {
-                coef[(g * 4 + 0) * C + c] = gamma[c] * invstd;   // scale
-                coef[(g * 4 + 1) * C + c] = beta[c];             // shift applied after (y - mean) * scale
-            }
-            if (xf) {                                            // for the convs that apply it as fma(y, scale, shift)
-                const float sc = gamma[c] * invstd;
-                xf[g * C + c] = make_float2(sc, beta[c] - (float)mean * sc);
-            }
-            if (running_mean) {
-                const double bias = conv_bias ? (double)conv_bias[c] : 0.0;
-                const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
-                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + bias));
-                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            for (int q = 0; q < GP && g0 + q < G; ++q) {
+                const int gg = g0 + q;
+                s = (red[q][0][0] + red[q][0][1]) + (red[q][0][2] + red[q][0][3]);
+                ss = (red[q][1][0] + red[q][1][1]) + (red[q][1][2] + red[q][1][3]);
+                const double mean = s / M;
+                double var = ss / M - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+                save_mean[gg * C + c] = (float)mean;
+                save_invstd[gg * C + c] = invstd;
+                if (coef) {
+                    coef[(gg * 4 + 0) * C + c] = gamma[c] * invstd;   // scale
+                    coef[(gg * 4 + 1) * C + c] = beta[c];             // shift applied after (y - mean) * scale
+                }
+                if (xf) {                                             // for the convs that apply it as fma(y, scale, shift)
+                    const float sc = gamma[c] * invstd;
+                    xf[gg * C + c] = make_float2(sc, beta[c] - (float)mean * sc);
+                }
+                if (running_mean) {
+                    const double bias = conv_bias ? (double)conv_bias[c] : 0.0;
+                    const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+                    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (mean + bias));
+                    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+                }
             }
         }
     }
@@ -359,7 +369,7 @@ static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_i
         if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
         else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
     }
-    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads), 0, s, given_partials ? given_partials : w.partials, B, Bg,
+    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads * (groups < 4 ? groups : 4)), 0, s, given_partials ? given_partials : w.partials, B, Bg,
                        given_partials ? given_parts_per_image : nch, (double)HW, conv_bias, gamma, beta, running_mean,
                        running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
     const float dscale = 1.f / (1.f - drop_p);
@@ -402,7 +412,7 @@ extern "C" int uaps_bn_finalize_train(const void* partials, int parts_per_image,
                                       float* save_invstd, void* xf, uaps_stream_t stream) {
     if (!partials || parts_per_image <= 0 || !gamma || !beta || !save_mean || !save_invstd || !xf || ((uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads), 0, (hipStream_t)stream, (const float2*)partials, B, B / groups,
+    hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads * (groups < 4 ? groups : 4)), 0, (hipStream_t)stream, (const float2*)partials, B, B / groups,
                        parts_per_image, (double)H * W, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked,
                        momentum, eps, save_mean, save_invstd, (float*)nullptr, C, (float2*)xf);
     return (int)hipGetLastError();
