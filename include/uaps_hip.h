@@ -32,7 +32,7 @@ typedef void* uaps_stream_t; /* hipStream_t */
 
 #define UAPS_OK 0
 #define UAPS_EINVAL (-1)     /* null pointer, non-positive dimension                       */
-#define UAPS_ERANGE (-2)     /* D or C outside the supported range                         */
+#define UAPS_ERANGE (-2)     /* D, C, kernel size, dilation or alignment outside what is built */
 #define UAPS_EWORKSPACE (-3) /* workspace smaller than uaps_loss_workspace_bytes() reports */
 
 int uaps_abi_version(void);

@@ -1,0 +1,69 @@
+"""C-ABI argument checking and the host-only planning entry points of libuaps_hip.so (include/uaps_hip.h), callable
+without a GPU: every call below returns before any HIP API is touched (validation failures) or never touches one
+(size / plan queries)."""
+import ctypes as C
+
+import pytest
+
+from uaps_amd import _lib
+
+OK, EINVAL, ERANGE = 0, -1, -2
+
+
+@pytest.fixture(scope="module")
+def L():
+    return _lib.lib()
+
+
+def test_error_codes_match_the_header(L):
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "uaps_hip.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(UAPS_E?\w+)\s+\(?(-?\d+)\)?", hdr)}
+    assert vals["UAPS_OK"] == OK and vals["UAPS_EINVAL"] == EINVAL and vals["UAPS_ERANGE"] == ERANGE
+    assert b"range" in L.uaps_error_string(ERANGE) or len(L.uaps_error_string(ERANGE)) > 0
+
+
+def test_null_and_empty_arguments_are_refused(L):
+    z = None
+    assert L.uaps_conv_fwd(z, z, z, z, 1, 8, 8, 8, 8, 3, 0, z) == EINVAL
+    assert L.uaps_conv_bwd_data(z, z, z, 1, 8, 8, 8, 8, 3, 0, z) == EINVAL
+    assert L.uaps_conv_fwd_bn(z, z, 0.01, 1, z, z, z, z, 1, 8, 8, 8, 8, 3, 0, z) == EINVAL
+    assert L.uaps_conv_bwd_weight_partial_bn(z, z, z, 0.01, 1, 0, 1, 8, 8, 8, 8, 3, 0, z, 0, z) == EINVAL
+    assert L.uaps_bn_finalize_train(z, 4, z, z, z, z, z, z, 0.1, 1e-5, 2, 8, 8, 8, 1, z, z, z, z) == EINVAL
+    assert L.uaps_softmax_klmap_bwd(z, z, z, 1, 4, 8, 8, z, z, z) == EINVAL
+    assert L.uaps_augment_batch(z, z, z, z, z, 0, 1, 8, 8, 8, 8, (C.c_float * 3)(), (C.c_float * 3)(), z, z, z) == EINVAL
+    assert L.uaps_up_cat_fwd(z, z, z, 1, 0, 4, 8, 8, z) == EINVAL
+    assert L.uaps_sum_tensors(z, 2, z, 16, z) == EINVAL
+
+
+def test_pack_sizes_and_workspace_queries(L):
+    nf, nb = C.c_size_t(), C.c_size_t()
+    assert L.uaps_conv_pack_floats(16, 3, 3, C.byref(nf), C.byref(nb)) == OK
+    assert nf.value == 9 * 4 * 16 and nb.value == 9 * 16 * 16          # K padded to 4 (Cin <= 4) / 16, N padded to 16
+    assert L.uaps_conv_pack_floats(64, 128, 1, C.byref(nf), C.byref(nb)) == OK
+    assert nf.value == 128 * 64 and nb.value == 64 * 128
+    assert L.uaps_conv_pack_floats(0, 3, 3, C.byref(nf), C.byref(nb)) == EINVAL
+    assert L.uaps_conv_pack_floats(16, 3, 5, C.byref(nf), C.byref(nb)) == EINVAL          # only 1x1 and 3x3 exist
+    n = C.c_size_t()
+    assert L.uaps_conv_wrw_workspace_bytes(32, 16, 16, 256, 256, 3, 0, C.byref(n)) == OK
+    assert n.value == 512 * (9 * 16 * 16 + 16) * 4                                       # 512 pixel splits of one 16x16 channel block
+    assert L.uaps_conv_wrw_workspace_bytes(32, 16, 16, 256, 256, 5, 0, C.byref(n)) == EINVAL
+    assert L.uaps_bn_workspace_bytes(0, 16, 8, 8, C.byref(n)) == EINVAL
+
+
+def test_kernel_plan_names_and_statistics_tiles(L):
+    buf = C.create_string_buffer(96)
+    assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
+    assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # the bench's dominant instantiation
+    assert L.uaps_conv_fwd_variant(32, 3, 16, 256, 256, 3, 0, buf, 96) == OK
+    assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 16, 4, 4, 1>"                # 3 input channels: 4-channel chunks
+    assert L.uaps_conv_fwd_variant(2, 16, 16, 16, 16, 3, 0, buf, 96) == OK
+    assert "16, 16" in buf.value.decode()                                                # narrow maps: 16x16 pixel tiles
+    assert L.uaps_conv_fwd_variant(32, 64, 64, 64, 64, 3, 2 << 24, buf, 96) == OK
+    assert buf.value.decode().endswith(", 2>")                                           # dilation 2 (ResNet stages)
+    assert L.uaps_conv_fwd_variant(32, 64, 64, 64, 64, 3, 3 << 24, buf, 96) == ERANGE     # dilation 3 does not exist
+    assert L.uaps_conv_wrw_variant(32, 64, 64, 64, 64, 3, 0, buf, 96) == OK
+    assert buf.value.decode() == "conv_wrw_kernel<3, 4, 32, 2, 2, 4, 1>"
+    parts = C.c_int()
+    assert L.uaps_conv_fwd_stats_parts(32, 16, 16, 256, 256, 3, 0, C.byref(parts)) == OK and parts.value == 32 * 8
+    assert L.uaps_conv_fwd_stats_parts(4, 128, 128, 16, 16, 3, 0, C.byref(parts)) == OK and parts.value == 1

@@ -8,7 +8,7 @@ extern "C" const char* uaps_error_string(int code) {
     switch (code) {
         case UAPS_OK: return "ok";
         case UAPS_EINVAL: return "invalid argument (null pointer or non-positive dimension)";
-        case UAPS_ERANGE: return "number of heads or classes outside the supported range (D 1..8, C 2..8)";
+        case UAPS_ERANGE: return "argument outside the supported range (heads 1..8, classes 2..8; conv kernels 1x1 / 3x3, dilation 1 / 2 / 4; the fused BatchNorm forms need W % 4 == 0 and 16-byte aligned tensors)";
         case UAPS_EWORKSPACE: return "workspace too small";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
