@@ -237,44 +237,45 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sums_kernel(const float* __re
     if (threadIdx.x == 0) partials[((long)c * gridDim.y / C + b) * nchunks + chunk] = r;
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_bwd(const float2* __restrict__ partials, int B, int Bg, int nch, double HW,
-                                                      const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                      float* __restrict__ coef, int C, float* __restrict__ dconv_bias) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int G = B / Bg, nparts = Bg * nch;
-    const double M = (double)Bg * HW;
-    double t1 = 0.0, t2 = 0.0;
-    for (int g = 0; g < G; ++g) {
-        const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
-        double s1 = 0.0, s2 = 0.0;
-        for (int i = lane; i < nparts; i += 64) { const float2 v = pp[i]; s1 += v.x; s2 += v.y; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        if (lane == 0) {
-            coef[(g * 4 + 2) * C + c] = (float)(s1 / M);
-            coef[(g * 4 + 3) * C + c] = (float)(s2 / M);
-        }
-        t1 += s1; t2 += s2;
-    }
-    if (lane == 0) {
-        dbeta[c] = (float)t1; dgamma[c] = (float)t2;
-        if (dconv_bias) dconv_bias[c] = 0.f;     // a bias in front of a train-mode BatchNorm cancels: d(bias) = sum of dy = 0
-    }
-}
-
 // dy = gamma * invstd * (dpre - mean(dpre) - xhat * mean(dpre * xhat))
 template <bool VEC, bool DROP>
 __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                              float* __restrict__ dy, int C, long HW, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, const float* __restrict__ coef,
+                                                             const float* __restrict__ beta, const float2* __restrict__ partials,
+                                                             int nch_p, int B, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dconv_bias,
                                                              float slope, float drop_p, float drop_scale, uint64_t seed,
                                                              uint64_t offset, int Bg) {
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C, g = b / Bg;
-    const float* cf = coef + (long)g * 4 * C;
-    const float mu = mean[g * C + c], is = invstd[g * C + c], sc = gamma[c] * is, sh = beta[c], k2 = cf[2 * C + c], k3 = cf[3 * C + c];
+    // The reduction's finalize runs here, not as a launch of its own: the first wave sums this channel's per-block
+    // partials of the block's statistics group (a few hundred float2, L2-resident) in a fixed order -- every block of
+    // the group computes the same two means bit for bit -- and the block of image 0, chunk 0 also adds up all groups
+    // for dgamma / dbeta (and writes the zero gradient of the conv bias in front of the BatchNorm).
+    __shared__ float sk[2];
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, nparts = Bg * nch_p;
+        const double M = (double)Bg * (double)HW;
+        const bool owner = b == 0 && chunk == 0;
+        const int G = B / Bg;
+        double t1 = 0.0, t2 = 0.0;
+        for (int gg = owner ? 0 : g; gg < (owner ? G : g + 1); ++gg) {
+            const float2* pp = partials + ((long)c * B + (long)gg * Bg) * nch_p;
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = lane; i < nparts; i += 64) { const float2 v = pp[i]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (gg == g && lane == 0) { sk[0] = (float)(s1 / M); sk[1] = (float)(s2 / M); }
+            t1 += s1; t2 += s2;
+        }
+        if (owner && lane == 0) {
+            dbeta[c] = (float)t1; dgamma[c] = (float)t2;
+            if (dconv_bias) dconv_bias[c] = 0.f;     // a bias in front of a train-mode BatchNorm cancels: d(bias) = sum of dy = 0
+        }
+    }
+    __syncthreads();
+    const float mu = mean[g * C + c], is = invstd[g * C + c], sc = gamma[c] * is, sh = beta[c], k2 = sk[0], k3 = sk[1];
     const long pbase = (long)plane * HW;
     const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
     if (VEC) {
@@ -463,10 +464,9 @@ static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, co
     const bool vec = (HW % 4 == 0) && al16(y) && al16(dout) && al16(dy);
     const float dscale = 1.f / (1.f - drop_p);
 #define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials, Bg)
-#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, w.coef, slope, drop_p, dscale, seed, offset, Bg)
+#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, (const float2*)w.partials, nch, B, dgamma, dbeta, dconv_bias, slope, drop_p, dscale, seed, offset, Bg)
     if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
     else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
-    hipLaunchKernelGGL(bn_finalize_bwd, dim3(C), dim3(64), 0, s, w.partials, B, Bg, nch, (double)HW, gamma, save_invstd, dgamma, dbeta, w.coef, C, dconv_bias);
     if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }
     else { if (drop_p > 0.f) UAPS_DX(false, true); else UAPS_DX(false, false); }
 #undef UAPS_SUMS
