@@ -148,6 +148,18 @@ int uaps_fanin_perturbed(const float* const* g_host, const int* mode_host, const
                          const uint64_t* offsets_host, int n, int groups, uint64_t seed, float range, float p, int B,
                          int C, int H, int W, float* out, uaps_stream_t stream);
 
+/* The forward counterpart: the n perturbed copies of a feature map (UAPS_unet.py:227-231) written by one pass over f
+ * instead of one kernel (and one read of f) per perturbation, with the stand-alone kernels' arithmetic and Philox
+ * indexing.  mode 1 FeatureNoise, 2 Dropout, 3 FeatureDropout: run uaps_feat_dropout_stats(f, ...) first (channel-mean
+ * attention map + per-image maximum into the uaps_feat_dropout_workspace_bytes(B, ...) workspace) and pass that workspace
+ * and the threshold factors u [groups]; keep_host[k] receives the uint8 [B,H,W] mask of a mode-3 output.
+ * Host arrays of n <= 8 entries, offsets [n][groups], groups <= 4, H*W % 4 == 0, 16-byte aligned tensors. */
+int uaps_feat_dropout_stats(const float* x, int B, int C, int H, int W, void* workspace, size_t workspace_bytes,
+                            uaps_stream_t stream);
+int uaps_fanout_perturbed(const float* f, float* const* out_host, const int* mode_host, uint8_t* const* keep_host,
+                          const uint64_t* offsets_host, const float* u_host, const void* fdrop_workspace, int n, int groups,
+                          uint64_t seed, float range, float p, int B, int C, int H, int W, uaps_stream_t stream);
+
 /* nn.MaxPool2d(2) of DownBlock (UAPS_unet.py:55-58): out [B,C,H/2,W/2] plus the arg-max position (dy*2+dx) per output
  * as uint8 (first maximum wins, NaN propagates).  Needs H even, W % 8 == 0, 16-byte aligned x/out.  Its backward is
  * mode 4 of uaps_fanin_perturbed (no zero fill, no scatter, no separate accumulation). */

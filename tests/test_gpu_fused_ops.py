@@ -329,3 +329,32 @@ def copy_double(m):
 def copy_to(m, dev):
     import copy
     return copy.deepcopy(m).to(dev)
+
+
+@pytest.mark.parametrize("B,C,H,W,groups,kinds", [(4, 16, 32, 32, 2, ("noise", "dropout", "feature_dropout")),
+                                                  (2, 8, 16, 24, 1, ("noise", "dropout", "feature_dropout")),
+                                                  (6, 5, 8, 8, 3, ("feature_dropout", "noise")),
+                                                  (4, 32, 64, 64, 2, ("noise", "dropout", "feature_dropout", "noise", "dropout"))])
+def test_fused_fan_out_forward_equals_the_per_perturbation_kernels(B, C, H, W, groups, kinds):
+    """uaps_fanout_perturbed (one pass over f for all perturbed copies, FeatureDropout statistics for the whole batch
+    at once) must give bit for bit what the FeatureNoise / Dropout / FeatureDropout kernels give from the same RNG
+    state: outputs, the keep mask used by the backward, and the pooled map."""
+    from uaps_amd import perturb
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    f = torch.randn(B, C, H, W, device=dev)
+    res = []
+    for fused_on in (True, False):
+        perturb._FUSED_FANOUT = fused_on
+        try:
+            perturb.manual_seed(21); np.random.seed(21)
+            x = f.clone().requires_grad_(True)
+            outs = perturb.perturbed_fan_out(x, list(kinds), groups, 0.3, with_pool=True)
+            g = [torch.ones_like(o) * (i + 1) for i, o in enumerate(outs)]
+            torch.autograd.backward(outs, g)
+            res.append(([o.detach() for o in outs], x.grad.clone()))
+        finally:
+            perturb._FUSED_FANOUT = True
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[1][1])          # the backward re-applies the same masks / noise

@@ -70,6 +70,8 @@ SIGNATURES = {
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
     "uaps_sum_tensors": (C.c_int, [_PTR, C.c_int, _PTR, C.c_long, _PTR]),
     "uaps_pair_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
+    "uaps_feat_dropout_stats": (C.c_int, [_PTR] + [C.c_int] * 4 + [_PTR, C.c_size_t, _PTR]),
+    "uaps_fanout_perturbed": (C.c_int, [_PTR] * 7 + [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_float] + [C.c_int] * 4 + [_PTR]),
     "uaps_augment_batch": (C.c_int, [_PTR] * 5 + [C.c_uint64] + [C.c_int] * 5 + [C.POINTER(C.c_float), C.POINTER(C.c_float), _PTR, _PTR, _PTR]),
     "uaps_softmax_klmap_bwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 4 + [_PTR] * 3),
     "uaps_softmax_pair_fwd": (C.c_int, [_PTR, _PTR] + [C.c_int] * 5 + [_PTR, _PTR, _PTR, _PTR, C.c_size_t, _PTR]),

@@ -310,6 +310,56 @@ __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, 
     }
 }
 
+// ---- forward counterpart: f -> P_1(f), ..., P_n(f) in ONE pass over f (each separate kernel re-read it) --------------
+// The same per-mode arithmetic and Philox indexing as the stand-alone kernels above (and as fanin_perturbed_kernel
+// re-applies in the backward): mode 1 FeatureNoise, 2 Dropout, 3 FeatureDropout with the keep mask derived here from
+// the attention map and the per-image maximum (fdrop_attention ran before), written once per pixel for the backward.
+struct FanOutArgs {
+    float4* out[kFanMax];
+    uchar4* keep[kFanMax];          // mode 3: keep mask output [B, H*W]
+    uint64_t off[kFanMax][kFanGroups];
+    int mode[kFanMax];
+    float u[kFanGroups];            // mode 3: threshold factor per statistics group
+    const float4* att;              // mode 3: [B, H*W] channel means
+    const uint32_t* maxkey;         // mode 3: [B] order-preserving keys of the per-image maximum
+    uint64_t seed;
+    float range, p, scale;
+    int n, B, Bg;
+    long chw4, hw4;
+};
+__global__ __launch_bounds__(kThreads) void fanout_perturbed_kernel(const float4* __restrict__ f, FanOutArgs a) {
+    const long total = (long)a.B * a.chw4;
+    for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+        const long b = e / a.chw4, ce = e - b * a.chw4;
+        const int grp = (int)(b / a.Bg);
+        const float4 x = f[e];
+#pragma unroll
+        for (int k = 0; k < kFanMax; ++k) {
+            if (k >= a.n) break;
+            float4 v = x;
+            if (a.mode[k] == 1) {
+                const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, a.seed);
+                const float n0 = (2.f * u01(r.x) - 1.f) * a.range, n1 = (2.f * u01(r.y) - 1.f) * a.range;
+                const float n2 = (2.f * u01(r.z) - 1.f) * a.range, n3 = (2.f * u01(r.w) - 1.f) * a.range;
+                v.x = add_rn(mul_rn(v.x, n0), v.x); v.y = add_rn(mul_rn(v.y, n1), v.y);
+                v.z = add_rn(mul_rn(v.z, n2), v.z); v.w = add_rn(mul_rn(v.w, n3), v.w);
+            } else if (a.mode[k] == 2) {
+                const U4 r = philox4x32_10(a.off[k][0] + (uint64_t)e, a.seed);
+                v.x = u01(r.x) >= a.p ? v.x * a.scale : 0.f; v.y = u01(r.y) >= a.p ? v.y * a.scale : 0.f;
+                v.z = u01(r.z) >= a.p ? v.z * a.scale : 0.f; v.w = u01(r.w) >= a.p ? v.w * a.scale : 0.f;
+            } else if (a.mode[k] == 3) {
+                const long pix = ce % a.hw4;
+                const float thr = mul_rn(fkey_inv(a.maxkey[b]), a.u[grp]);
+                const float4 t = a.att[b * a.hw4 + pix];
+                const bool k0 = t.x < thr, k1 = t.y < thr, k2 = t.z < thr, k3 = t.w < thr;
+                if (ce < a.hw4) a.keep[k][b * a.hw4 + pix] = make_uchar4(k0, k1, k2, k3);      // channel 0 writes the mask
+                v.x = k0 ? v.x : 0.f; v.y = k1 ? v.y : 0.f; v.z = k2 ? v.z : 0.f; v.w = k3 ? v.w : 0.f;
+            }
+            a.out[k][e] = v;
+        }
+    }
+}
+
 // ---- confusion matrix ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void confusion_kernel(const float* __restrict__ z, const int64_t* __restrict__ labels, int C,
                                                              long HW, long N, unsigned long long* __restrict__ counts) {
@@ -411,6 +461,57 @@ extern "C" int uaps_feat_dropout_bwd(const float* dy, const uint8_t* keep, float
     int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
     if (vec) hipLaunchKernelGGL(fdrop_bwd<4>, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
     else hipLaunchKernelGGL(fdrop_bwd<1>, dim3(gx, B), dim3(kThreads), 0, (hipStream_t)stream, dy, keep, dx, C, HW);
+    return (int)hipGetLastError();
+}
+
+// FeatureDropout statistics for a whole batch: att[b,hw] = mean_c x[b,c,hw] and the per-image maximum key, into the
+// workspace of uaps_feat_dropout_workspace_bytes(B, ...) (what uaps_feat_dropout_fwd computes before it applies the mask).
+extern "C" int uaps_feat_dropout_stats(const float* x, int B, int C, int H, int W, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    if (!x || !ws || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    size_t need; uaps_feat_dropout_workspace_bytes(B, C, H, W, &need);
+    if (ws_bytes < need) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    uint32_t* maxkey = (uint32_t*)ws;
+    float* att = (float*)((char*)ws + (((size_t)B * 4 + 255) / 256) * 256);
+    hipError_t e = hipMemsetAsync(maxkey, 0, (size_t)B * 4, s);
+    if (e != hipSuccess) return (int)e;
+    const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
+    if (vec) hipLaunchKernelGGL(fdrop_attention<4>, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
+    else hipLaunchKernelGGL(fdrop_attention<1>, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
+    return (int)hipGetLastError();
+}
+
+// f [B,C,H,W] -> n perturbed copies in one pass (see fanout_perturbed_kernel): host arrays of n <= 8 entries: out (device
+// pointers), mode (1 FeatureNoise, 2 Dropout, 3 FeatureDropout), keep (device uint8 [B,H,W] outputs for mode 3, else
+// NULL), offsets [n][groups] (mode 1: one Philox offset per statistics group; mode 2: offsets[k*groups]); u [groups]: the
+// FeatureDropout threshold factors; fdrop_ws: the workspace uaps_feat_dropout_stats filled for this f (NULL without
+// mode 3).  Needs H*W % 4 == 0, 16-byte aligned tensors, groups <= 4 (else UAPS_EINVAL: use the separate kernels).
+extern "C" int uaps_fanout_perturbed(const float* f, float* const* out, const int* mode, uint8_t* const* keep,
+                                     const uint64_t* offsets, const float* u, const void* fdrop_ws, int n, int groups, uint64_t seed,
+                                     float range, float p, int B, int C, int H, int W, uaps_stream_t stream) {
+    if (!f || !out || !mode || n < 1 || n > kFanMax || groups < 1 || groups > kFanGroups || B <= 0 || C <= 0 || H <= 0 || W <= 0 ||
+        B % groups)
+        return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (HW % 4 || !al16(f)) return UAPS_EINVAL;
+    FanOutArgs a{};
+    for (int k = 0; k < n; ++k) {
+        if (!out[k] || !al16(out[k]) || mode[k] < 1 || mode[k] > 3) return UAPS_EINVAL;
+        if (mode[k] == 3 && (!keep || !keep[k] || (reinterpret_cast<uintptr_t>(keep[k]) & 3) || !u || !fdrop_ws)) return UAPS_EINVAL;
+        if (mode[k] != 3 && !offsets) return UAPS_EINVAL;
+        a.out[k] = (float4*)out[k]; a.mode[k] = mode[k]; a.keep[k] = keep ? (uchar4*)keep[k] : nullptr;
+        for (int q = 0; q < groups; ++q) a.off[k][q] = offsets ? offsets[(size_t)k * groups + q] : 0;
+    }
+    for (int q = 0; q < groups; ++q) a.u[q] = u ? u[q] : 0.f;
+    if (fdrop_ws) {
+        a.maxkey = (const uint32_t*)fdrop_ws;
+        a.att = (const float4*)((const char*)fdrop_ws + (((size_t)B * 4 + 255) / 256) * 256);
+    }
+    a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
+    a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4;
+    hipLaunchKernelGGL(fanout_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)f, a);
     return (int)hipGetLastError();
 }
 

@@ -11,6 +11,7 @@ forms take recorded draws, for parity tests against the reference.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -291,6 +292,7 @@ def FeatureDropout(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
 # ---- all decoders' views of one encoder feature map, with a fused backward ---------------------------------
 
 _KIND_MODE = {"noise": 1, "dropout": 2, "feature_dropout": 3}
+_FUSED_FANOUT = os.environ.get("UAPS_FUSED_FANOUT", "1") != "0"      # A/B switch for tools/ab_bench.sh
 
 
 class _PerturbFan(torch.autograd.Function):
@@ -310,6 +312,51 @@ class _PerturbFan(torch.autograd.Function):
         L = _lib.lib()
         outs, offsets, keeps = [f.view_as(f)], [[0] * groups], [None]
         seed = _RngState.seed
+        n = len(kinds)
+        if _FUSED_FANOUT and n >= 1 and (H * W) % 4 == 0 and groups <= 4 and n <= 8 and f.data_ptr() % 16 == 0 \
+                and all(k in _KIND_MODE for k in kinds):
+            # one pass over f for all the copies (same draws, same order of RNG reservations as the per-kernel path below)
+            ys = [torch.empty_like(f) for _ in kinds]
+            us = [0.0] * groups
+            kp = [None] * n
+            ws = None
+            for i, kind in enumerate(kinds):
+                if kind == "noise":
+                    offsets.append([_RngState.reserve(chw)[1] for _ in range(groups)]); keeps.append(None)
+                elif kind == "dropout":
+                    offsets.append([_RngState.reserve(f.numel())[1]] * groups); keeps.append(None)
+                else:
+                    if ws is not None:
+                        raise ValueError("one FeatureDropout per fan-out")      # a second one would need its own thresholds
+                    need = C.c_size_t()
+                    _lib.check(L.uaps_feat_dropout_workspace_bytes(B, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
+                    key = (dev.index, _lib.current_stream(dev))
+                    ws = _fd_ws.get(key)
+                    if ws is None or ws.numel() < need.value:
+                        ws = _fd_ws[key] = torch.empty(need.value, dtype=torch.uint8, device=dev)
+                    us = [float(np.random.uniform(0.7, 0.9)) for _ in range(groups)]
+                    kp[i] = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+                    offsets.append([0] * groups); keeps.append(kp[i])
+            with _lib.device_guard(dev):
+                st = _lib.current_stream(dev)
+                if ws is not None:
+                    _lib.check(L.uaps_feat_dropout_stats(f.data_ptr(), B, Cc, H, W, ws.data_ptr(), ws.numel(), st), "uaps_feat_dropout_stats")
+                rc = L.uaps_fanout_perturbed(f.data_ptr(), (C.c_void_p * n)(*[y.data_ptr() for y in ys]),
+                                             (C.c_int * n)(*[_KIND_MODE[k] for k in kinds]),
+                                             (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in kp]),
+                                             (C.c_uint64 * (n * groups))(*[o for offs in offsets[1:] for o in offs]),
+                                             (C.c_float * groups)(*us), ws.data_ptr() if ws is not None else None, n, groups, seed,
+                                             float(noise_range), float(drop_p), B, Cc, H, W, st)
+                _lib.check(rc, "uaps_fanout_perturbed")
+                outs.extend(ys)
+                if with_pool:
+                    pooled = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=dev)
+                    idx = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.uint8, device=dev)
+                    _lib.check(L.uaps_maxpool2x2_fwd(f.data_ptr(), B, Cc, H, W, pooled.data_ptr(), idx.data_ptr(), st), "uaps_maxpool2x2_fwd")
+                    outs.append(pooled); offsets.append([0] * groups); keeps.append(idx)
+            ctx.meta = (tuple(kinds), groups, seed, float(noise_range), float(drop_p), offsets, (B, Cc, H, W), bool(with_pool))
+            ctx.keeps = keeps
+            return tuple(outs)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
             for kind in kinds:
