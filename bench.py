@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--aux", type=int, default=3)
     ap.add_argument("--net", default="unet_uaps", help="unet_uaps (BASELINE.json configs[1], the reported metric) or resnet50_uaps (configs[4] shape study)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decoder-streams", action="store_true",
+                    help="run the auxiliary decoders on their own HIP streams (UAPS_DECODER_STREAMS=1): higher images/s, but launches of "
+                         "different decoders overlap, so the per-launch roofline figures no longer describe one kernel")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,6 +74,9 @@ def main():
     import uaps_amd
     from uaps_amd import losses
 
+    if args.decoder_streams:
+        import uaps_amd.unet as _unet
+        _unet._DECODER_STREAMS = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,6 +181,9 @@ def main():
                             "flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time; "
                             "traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); peak is the "
                             "nominal 2.4 GHz figure -- under this kernel the shader clock measured 2.03-2.14 GHz (DESIGN.md section 5)"}
+            if args.decoder_streams or os.environ.get("UAPS_DECODER_STREAMS", "0") != "0":
+                roof["note"] += ("; DECODER STREAMS ON: launches of the four decoders overlap on the GPU, a launch's event-to-event time "
+                                 "includes other kernels' share of the CUs, so achieved / frac are NOT standalone-kernel figures in this run")
         else:
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

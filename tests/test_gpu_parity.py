@@ -413,3 +413,33 @@ def test_training_step_runs_at_other_baseline_configs(in_chns, C, n_aux, H, W, b
     assert losses_seen[-1] < losses_seen[0], losses_seen
     assert len(grads) == len(list(model.parameters())) and all(grads.values())
     assert tr.last["w"].shape == (n_aux + 1,)
+
+
+def test_decoder_streams_give_bit_identical_steps():
+    """UAPS_DECODER_STREAMS (one HIP stream per auxiliary decoder, forward and backward) only reorders launches: three
+    training steps from the same seeds must match the single-stream run bit for bit (loss, a parameter from every
+    decoder and the encoder, BatchNorm running statistics)."""
+    import uaps_amd
+    import uaps_amd.unet as unet_mod
+    from uaps_amd import perturb
+
+    def run(streams):
+        unet_mod._DECODER_STREAMS = streams
+        try:
+            torch.manual_seed(5); np.random.seed(5); perturb.manual_seed(5)
+            model = uaps_amd.net_factory("unet_uaps", 3, 4).to(DEV)
+            tr = uaps_amd.UAPSTrainer(model, seed=5)
+            data = uaps_amd.data.SyntheticBatches(4, 3, 4, 64, 64, n_batches=2, seed=5, device=DEV)
+            losses = [float(tr.train_step(*data.next())["loss"]) for _ in range(3)]
+            sd = model.state_dict()
+            keys = ["encoder.in_conv.conv_conv.0.weight", "main_decoder.up1.conv1x1.weight", "aux_decoder1.up4.conv.conv_conv.4.weight",
+                    "aux_decoder2.out_conv.weight", "aux_decoder3.up2.conv.conv_conv.1.running_mean", "aux_decoder3.up2.conv.conv_conv.5.weight"]
+            return losses, [sd[k].clone() for k in keys]
+        finally:
+            unet_mod._DECODER_STREAMS = False
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0 == l1
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)

@@ -32,6 +32,9 @@ _VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 _FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
 _FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
 _FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
+# One HIP stream per auxiliary decoder (see UNet_UAPS.forward): +5 % images/s on the bench step, opt-in because kernels of
+# different decoders then overlap and per-launch timings (bench.py's roofline, rocprof averages) stop describing one kernel.
+_DECODER_STREAMS = os.environ.get("UAPS_DECODER_STREAMS", "0") != "0"
 
 
 class ConvBlock(nn.Module):
@@ -206,6 +209,7 @@ class UNet_UAPS(nn.Module):
             setattr(self, f"aux_decoder{i}", Decoder(class_num, feature_chns))
         self._noise = perturb.FeatureNoise()
         self._conv_weights = None
+        self._streams = None
 
     def aux_decoders(self) -> List[Decoder]:
         return [getattr(self, f"aux_decoder{i}") for i in range(1, self.n_aux + 1)]
@@ -250,7 +254,27 @@ class UNet_UAPS(nn.Module):
                 if blk is not None:
                     f = blk.maxpool_conv[1](fan[-1]) if pool else blk(f)
             per_dec = [[fan[d] for fan in fans] for d in range(1 + self.n_aux)]
-            outs = [self.main_decoder(per_dec[0])] + [dec(per_dec[i + 1]) for i, dec in enumerate(self.aux_decoders())]
+            decoders = [self.main_decoder] + self.aux_decoders()
+            if not _DECODER_STREAMS:
+                return tuple(dec(per_dec[d]) for d, dec in enumerate(decoders))
+            # The decoders are independent chains of ~60 launches each: every auxiliary decoder gets its own HIP stream
+            # (forward here, and autograd runs each backward node on its forward stream), so one decoder's small
+            # dependent kernels (BatchNorm finalize, weight-gradient reduce) and the tail of its convolutions overlap the
+            # other decoders' convolutions instead of leaving most CUs idle.
+            main = torch.cuda.current_stream(x.device)
+            if self._streams is None or len(self._streams) != self.n_aux or self._streams[0].device != x.device:
+                self._streams = [torch.cuda.Stream(device=x.device) for _ in range(self.n_aux)]
+            ready = main.record_event()
+            outs = [None] * len(decoders)
+            for d in range(1, len(decoders)):
+                side = self._streams[d - 1]
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    outs[d] = decoders[d](per_dec[d])
+                outs[d].record_stream(main)              # consumed by the loss on the main stream
+            outs[0] = decoders[0](per_dec[0])
+            for side in self._streams:
+                main.wait_stream(side)
             return tuple(outs)
         feats = self.encoder(x)
         if x.is_cuda and torch.is_grad_enabled() and self.n_aux > 0:
