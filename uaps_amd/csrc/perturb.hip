@@ -122,7 +122,16 @@ __global__ __launch_bounds__(kThreads) void fdrop_attention(const float* __restr
             const float4 v = *reinterpret_cast<const float4*>(xb + i);
             s[0] = v.x; s[1] = v.y; s[2] = v.z; s[3] = v.w;
             int c = 1;
-            for (; c + 3 < C; c += 4) {            // four loads in flight, adds in channel order
+            for (; c + 14 < C; c += 15) {          // fifteen loads in flight (a 16-channel level is one batch), adds in channel order
+                float4 t[15];
+#pragma unroll
+                for (int q = 0; q < 15; ++q) t[q] = *reinterpret_cast<const float4*>(xb + (long)(c + q) * HW + i);
+#pragma unroll
+                for (int q = 0; q < 15; ++q) {
+                    s[0] = add_rn(s[0], t[q].x); s[1] = add_rn(s[1], t[q].y); s[2] = add_rn(s[2], t[q].z); s[3] = add_rn(s[3], t[q].w);
+                }
+            }
+            for (; c + 3 < C; c += 4) {            // four loads in flight
                 float4 t[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(xb + (long)(c + q) * HW + i);
@@ -150,7 +159,56 @@ __global__ __launch_bounds__(kThreads) void fdrop_attention(const float* __restr
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t > best ? t : best; }
-    if ((threadIdx.x & 63) == 0 && best) atomicMax(maxkey + b, best);
+    // one atomic per block, not per wave: a 256x256 level would otherwise queue 256 atomics per image on one address
+    __shared__ uint32_t wbest[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = max(max(wbest[0], wbest[1]), max(wbest[2], wbest[3]));
+        if (best) atomicMax(maxkey + b, best);
+    }
+}
+// The same for the deep encoder levels (many channels, few pixels): the four waves of a block own the same 256 pixels
+// and a quarter of the channels each (in channel order), the quarter sums are combined ((q0 + q1) + q2) + q3 through
+// LDS -- 4x the loads in flight where the plain kernel is latency-bound on a serial chain of C loads per lane.
+__global__ __launch_bounds__(kThreads) void fdrop_attention_split(const float* __restrict__ x, int C, long HW, float* __restrict__ att,
+                                                                  uint32_t* __restrict__ maxkey) {
+    __shared__ float4 part[3][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* xb = x + (long)b * C * HW;
+    const long i = ((long)blockIdx.x * 64 + lane) * 4;
+    const int c0 = wave * (C / 4), c1 = c0 + C / 4;           // C % 4 == 0 (host checks)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < HW) {
+        s = *reinterpret_cast<const float4*>(xb + (long)c0 * HW + i);
+        int c = c0 + 1;
+        for (; c + 3 < c1; c += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(xb + (long)(c + q) * HW + i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s.x = add_rn(s.x, t[q].x); s.y = add_rn(s.y, t[q].y); s.z = add_rn(s.z, t[q].z); s.w = add_rn(s.w, t[q].w); }
+        }
+        for (; c < c1; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(xb + (long)c * HW + i);
+            s.x = add_rn(s.x, t.x); s.y = add_rn(s.y, t.y); s.z = add_rn(s.z, t.z); s.w = add_rn(s.w, t.w);
+        }
+    }
+    if (wave > 0) part[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t best = 0;
+    if (i < HW) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const float4 t = part[q][lane]; s.x = add_rn(s.x, t.x); s.y = add_rn(s.y, t.y); s.z = add_rn(s.z, t.z); s.w = add_rn(s.w, t.w); }
+        s.x = s.x / (float)C; s.y = s.y / (float)C; s.z = s.z / (float)C; s.w = s.w / (float)C;
+        *reinterpret_cast<float4*>(att + (long)b * HW + i) = s;
+        const uint32_t k0 = fkey(s.x), k1 = fkey(s.y), k2 = fkey(s.z), k3 = fkey(s.w);
+        best = max(max(k0, k1), max(k2, k3));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(best, o, 64); best = t > best ? t : best; }
+    if (lane == 0 && best) atomicMax(maxkey + b, best);
 }
 // pass B: keep = att < max * u ; y = x * keep
 template <int V>
@@ -477,7 +535,11 @@ extern "C" int uaps_feat_dropout_stats(const float* x, int B, int C, int H, int 
     hipError_t e = hipMemsetAsync(maxkey, 0, (size_t)B * 4, s);
     if (e != hipSuccess) return (int)e;
     const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
+    if (vec && C >= 64 && C % 4 == 0 && HW <= 4096) {      // deep levels: split the channels over the waves of a block
+        hipLaunchKernelGGL(fdrop_attention_split, dim3((unsigned)((HW / 4 + 63) / 64), B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
+        return (int)hipGetLastError();
+    }
+    int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 2048) gx = (int)((2048 + B - 1) / B);
     if (vec) hipLaunchKernelGGL(fdrop_attention<4>, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
     else hipLaunchKernelGGL(fdrop_attention<1>, dim3(gx, B), dim3(kThreads), 0, s, x, C, HW, att, maxkey);
     return (int)hipGetLastError();
