@@ -185,10 +185,14 @@ __global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* _
     for (int k = 0; k < 7; ++k) { wx[k] = sWx[lx][k]; wy[k] = sWy[ly][k]; }
     // ---- reduce along x: T[r][lx] = sum_k wx[k] * A[r][2*lx + 1 + k]   (2*ix - 3 + k - ox0 = 2*lx + 1 + k) ----
     for (int r = ly; r < kPr; r += kThreads / kLx) {
-        const float* a = &sA[r * kPc + 2 * lx + 1];
+        // columns 2*lx .. 2*lx + 7 as four 8-byte reads: lanes are 2 floats apart, so ds_read_b64 covers all 64 banks once
+        // (seven ds_read_b32 at that stride are 2-way conflicted); a[k] = column 2*lx + 1 + k
+        const float2* a2 = reinterpret_cast<const float2*>(&sA[r * kPc + 2 * lx]);
+        const float2 p0 = a2[0], p1 = a2[1], p2 = a2[2], p3 = a2[3];
+        const float a[7] = {p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
         float row = 0.f;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) if (wx[k] != 0.f) row += wx[k] * a[k];
+        for (int k = 0; k < 7; ++k) row += wx[k] * a[k];       // taps outside the footprint have weight 0 (patch is zero-filled: finite)
         sT[r * kLx + lx] = row;
     }
     __syncthreads();
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* _
     if (ix < w && iy < h) {
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) if (wy[k] != 0.f) acc += wy[k] * sT[(2 * ly + k) * kLx + lx];
+        for (int k = 0; k < 7; ++k) acc += wy[k] * sT[(2 * ly + k) * kLx + lx];
         dlow[(((long)b * Cl + c) * h + iy) * w + ix] = acc;
     }
 }
