@@ -443,3 +443,45 @@ def test_decoder_streams_give_bit_identical_steps():
     assert l0 == l1
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+def test_grad_buckets_over_rccl_single_rank():
+    """The N > 1 exchange step (uaps_amd.dist.GradBuckets: per-module flat buckets, asynchronous all-reduce launched from
+    post-accumulate hooks during backward, gradients re-pointed at the reduced buffers) exercised over the real RCCL
+    backend with one rank: with the bucket's divisor forced to 2 every gradient must come out exactly halved.  (The
+    multi-rank logic is covered on CPU by tests/test_ddp_gloo.py; this checks the nccl call path, streams and views.)"""
+    import torch.distributed as dist
+    import uaps_amd
+    from uaps_amd import dist as udist, perturb
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        def grads(with_buckets):
+            torch.manual_seed(9); np.random.seed(9); perturb.manual_seed(9)
+            model = uaps_amd.net_factory("unet_uaps", 3, 4).to(DEV)
+            data = uaps_amd.data.SyntheticBatches(2, 3, 4, 32, 32, n_batches=1, seed=9, device=DEV)
+            x_l, y_l, x_u = data.next()
+            buckets = None
+            if with_buckets:
+                buckets = udist.GradBuckets(model)
+                buckets.world = 2                                   # divisor of the average; one rank contributes the sum
+                buckets.remove()
+                for bi, params in enumerate(buckets.buckets):       # register the hooks the world > 1 constructor would
+                    for p in params:
+                        buckets._hooks.append(p.register_post_accumulate_grad_hook(buckets._make_hook(bi)))
+                buckets.reset()
+            both = model.forward_pair(x_l, x_u)
+            out = uaps_amd.uaps_pair_loss(both, y_l, np.full(4, 0.25), 0.1, 0.1)
+            out.loss.backward()
+            if buckets is not None:
+                buckets.finish()
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in model.parameters()]
+
+        ref, got = grads(False), grads(True)
+        assert len(ref) == len(got) == 208
+        for a, b in zip(ref, got):
+            assert torch.equal(b, a * 0.5)
+    finally:
+        dist.destroy_process_group()
