@@ -85,7 +85,10 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created even for one rank, so the barrier /
+    # max-over-ranks plumbing below is the same code at every N
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -125,7 +128,7 @@ def main():
             conv.KERNEL_EVENTS = losses.KERNEL_EVENTS = None
     dominant = max(discover, key=lambda k: discover[k]["total_us"]) if discover else None
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     losses.KERNEL_EVENTS = {}
@@ -134,13 +137,13 @@ def main():
     for _ in range(args.steps):
         trainer.train_step(*data.next())
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ev, losses.KERNEL_EVENTS = losses.KERNEL_EVENTS, None
     cev, conv.KERNEL_EVENTS, conv.EVENT_FILTER = conv.KERNEL_EVENTS, None, None
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -200,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
             res["cpu_baseline"] = cpu_baseline(4, H, W)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
