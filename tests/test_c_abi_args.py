@@ -67,3 +67,14 @@ def test_kernel_plan_names_and_statistics_tiles(L):
     parts = C.c_int()
     assert L.uaps_conv_fwd_stats_parts(32, 16, 16, 256, 256, 3, 0, C.byref(parts)) == OK and parts.value == 32 * 8
     assert L.uaps_conv_fwd_stats_parts(4, 128, 128, 16, 16, 3, 0, C.byref(parts)) == OK and parts.value == 1
+
+
+def test_tensors_of_two_gib_or_more_are_refused_before_any_launch(L):
+    """The conv kernels address a channel block with 32-bit buffer offsets: a [C, H, W] block of >= 2 GiB is out of range.
+    The check precedes every HIP call, so dummy (never dereferenced) pointers suffice here."""
+    fake = C.c_void_p(1 << 20)
+    big = (1, 16, 16, 8192, 8192)                       # 16 * 8192 * 8192 * 4 B = 4 GiB per image
+    assert L.uaps_conv_fwd(fake, fake, None, fake, *big, 3, 0, None) == ERANGE
+    assert L.uaps_conv_bwd_data(fake, fake, fake, *big, 3, 0, None) == ERANGE
+    assert L.uaps_conv_bwd_weight_partial(fake, fake, 0, *big, 3, 0, fake, 1 << 40, None) == ERANGE
+    assert L.uaps_conv_fwd(fake, fake, None, fake, 1, 16, 16, 64, 64, 5, 0, None) == ERANGE      # 5x5 does not exist
