@@ -88,14 +88,26 @@ def main():
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so the barrier /
     # max-over-ranks plumbing below is the same code at every N
     distributed = world > 1 or "RANK" in os.environ
+    saved_stdout = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL prints its version banner (NCCL_DEBUG=VERSION on the GPU boxes) on stdout when the communicator is created:
+        # point fd 1 at stderr until the first collective has run, so that stdout carries the one JSON line only
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(1337)
     D, C, H, W, b = args.aux + 1, args.classes, args.size, args.size, args.batch
     model = uaps_amd.net_factory(args.net, 3, C, n_aux=args.aux)
     uaps_amd.dist.broadcast_model(model)
+    if saved_stdout is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     trainer = uaps_amd.UAPSTrainer(model, seed=1337)
     data = uaps_amd.data.SyntheticBatches(b, 3, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
 
