@@ -145,9 +145,12 @@ def main():
     torch.cuda.synchronize()
     losses.KERNEL_EVENTS = {}
     conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, ({dominant} if dominant else None)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread (median, p10 / p90)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         trainer.train_step(*data.next())
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -203,6 +206,7 @@ def main():
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic}
+        step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
         res = {"metric": "training images/sec (labeled+unlabeled) NEU-Seg 256x256 K=3", "value": round(2 * b * world * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -210,6 +214,8 @@ def main():
                "config": {"workload": f"UAPS K={args.aux} decoders, NEU-Seg-shaped {H}x{W} {C}-class, batch {b}+{b} per GPU (BASELINE.json configs[1])",
                           "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5)},
                "roofline": roof, "kernels": kern}
+        res["step_ms"] = {"p10": round(float(np.percentile(step_ms, 10)), 3), "p50": round(float(np.percentile(step_ms, 50)), 3),
+                          "p90": round(float(np.percentile(step_ms, 90)), 3), "note": "GPU time between per-step HIP events on rank 0"}
         if args.net != "unet_uaps":
             res["config"]["workload"] = f"{args.net} K={args.aux}, {H}x{W} {C}-class, batch {b}+{b} per GPU (not the BASELINE metric config)"
         if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
