@@ -31,25 +31,70 @@ def loss_kernel_bytes(name, D, C, npix):
     return per_px * npix
 
 
-def cpu_baseline(batch, H, W, steps=3):
-    """The oracle's whole step (oracle/uaps_oracle.py CpuStep: same net, unfused loss, autograd, Adam)
-    timed on this box's host cores on a bounded sample.  Baseline only, never the product path."""
+def host_cpu_info():
+    """What the CPU baseline ran on: lscpu's socket / core / thread counts and the cores this process may use."""
+    import subprocess
+    info = {}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        want = {"CPU(s)": "cpus", "Socket(s)": "sockets", "Core(s) per socket": "cores_per_socket", "Thread(s) per core": "threads_per_core",
+                "Model name": "model"}
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in want and want[k.strip()] not in info:
+                v = v.strip()
+                info[want[k.strip()]] = int(v) if v.isdigit() else v
+    except Exception as e:                                  # lscpu missing: report what Python knows
+        info["lscpu_error"] = str(e)
+    info["usable_cpus"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    try:                                                    # a cgroup CPU quota caps the cores a container really gets
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            info["cgroup_quota_cpus"] = round(int(quota) / int(period), 2)
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(batch, H, W, budget_s=25.0):
+    """The oracle's whole step (oracle/uaps_oracle.py CpuStep: same net, unfused loss, autograd, Adam) timed on this box's
+    host cores at the metric's own batch, with torch.set_num_threads at (a) the physical cores of one socket and (b) every
+    usable core.  A bounded sample: one warm-up step, then steps until two are done or `budget_s`
+    seconds have passed, per setting.  Baseline only, never the product path."""
     import numpy as np
     import torch
     import uaps_amd
     from oracle import uaps_oracle as O
+    info = host_cpu_info()
+    usable = int(info.get("cgroup_quota_cpus") or info["usable_cpus"])
+    usable = max(1, min(usable, info["usable_cpus"]))
+    one_socket = int(info.get("cores_per_socket") or usable)
+    settings = sorted({max(1, min(one_socket, usable)), usable})
     torch.manual_seed(1337); np.random.seed(1337)
     net = uaps_amd.UNet_UAPS(3, 4)
-    st = O.CpuStep(net.state_dict())
     data = uaps_amd.data.SyntheticBatches(batch, H=H, W=W, n_batches=1, device="cpu")
     xl, yl, xu = data.next()
-    st.step(xl, yl, xu)                                    # warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        st.step(xl, yl, xu)
-    dt = time.perf_counter() - t0
-    return {"value": round(2 * batch * steps / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} steps of {batch}+{batch} images {H}x{W} D=4 C=4 (oracle CpuStep, torch CPU fp32, 1 warm-up)"}
+    runs = []
+    prev = torch.get_num_threads()
+    for n in settings:
+        torch.set_num_threads(n)
+        st = O.CpuStep(net.state_dict())
+        t0 = time.perf_counter()
+        st.step(xl, yl, xu)                                # warm-up
+        warm = time.perf_counter() - t0
+        done, t0 = 0, time.perf_counter()
+        while done < 2 and (done == 0 or time.perf_counter() - t0 < budget_s):
+            st.step(xl, yl, xu)
+            done += 1
+        dt = time.perf_counter() - t0
+        runs.append({"threads": n, "images_per_s": round(2 * batch * done / dt, 3), "s_per_step": round(dt / done, 2),
+                     "steps": done, "warmup_step_s": round(warm, 2)})
+    torch.set_num_threads(prev)
+    best = max(runs, key=lambda r: r["images_per_s"])
+    return {"value": best["images_per_s"], "unit": "images/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['steps']} step(s) of {batch}+{batch} images {H}x{W} D=4 C=4 after 1 warm-up step (oracle CpuStep: the "
+                      "reference-structured unfused PyTorch-CPU fp32 step), best of the thread settings in `runs`",
+            "runs": runs, "host": info}
 
 
 def main():
@@ -63,9 +108,10 @@ def main():
     ap.add_argument("--aux", type=int, default=3)
     ap.add_argument("--net", default="unet_uaps", help="unet_uaps (BASELINE.json configs[1], the reported metric) or resnet50_uaps (configs[4] shape study)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decoder-streams", action="store_true",
-                    help="run the auxiliary decoders on their own HIP streams (UAPS_DECODER_STREAMS=1): higher images/s, but launches of "
-                         "different decoders overlap, so the per-launch roofline figures no longer describe one kernel")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="time the headline steps with all launches on one HIP stream (default: one stream per auxiliary decoder, "
+                         "bit-identical results, launches of different decoders overlap)")
+    ap.add_argument("--analysis-steps", type=int, default=6, help="single-stream steps after the timed region for the per-kernel figures")
     args = ap.parse_args()
 
     import numpy as np
@@ -74,9 +120,8 @@ def main():
     import uaps_amd
     from uaps_amd import losses
 
-    if args.decoder_streams:
-        import uaps_amd.unet as _unet
-        _unet._DECODER_STREAMS = True
+    import uaps_amd.unet as _unet
+    _unet._DECODER_STREAMS = not args.single_stream
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,29 +167,13 @@ def main():
                          "work": float(sum(r[2] for r in recs if len(r) > 2))}
         return out
 
-    # Warm-up.  The first warm-up step also times EVERY hand-written conv/loss launch once with HIP events to find
-    # the kernel instantiation that dominates the step; the timed region then brackets only that kernel's launches
-    # (and the four loss kernels), so the event records do not perturb the measured step.
-    discover = None
+    # ---- headline: W warm-up steps, then exactly K timed steps, in the fastest bit-identical launch mode ----
     for i in range(args.warmup):
-        if i == args.warmup - 1:
-            torch.cuda.synchronize()
-            conv.KERNEL_EVENTS, conv.EVENT_FILTER, losses.KERNEL_EVENTS = {}, None, {}
         trainer.train_step(*data.next())
-        if i == args.warmup - 1:
-            torch.cuda.synchronize()
-            discover = summarize(conv.KERNEL_EVENTS)
-            for k, pairs in losses.KERNEL_EVENTS.items():
-                us = [s.elapsed_time(e) * 1e3 for s, e in pairs]
-                discover[k] = {"calls": len(us), "avg_us": float(np.mean(us)), "total_us": float(np.sum(us)), "work": 0.0}
-            conv.KERNEL_EVENTS = losses.KERNEL_EVENTS = None
-    dominant = max(discover, key=lambda k: discover[k]["total_us"]) if discover else None
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    losses.KERNEL_EVENTS = {}
-    conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, ({dominant} if dominant else None)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread (median, p10 / p90)
     t0 = time.perf_counter()
     marks[0].record()
@@ -156,70 +185,124 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ev, losses.KERNEL_EVENTS = losses.KERNEL_EVENTS, None
-    cev, conv.KERNEL_EVENTS, conv.EVENT_FILTER = conv.KERNEL_EVENTS, None, None
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     last_loss = float(trainer.last["loss"])
 
+    # ---- per-kernel analysis pass, same process, SINGLE stream (a launch's event-to-event time is then that kernel alone):
+    # one step with every hand-written conv / loss launch bracketed by HIP events on its launch stream (finds the dominant
+    # instantiation and sums the step's algorithmic flops), then `analysis_steps` steps with events around the dominant
+    # kernel's launches and the loss kernels only, timed as a whole for the single-stream ms/step ----
+    discover, ev, cev, single_ms = None, {}, {}, None
+    if args.analysis_steps > 0:                              # every rank steps (the gradient exchange is collective); rank 0's events are reported
+        _unet._DECODER_STREAMS = False
+        trainer.train_step(*data.next())                   # re-warm in the new mode
+        torch.cuda.synchronize()
+        conv.KERNEL_EVENTS, conv.EVENT_FILTER, losses.KERNEL_EVENTS = {}, None, {}
+        trainer.train_step(*data.next())
+        torch.cuda.synchronize()
+        discover = summarize(conv.KERNEL_EVENTS)
+        for k, pairs in losses.KERNEL_EVENTS.items():
+            us = [s.elapsed_time(e) * 1e3 for s, e in pairs]
+            discover[k] = {"calls": len(us), "avg_us": float(np.mean(us)), "total_us": float(np.sum(us)), "work": 0.0}
+        conv_names = [k for k in discover if discover[k]["work"] > 0]
+        dominant = max(conv_names, key=lambda k: discover[k]["total_us"]) if conv_names else None
+        losses.KERNEL_EVENTS = {}
+        conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, ({dominant} if dominant else None)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for i in range(args.analysis_steps):
+            trainer.train_step(*data.next())
+        a1.record()
+        torch.cuda.synchronize()
+        single_ms = a0.elapsed_time(a1) / args.analysis_steps
+        ev, losses.KERNEL_EVENTS = losses.KERNEL_EVENTS, None
+        cev, conv.KERNEL_EVENTS, conv.EVENT_FILTER = conv.KERNEL_EVENTS, None, None
+        _unet._DECODER_STREAMS = not args.single_stream
+    else:
+        dominant = None
+
     if rank == 0:
         npix = b * H * W
+        n_an = max(args.analysis_steps, 1)
         kern = {}
         for name, pairs in ev.items():
             ms = [s.elapsed_time(e) for s, e in pairs]
             avg_s = float(np.mean(ms)) * 1e-3
             by = loss_kernel_bytes(name, D, C, npix)
-            kern[name] = {"calls_per_step": len(ms) / args.steps, "avg_us": round(avg_s * 1e6, 2), "GBps": round(by / avg_s / 1e9, 1)}
+            kern[name] = {"calls_per_step": len(ms) / n_an, "avg_us": round(avg_s * 1e6, 2), "GBps": round(by / avg_s / 1e9, 1)}
         timed = summarize(cev)
-        if dominant is None and timed:
-            dominant = max(timed, key=lambda k: timed[k]["total_us"])
         for name, v in timed.items():
-            kern[name] = {"calls_per_step": v["calls"] / args.steps, "avg_us": round(v["avg_us"], 2),
+            kern[name] = {"calls_per_step": v["calls"] / n_an, "avg_us": round(v["avg_us"], 2),
                           "TFLOPs": round(v["work"] / v["total_us"] / 1e6, 2)}
-        for name, v in (discover or {}).items():          # one warm-up step's sample of the other instantiations
+        for name, v in (discover or {}).items():          # one single-stream step's sample of the other instantiations
             if name not in kern:
-                kern[name] = {"calls_per_step": v["calls"], "avg_us": round(v["avg_us"], 2), "sample": "1 warm-up step"}
+                kern[name] = {"calls_per_step": v["calls"], "avg_us": round(v["avg_us"], 2), "sample": "1 step"}
                 if v["work"]:
                     kern[name]["TFLOPs"] = round(v["work"] / v["total_us"] / 1e6, 2)
-        traffic = None
-        try:   # HBM bytes per launch from the rocprofv3 PMC passes (profiles/README.md), when they have been collected
+        pmc = {}
+        try:   # HBM bytes per launch / per step from the rocprofv3 PMC passes (profiles/README.md), when they have been collected
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                traffic = json.load(f).get(dominant)
+                pmc = json.load(f)
         except (OSError, ValueError):
             pass
+        traffic = pmc.get(dominant)
+        ms_per_step = dt / args.steps * 1e3
         if dominant in timed:
             v = timed[dominant]
             ach = v["work"] / v["total_us"] / 1e6                     # TFLOP/s, algorithmic 2*B*H*W*Cin*Cout*k*k per launch
             roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic, "avg_us": round(v["avg_us"], 2),
-                    "launches_per_step": v["calls"] / args.steps,
-                    "note": "kernel instantiation with the largest share of the step (found in the last warm-up step); algorithmic "
-                            "flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time; "
-                            "traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); peak is the "
-                            "nominal 2.4 GHz figure -- under this kernel the shader clock measured 2.03-2.14 GHz (DESIGN.md section 5)"}
-            if args.decoder_streams or os.environ.get("UAPS_DECODER_STREAMS", "0") != "0":
-                roof["note"] += ("; DECODER STREAMS ON: launches of the four decoders overlap on the GPU, a launch's event-to-event time "
-                                 "includes other kernels' share of the CUs, so achieved / frac are NOT standalone-kernel figures in this run")
-        else:
+                    "launches_per_step": v["calls"] / n_an,
+                    "note": "kernel instantiation with the largest share of the step; measured in the single-stream analysis pass "
+                            f"of this process ({args.analysis_steps} steps after the timed region; launches of different decoders "
+                            "overlap in the headline mode, so a launch's event-to-event time is only that kernel's when single-stream): "
+                            "algorithmic flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time on "
+                            "the launch stream; traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); "
+                            "peak is the nominal 2.4 GHz fp32 matrix figure (DESIGN.md section 5)"}
+        elif ev:
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic}
+                    "frac": round(kern[dom]["GBps"] / HBM_PEAK_GBS, 4), "traffic": pmc.get(dom)}
+        else:
+            roof = None
+        if roof is not None and discover:
+            # step level: t_min = max(flops / fp32 matrix peak, HBM bytes / HBM peak) against the measured step
+            step_flops = float(sum(v["work"] for v in discover.values()))
+            step_bytes = pmc.get("__step_total_bytes")
+            t_mfma = step_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
+            t_hbm = step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if step_bytes else None
+            t_min = max(t_mfma, t_hbm or 0.0)
+            roof.update({"step_flops": step_flops, "step_hbm_bytes": step_bytes,
+                         "step_hbm_bytes_note": "sum over all kernels of launches x (2*FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 "
+                                                "--pmc passes of this bench command, per step; null when no PMC summary is committed",
+                         "t_min_ms": round(t_min, 3), "t_min_mfma_ms": round(t_mfma, 3), "t_min_hbm_ms": round(t_hbm, 3) if t_hbm else None,
+                         "frac_step": round(t_min / ms_per_step, 4),
+                         "frac_step_single_stream": round(t_min / single_ms, 4) if single_ms else None,
+                         "step_TFLOPs": round(step_flops / ms_per_step / 1e9, 2),
+                         "step_hbm_GBps": round(step_bytes / ms_per_step / 1e6, 1) if step_bytes else None,
+                         "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+        mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (bit-identical to single-stream)"
         res = {"metric": "training images/sec (labeled+unlabeled) NEU-Seg 256x256 K=3", "value": round(2 * b * world * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"UAPS K={args.aux} decoders, NEU-Seg-shaped {H}x{W} {C}-class, batch {b}+{b} per GPU (BASELINE.json configs[1])",
-                          "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5)},
+                          "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5),
+                          "launch_mode": mode},
                "roofline": roof, "kernels": kern}
         res["step_ms"] = {"p10": round(float(np.percentile(step_ms, 10)), 3), "p50": round(float(np.percentile(step_ms, 50)), 3),
-                          "p90": round(float(np.percentile(step_ms, 90)), 3), "note": "GPU time between per-step HIP events on rank 0"}
+                          "p90": round(float(np.percentile(step_ms, 90)), 3), "note": "GPU time between per-step HIP events on rank 0 (headline mode)"}
+        if single_ms:
+            res["single_stream"] = {"ms_per_step": round(single_ms, 3), "images_per_s": round(2 * b / single_ms * 1e3, 1),
+                                    "steps": args.analysis_steps, "note": "the analysis pass the per-kernel figures come from (rank 0, HIP events)"}
         if args.net != "unet_uaps":
             res["config"]["workload"] = f"{args.net} K={args.aux}, {H}x{W} {C}-class, batch {b}+{b} per GPU (not the BASELINE metric config)"
         if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
-            res["cpu_baseline"] = cpu_baseline(4, H, W)
+            res["cpu_baseline"] = cpu_baseline(b, H, W)
         print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()

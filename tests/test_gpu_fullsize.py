@@ -1,0 +1,220 @@
+"""-m gpu: parity at the sizes bench.py times (BASELINE.json configs[1]: 16 + 16 images 256x256, real-width net, and the
+512x512 top level of configs[3]) -- the kernel instantiations, pixel-split counts, XCD swizzles and slab reductions that
+the small-shape tests never reach.
+
+(a) every distinct convolution of the step, launched at the bench batch (B = 32; 16 for the 512x512 layers), against
+    PyTorch CPU convolutions: forward and input gradient on three image slices of the launch (images are independent),
+    weight / bias gradient over the whole batch in float64 (utilities/UAPS_unet.py:36-44, 73, 138); the two-tensor
+    (never-materialised concat) and the BatchNorm-in-staging variants at their real shapes too;
+(b) one whole step of the real-width UNet_UAPS(3, 4) at 256x256, 2 + 2 images, recorded perturbation draws, against
+    oracle.uaps_oracle.uaps_forward / step_loss on the CPU (UAPS_unet.py:224-233, UAPS_train.py:186-292): logits,
+    pseudo-labels, loss and all 208 parameter gradients, through both the two-forward and the forward_pair route.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from step_helpers import injected, injected_pair
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (B, Cin, Cout, H, W, ks, form): form 'plain' = conv2d, 'cat' = conv2d_cat on two halves of the input channels
+STEP_CONVS = [
+    (32, 3, 16, 256, 256, 3, "plain"), (32, 16, 16, 256, 256, 3, "plain"), (32, 16, 32, 128, 128, 3, "plain"),
+    (32, 32, 32, 128, 128, 3, "plain"), (32, 32, 64, 64, 64, 3, "plain"), (32, 64, 64, 64, 64, 3, "plain"),
+    (32, 64, 128, 32, 32, 3, "plain"), (32, 128, 128, 32, 32, 3, "plain"), (32, 128, 256, 16, 16, 3, "plain"),
+    (32, 256, 256, 16, 16, 3, "plain"),
+    (32, 256, 128, 16, 16, 1, "plain"), (32, 128, 64, 32, 32, 1, "plain"), (32, 64, 32, 64, 64, 1, "plain"),
+    (32, 32, 16, 128, 128, 1, "plain"),
+    (32, 256, 128, 32, 32, 3, "cat"), (32, 128, 64, 64, 64, 3, "cat"), (32, 64, 32, 128, 128, 3, "cat"),
+    (32, 32, 16, 256, 256, 3, "cat"),
+    (32, 16, 4, 256, 256, 3, "plain"),                               # out_conv, C = 4
+    # configs[3] (K=5, DAGM-shaped 1 x 512 x 512, 2 classes, 8 + 8 images): the top-resolution layers
+    (16, 1, 16, 512, 512, 3, "plain"), (16, 16, 16, 512, 512, 3, "plain"), (16, 32, 16, 512, 512, 3, "cat"),
+    (16, 16, 2, 512, 512, 3, "plain"),
+]
+_IDS = [f"{f}-B{B}-{ci}to{co}-{H}x{W}-k{ks}" for B, ci, co, H, W, ks, f in STEP_CONVS]
+
+
+def _mk(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def _close(a, ref, what, tol=2e-5, where=None):
+    scale = float(ref.abs().max()) + 1e-12
+    diff = (a.detach().cpu().double() - ref.double()).abs()
+    err = float((diff if where is None else diff[where]).max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,form", STEP_CONVS, ids=_IDS)
+def test_step_convolutions_at_bench_batch_vs_torch_cpu(B, Cin, Cout, H, W, ks, form):
+    from uaps_amd.conv import conv2d, conv2d_cat
+    x = _mk((B, Cin, H, W), 1)
+    w = _mk((Cout, Cin, ks, ks), 2) / np.sqrt(Cin * ks * ks)
+    b = _mk((Cout,), 3)
+    dy = _mk((B, Cout, H, W), 4)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    if form == "cat":
+        x1, x2 = (t.contiguous().to(DEV).requires_grad_(True) for t in (x[:, : Cin // 2], x[:, Cin // 2:]))
+        y = conv2d_cat(x1, x2, wg, bg)
+        y.backward(dy.to(DEV))
+        dx = torch.cat([x1.grad, x2.grad], dim=1)
+    else:
+        xg = x.to(DEV).requires_grad_(True)
+        y = conv2d(xg, wg, bg)
+        y.backward(dy.to(DEV))
+        dx = xg.grad
+    # forward / input gradient: three images of the launch (first, last, one inside) on the CPU in fp32
+    sel = [0, B // 2 - 1, B - 1]
+    xr = x[sel].clone().requires_grad_(True)
+    yr = F.conv2d(xr, w, b, padding=ks // 2)
+    yr.backward(dy[sel])
+    _close(y[sel], yr.detach(), "y")
+    _close(dx[sel], xr.grad, "dx")
+    # weight / bias gradient: the whole batch, float64 on the CPU
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=ks // 2)
+    _close(wg.grad, dw_ref, "dw")
+    _close(bg.grad, dy.double().sum(dim=(0, 2, 3)), "db")
+
+
+# the BatchNorm(train)+LeakyReLU-while-staging variants of the step: (B, Cin, Cout, H, W, ks)
+BN_CONVS = [(32, 128, 128, 32, 32, 3), (32, 128, 64, 32, 32, 1), (32, 64, 64, 64, 64, 3), (32, 64, 32, 64, 64, 1),
+            (32, 32, 32, 128, 128, 3), (32, 32, 16, 128, 128, 1), (32, 16, 16, 256, 256, 3), (32, 16, 4, 256, 256, 3),
+            (16, 16, 16, 512, 512, 3), (16, 16, 2, 512, 512, 3)]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", BN_CONVS, ids=[f"B{B}-{ci}to{co}-{H}x{W}-k{ks}" for B, ci, co, H, W, ks in BN_CONVS])
+def test_bn_in_staging_convolutions_at_bench_batch_vs_torch_cpu(B, Cin, Cout, H, W, ks):
+    """conv2(leaky_relu(bn_train(y))) where conv2 applies the normalisation while it stages y (fused.bn_act_conv), two
+    statistics groups as in the step, against torch modules on the CPU (fp32 autograd over the whole batch)."""
+    from uaps_amd import conv, fused
+    g = torch.Generator().manual_seed(B + Cin + Cout + H + ks)
+    x0 = torch.randn(B, 8, H, W, generator=g)
+    w0 = torch.randn(Cin, 8, 3, 3, generator=g) / np.sqrt(72.0)
+    bn = torch.nn.BatchNorm2d(Cin)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g); bn.bias.uniform_(-0.5, 0.5, generator=g)
+    w2 = torch.randn(Cout, Cin, ks, ks, generator=g) / np.sqrt(Cin * ks * ks)
+    b2 = torch.randn(Cout, generator=g)
+    dz = torch.randn(B, Cout, H, W, generator=g)
+    import copy
+    bng = copy.deepcopy(bn).to(DEV)
+    w2g, b2g = w2.to(DEV).requires_grad_(True), b2.to(DEV).requires_grad_(True)
+    with fused.stat_groups(2):
+        y, st = conv.conv2d_with_stats(x0.to(DEV), w0.to(DEV), None)
+        y = y.detach().requires_grad_(True)
+        z = fused.bn_act_conv(y, st, None, bng, 0.01, w2g, b2g)
+    z.backward(dz.to(DEV))
+    # CPU: the same raw y (copied back, so only the second stage is compared), one BatchNorm call per half
+    yc = y.detach().cpu().requires_grad_(True)
+    w2c, b2c = w2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    h = B // 2
+    pre = torch.cat([bn(yc[:h]), bn(yc[h:])], 0)
+    a = F.leaky_relu(pre, 0.01)
+    zc = F.conv2d(a, w2c, b2c, padding=ks // 2)
+    zc.backward(dz)
+    _close(z, zc.detach(), "z", 3e-5)
+    # LeakyReLU's derivative jumps from 0.01 to 1 at 0: where the normalised value is within rounding of 0 (a handful of the
+    # 10^7..10^8 elements) the two evaluations may legitimately sit on different sides; everything else must agree
+    sure = pre.detach().abs() > 1e-5
+    assert float(sure.float().mean()) > 0.9999
+    _close(y.grad, yc.grad, "dy", 1e-4, where=sure)
+    _close(w2g.grad, w2c.grad, "dw", 1e-4)
+    _close(b2g.grad, b2c.grad, "db", 1e-4)
+    _close(bng.weight.grad, bn.weight.grad, "dgamma", 1e-4)
+    _close(bng.bias.grad, bn.bias.grad, "dbeta", 1e-4)
+    _close(bng.running_mean, bn.running_mean, "running_mean", 1e-5)
+    _close(bng.running_var, bn.running_var, "running_var", 1e-5)
+
+
+@pytest.mark.parametrize("pair", [False, True], ids=["two_forwards", "forward_pair"])
+def test_real_width_step_256_vs_cpu_oracle(pair, monkeypatch):
+    """UNet_UAPS(3, 4) at its real width ([16, 32, 64, 128, 256] channels, 3.7 M parameters) on 2 + 2 images of
+    256 x 256 with recorded perturbation draws and encoder dropout off: D logits of both batches, pseudo-labels, the
+    loss and the gradient of all 208 parameters against the CPU oracle's unfused restatement of
+    UAPS_unet.py:224-233 + UAPS_train.py:186-292."""
+    import uaps_amd
+    from oracle import uaps_oracle as O
+    from uaps_amd import losses, unet
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    B, H, W, C = 2, 256, 256, 4
+    model = unet.UNet_UAPS(3, C, n_aux=3, dropout=[0.0] * 5)
+    with torch.no_grad():                                   # non-trivial BatchNorm affine parameters
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.7, 1.3); m.bias.uniform_(-0.2, 0.2)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    xl = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+    xu = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+    yl = torch.tensor(uaps_amd.data.synthetic_masks(rng, B, C, H, W))
+    w = rng.dirichlet(np.ones(4), size=1)[0]
+    chans = list(unet.FEATURE_CHANNELS)
+    fshapes = [(c, H >> i, W >> i) for i, c in enumerate(chans)]
+    rec = {tag: {"noise": [torch.tensor(rng.uniform(-0.3, 0.3, s).astype(np.float32)) for s in fshapes],
+                 "mask": [torch.tensor((rng.random((B,) + s) < 0.5).astype(np.float32)) for s in fshapes],
+                 "u": [float(rng.uniform(0.7, 0.9)) for _ in fshapes]} for tag in ("l", "u")}
+    cw1, cw2 = 0.07, 0.05
+
+    # ---- CPU oracle ----
+    for k in sd_cpu:
+        if sd_cpu[k].is_floating_point() and (k.endswith(".weight") or k.endswith(".bias")):
+            sd_cpu[k].requires_grad_(True)
+    lab_c = O.uaps_forward(xl, sd_cpu, True, rec["l"], dropout=[0.0] * 5)
+    un_c = O.uaps_forward(xu, sd_cpu, True, rec["u"], dropout=[0.0] * 5)
+    r = O.step_loss(un_c, lab_c, yl, w, cw1, cw2)
+    r["loss"].backward()
+
+    # ---- HIP path ----
+    model.to(DEV).train()
+
+    def dev_draws(tag):
+        d = rec[tag]
+        return [t.to(DEV) for t in d["noise"]], [t.to(DEV) for t in d["mask"]], d["u"]
+
+    xl_g, xu_g, yl_g = xl.to(DEV), xu.to(DEV), yl.to(DEV)
+    if pair:
+        both = model.forward_pair(xl_g, xu_g, perturbations=injected_pair(dev_draws("l"), dev_draws("u")))
+        out = losses.uaps_pair_loss(both, yl_g, w, cw1, cw2)
+        lab_g, un_g = [t[:B] for t in both], [t[B:] for t in both]
+    else:
+        lab_g = model(xl_g, perturbations=injected(*dev_draws("l")))
+        un_g = model(xu_g, perturbations=injected(*dev_draws("u")))
+        out = losses.uaps_step_loss(lab_g, yl_g, un_g, w, cw1, cw2)
+    out.loss.backward()
+
+    for k in range(4):
+        np.testing.assert_allclose(lab_g[k].detach().cpu().numpy(), lab_c[k].detach().numpy(), atol=1e-4, err_msg=f"labelled head {k}")
+        np.testing.assert_allclose(un_g[k].detach().cpu().numpy(), un_c[k].detach().numpy(), atol=1e-4, err_msg=f"unlabelled head {k}")
+    top2 = r["mixed"].detach().topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert float(clear.float().mean()) > 0.9
+    assert torch.equal(out.pseudo.cpu()[clear], r["pseudo"][clear])
+    np.testing.assert_allclose(float(out.loss), float(r["loss"]), rtol=2e-5)
+    params = dict(model.named_parameters())
+    assert len(params) == 208
+    worst = (0.0, "")
+    for n, p in params.items():
+        ref = sd_cpu[n].grad
+        assert ref is not None and p.grad is not None, n
+        scale = float(ref.abs().max())
+        err = float((p.grad.cpu() - ref).abs().max())
+        worst = max(worst, (err / (scale + 1e-12), n))
+        # conv biases in front of a train-mode BatchNorm have an exactly-zero gradient in exact arithmetic: the CPU
+        # autograd leaves rounding noise there, the HIP path writes 0
+        if scale < 1e-7:
+            assert err < 1e-6, n
+        else:
+            assert err <= 2e-3 * scale, f"{n}: max err {err:.3e} vs scale {scale:.3e}"
+    print(f"worst relative gradient error {worst[0]:.2e} ({worst[1]})")
+    # BatchNorm running statistics after the two forwards (updated twice, labelled batch first)
+    sd_g = model.state_dict()
+    for k, v in sd_g.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(v.cpu().numpy(), sd_cpu[k].detach().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(sd_cpu[k]) == 2, k

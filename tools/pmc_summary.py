@@ -37,6 +37,7 @@ def short(name):
 
 def main():
     root = sys.argv[1]
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # training steps the profiled command ran (warm-up included)
     fetch, write = per_kernel(root, "FETCH_SIZE"), per_kernel(root, "WRITE_SIZE")
     out, rows = {}, []
     for k in set(fetch) | set(write):
@@ -49,6 +50,10 @@ def main():
         out[short(k)] = round(corrected)
         rows.append((corrected * n, short(k), n, fetch_b, write_b, corrected))
     rows.sort(reverse=True)
+    if steps > 0:      # whole-step HBM traffic: every launch of every kernel of the run, per step (bench.py: roofline.step_hbm_bytes)
+        out["__step_total_bytes"] = round(sum(r[0] for r in rows) / steps)
+        out["__steps_profiled"] = steps
+        print(f"HBM bytes per step over all kernels ({steps} steps profiled): {out['__step_total_bytes'] / 1e9:.2f} GB")
     print(f"{'kernel':70s} {'launches':>8s} {'FETCH_SIZE B/launch (raw)':>26s} {'WRITE_SIZE B/launch':>20s} {'HBM B/launch (2*F+W)':>22s}")
     for _, k, n, fb, wb, c in rows[:40]:
         print(f"{k[:70]:70s} {n:8d} {fb:26.0f} {wb:20.0f} {c:22.0f}")
