@@ -236,7 +236,12 @@ int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs,
 /* ---------------------------------------------------------------------------------------------
  * Convolutions of the U-Net: every nn.Conv2d of utilities/UAPS_unet.py (ConvBlock 3x3 :36-44,
  * UpBlock.conv1x1 :73, Decoder.out_conv :138-139; stride 1, padding ks/2, ks in {1,3}), fp32 NCHW,
- * computed on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32) as an implicit GEMM.
+ * computed as an implicit GEMM on the matrix cores in one of two arithmetic modes (uaps_conv_set_mode):
+ *   1 (default)  exact three-way bf16 split of both fp32 operands, six partial products per multiply on
+ *                v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the error of an fp32 fma chain at 2.67x the
+ *                fp32 matrix rate (csrc/conv_split.hpp); used for 16-byte-aligned rows without dilation,
+ *   0            the exact-f32 matrix instruction v_mfma_f32_16x16x4_f32 for everything (also: UAPS_CONV_MODE=0,
+ *                or bit 28 of `cfg` for one call).
  * They replace the three aten::convolution / convolution_backward calls PyTorch makes per layer.
  *
  * Weights are used in a packed, zero-padded layout produced by uaps_conv_pack_weights from the
@@ -249,6 +254,9 @@ int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs,
  * Bits 24-27 of `cfg` are functional: the dilation of a 3x3 kernel, 0/1 (none), 2 or 4, with padding = dilation
  * (the dilated stages of utilities/resnet.py:8-10, 201-203); pass the same value to all three directions.
  * ------------------------------------------------------------------------------------------- */
+int uaps_conv_set_mode(int mode);      /* 0 / 1 as above; process-wide, not stream-ordered: set it between steps */
+int uaps_conv_get_mode(void);
+/* both packed buffers hold the fp32 layout followed by the bf16-split layout; they must be 16-byte aligned */
 int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);
 int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream);
 /* n convolutions packed by one launch (host arrays with n entries; wf[i] or wb[i] may be NULL). */

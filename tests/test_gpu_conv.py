@@ -9,6 +9,17 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["split", "exact"])
+def conv_mode(request):
+    """Every test of this file runs in both arithmetic modes of the convolution kernels: the three-way bf16 split on the
+    bf16 matrix pipe (the default) and the fp32 matrix instruction."""
+    from uaps_amd import conv
+    prev = conv.get_mode()
+    conv.set_mode(request.param)
+    yield request.param
+    conv.set_mode(prev)
+
 # (B, Cin, Cout, H, W, ks)
 SHAPES = [
     (2, 3, 16, 32, 32, 3),      # first encoder conv (Cin padded to 4)
@@ -179,3 +190,37 @@ def test_dilated_conv_vs_torch_cpu(B, Cin, Cout, H, W, dil):
         scale = float(ref.abs().max()) + 1e-12
         err = float((got.cpu() - ref).abs().max())
         assert err <= 2e-5 * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [(4, 64, 64, 64, 64, 3), (2, 16, 16, 256, 256, 3), (4, 256, 128, 16, 16, 1), (2, 3, 16, 128, 128, 3),
+                                               (2, 128, 128, 32, 32, 3)])
+def test_split_mode_is_as_accurate_as_the_fp32_matrix_instruction(B, Cin, Cout, H, W, ks, conv_mode):
+    """The bf16-split kernels claim fp32 accuracy: measured against a float64 reference, their forward / input-gradient
+    error must be of the size of the exact fp32 kernels' (both are a few 1e-7 of sum |a*b|), on inputs with a wide
+    dynamic range (log-normal magnitudes) so that all three pieces of every operand matter."""
+    if conv_mode != "split":
+        pytest.skip("compares the two modes itself")
+    from uaps_amd import conv
+    g = torch.Generator().manual_seed(B * 7 + Cin + ks)
+    x = torch.randn(B, Cin, H, W, generator=g) * torch.exp(2.0 * torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) * torch.exp(torch.randn(Cout, Cin, ks, ks, generator=g)) / np.sqrt(Cin * ks * ks)
+    dy = torch.randn(B, Cout, H, W, generator=g) * torch.exp(2.0 * torch.randn(B, Cout, H, W, generator=g))
+    xr, wr = x.double().requires_grad_(True), w.double()
+    yr = F.conv2d(xr, wr, None, padding=ks // 2)
+    yr.backward(dy.double())
+    mag_y = F.conv2d(x.double().abs(), wr.abs(), None, padding=ks // 2)                     # sum |a*b| per output
+    mag_dx = torch.nn.grad.conv2d_input(x.shape, wr.abs(), dy.double().abs(), padding=ks // 2)
+    dev = torch.device("cuda:0")
+    errs = {}
+    for mode in ("split", "exact"):
+        conv.set_mode(mode)
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev)
+        y = conv.conv2d(xg, wg)
+        y.backward(dy.to(dev))
+        errs[mode] = (float(((y.detach().cpu().double() - yr.detach()).abs() / mag_y).max()),
+                      float(((xg.grad.cpu().double() - xr.grad).abs() / mag_dx).max()))
+    conv.set_mode("split")
+    print(errs)
+    for i, what in enumerate(("y", "dx")):
+        assert errs["split"][i] < 1.5 * errs["exact"][i] + 1e-7, (what, errs)
+        assert errs["split"][i] < 5e-6, (what, errs)                       # both are a few fp32 roundings of sum |a*b| (K up to 2304)

@@ -49,6 +49,8 @@ SIGNATURES = {
     "uaps_bn_act_bwd_eval": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [C.c_int] * 4 + [_PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_up_cat_fwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 5 + [_PTR]),
     "uaps_up_cat_bwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 5 + [_PTR]),
+    "uaps_conv_set_mode": (C.c_int, [C.c_int]),
+    "uaps_conv_get_mode": (C.c_int, []),
     "uaps_conv_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "uaps_conv_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
     "uaps_conv_pack_weights_batch": (C.c_int, [_PTR] * 6 + [C.c_int, _PTR]),

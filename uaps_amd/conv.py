@@ -60,7 +60,8 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
         _lib.check(rc, "uaps_conv_*_variant")
         name = buf.value.decode()
         if kind.endswith("_bn"):      # the variants that apply BatchNorm + LeakyReLU while staging (fused._BnActConv)
-            name = name.replace("conv_fwd_kernel", "conv_fwd_bn_kernel").replace("conv_wrw_kernel", "conv_wrw_bn_kernel")
+            name = (name.replace("conv_fwd_kernel", "conv_fwd_bn_kernel").replace("conv_wrw_kernel", "conv_wrw_bn_kernel")
+                    .replace("conv_sfwd_kernel", "conv_sfwd_bn_kernel").replace("conv_s32_kernel", "conv_s32_bn_kernel").replace("conv_swrw_kernel", "conv_swrw_bn_kernel"))
         _variant_cache[key] = name
     return name
 
@@ -84,6 +85,19 @@ class _timed:
             self.e.record()
             KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e, self.flops))
         return False
+
+
+def set_mode(mode) -> None:
+    """Arithmetic of the convolution kernels: 'split' / 1 (default) = exact three-way bf16 split of both fp32 operands on the
+    bf16 matrix pipe (csrc/conv_split.hpp, fp32-chain accuracy at 2.67x the fp32 matrix rate), 'exact' / 0 = the fp32 matrix
+    instruction everywhere.  Process-wide; also UAPS_CONV_MODE=0/1 in the environment."""
+    m = {"split": 1, "exact": 0, "f32": 0}.get(mode, mode)
+    _lib.check(_lib.lib().uaps_conv_set_mode(int(m)), "uaps_conv_set_mode")
+    _variant_cache.clear()
+
+
+def get_mode() -> str:
+    return "split" if _lib.lib().uaps_conv_get_mode() == 1 else "exact"
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:

@@ -2,8 +2,27 @@
 // (include/uaps_hip.h, section "Convolutions").
 #include "../../include/uaps_hip.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include "conv_kernels.hpp"
+#include "conv_split.hpp"
 using namespace uaps;
+
+// 0 = exact fp32 matrix instructions (v_mfma_f32_16x16x4_f32), 1 = exact 3-way bf16 split on the bf16 matrix pipe
+// (conv_split.hpp; the default).  Initialised from UAPS_CONV_MODE, switchable with uaps_conv_set_mode.
+static int g_conv_mode = -1;
+static int conv_mode() {
+    if (g_conv_mode < 0) {
+        const char* e = getenv("UAPS_CONV_MODE");
+        g_conv_mode = (e && (e[0] == '0' || e[0] == 'e' || e[0] == 'f')) ? 0 : 1;      // "0" / "exact" / "f32"
+    }
+    return g_conv_mode;
+}
+extern "C" int uaps_conv_set_mode(int mode) {
+    if (mode != 0 && mode != 1) return UAPS_EINVAL;
+    g_conv_mode = mode;
+    return UAPS_OK;
+}
+extern "C" int uaps_conv_get_mode(void) { return conv_mode(); }
 
 namespace {
 
@@ -51,7 +70,42 @@ int dispatch_dilated(const ConvFwdArgs& a, int bn, bool vec, int xl, hipStream_t
     return launch_fwd<3, 8, 32, 64, 8, DIL>(a, vec, xl, s);
 }
 
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; };
+// ---- split-bf16 kernels (conv_split.hpp): 16-byte rows only, no dilation ----
+template <int KS, int TH, int TW, int BN, int CK>
+int launch_sfwd(ConvFwdArgs a, hipStream_t s) {
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    a.nblk = a.CoutP / BN;
+    const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.xf) hipLaunchKernelGGL((conv_sfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_sfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+template <int KS, int TH, int TW>
+int dispatch_sfwd(const ConvFwdArgs& a, int bn, int ck, hipStream_t s) {
+    if constexpr (KS == 3) {
+        if (ck == 8) return bn == 16 ? launch_sfwd<3, TH, TW, 16, 8>(a, s) : launch_sfwd<3, TH, TW, 32, 8>(a, s);
+        return bn == 16 ? launch_sfwd<3, TH, TW, 16, 16>(a, s) : launch_sfwd<3, TH, TW, 32, 16>(a, s);
+    } else {
+        return bn == 16 ? launch_sfwd<1, TH, TW, 16, 32>(a, s) : launch_sfwd<1, TH, TW, 32, 32>(a, s);
+    }
+}
+
+template <int BN>
+int launch_s32(ConvFwdArgs a, hipStream_t s) {
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 7) / 8;
+    a.nblk = a.CoutP / BN;
+    const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.xf) hipLaunchKernelGGL((conv_s32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_s32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// split: one of the bf16-split kernels runs; s32: the 32x32x16 form (3x3, 8x32 tiles, >= 32 output channels)
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
@@ -73,6 +127,24 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     if (cfg & 0xff) { bn = cfg & 0xff; if ((bn != 16 && bn != 32 && bn != 64) || p->CoutP % bn) return UAPS_EINVAL; }
     if (p->ck == 4) bn = 16;
     p->bn = bn;
+    // the split-bf16 form: 16-byte rows, no dilation, no forced tile / LDS settings; cfg bit 28 forces the exact kernels
+    // cfg bits 29-30 select among them for tools/bench_modes.py: 1 = the 16x16x32 form, 2 = the 32x32x16 form (low byte: BN)
+    // measured (tools/bench_modes.py, B = 32): the split forms win 1.2-1.7x on every 3x3 layer with more than 8 contraction
+    // channels and lose on 1x1 convolutions (HBM-bound, the split only adds staging work) and on the <= 8-channel layers
+    // (a chunk of 8 channels fills 9 of 12 k-groups); cfg bits 29-30 != 0 force a split form regardless
+    p->split = conv_mode() == 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || ((cfg >> 29) & 3));
+    const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
+    p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);
+    p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 512) ? 32 : 16;
+    p->s32 = p->split && ks == 3 && p->tw == 32 && p->CoutP % 32 == 0 && sel != 1;
+    if (p->s32) {
+        p->sck = 8;
+        p->sbn = (p->CoutP % 64 == 0 && tiles * (p->CoutP / 64) >= 512) ? 64 : 32;
+        if (bn_req == 32 || (bn_req == 64 && p->CoutP % 64 == 0)) p->sbn = bn_req;
+    } else if (p->split && bn_req) {
+        if ((bn_req != 16 && bn_req != 32) || p->CoutP % bn_req) return UAPS_EINVAL;
+        p->sbn = bn_req;
+    }
     return UAPS_OK;
 }
 
@@ -91,12 +163,21 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     const int rc = plan_fwd(x, y, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
     if ((x2 && (uintptr_t)x2 % 16) || (y2 && (uintptr_t)y2 % 16)) p.vec = false;
+    if (!p.vec || (Csplit < Cin && Csplit % p.sck)) p.split = false;      // unaligned tensors / odd concat split: exact kernels
     ConvFwdArgs a{};
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool wide = p.tw == 32;
+    if (p.split) {
+        // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
+        a.wp = wp + (size_t)ks * ks * p.CinP * p.CoutP;
+        a.CinP = split_cgroups(Cin);
+        if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
+        if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
+        return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);
+    }
     if (p.dil == 2) return dispatch_dilated<2>(a, p.bn, p.vec, p.extra_lds, s);
     if (p.dil == 4) return dispatch_dilated<4>(a, p.bn, p.vec, p.extra_lds, s);
     if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
@@ -105,21 +186,31 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
 
 }  // namespace
 
+static PackDesc make_pack_desc(const float* w, float* wf, float* wb, int Cout, int Cin, int ks) {
+    PackDesc q{};
+    q.w = w; q.wf = wf; q.wb = wb; q.Cout = Cout; q.Cin = Cin; q.taps = ks * ks;
+    q.CinP = kdim_pad(Cin, ks); q.CoutP = ndim_pad(Cout); q.CoutPk = kdim_pad(Cout, ks); q.CinPn = ndim_pad(Cin);
+    q.CGf = split_cgroups(Cin); q.CGb = split_cgroups(Cout);
+    return q;
+}
+
+// Sizes (in floats) of the two packed buffers of a convolution: each holds the exact fp32 layout followed by the
+// three-piece bf16 layout of conv_split.hpp (3 * taps * groups * channels * 16 bytes).
 extern "C" int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats, size_t* bwd_floats) {
     if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) return UAPS_EINVAL;
     const size_t taps = (size_t)ks * ks;
-    if (fwd_floats) *fwd_floats = taps * kdim_pad(Cin, ks) * ndim_pad(Cout);
-    if (bwd_floats) *bwd_floats = taps * kdim_pad(Cout, ks) * ndim_pad(Cin);
+    if (fwd_floats) *fwd_floats = taps * kdim_pad(Cin, ks) * ndim_pad(Cout) + 3 * taps * split_cgroups(Cin) * ndim_pad(Cout) * 4;
+    if (bwd_floats) *bwd_floats = taps * kdim_pad(Cout, ks) * ndim_pad(Cin) + 3 * taps * split_cgroups(Cout) * ndim_pad(Cin) * 4;
     return UAPS_OK;
 }
 
 extern "C" int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream) {
     if (!w || Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3) || (!wf && !wb)) return UAPS_EINVAL;
-    const int taps = ks * ks;
-    const long n = (long)taps * (kdim_pad(Cin, ks) * ndim_pad(Cout) + kdim_pad(Cout, ks) * ndim_pad(Cin));
+    if (((uintptr_t)wf | (uintptr_t)wb) % 16) return UAPS_EINVAL;
+    const PackDesc q = make_pack_desc(w, wf, wb, Cout, Cin, ks);
+    const long n = conv_pack_elems(q);
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wf, wb, Cout, Cin, taps,
-                       kdim_pad(Cin, ks), ndim_pad(Cout), kdim_pad(Cout, ks), ndim_pad(Cin));
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
 
@@ -134,10 +225,9 @@ extern "C" int uaps_conv_pack_weights_batch(const float* const* w, float* const*
         for (int i = 0; i < m; ++i) {
             const int k = base + i;
             if (!w[k] || Cout[k] <= 0 || Cin[k] <= 0 || (ks[k] != 1 && ks[k] != 3)) return UAPS_EINVAL;
-            PackDesc& q = pb.d[i];
-            q.w = w[k]; q.wf = wf[k]; q.wb = wb[k]; q.Cout = Cout[k]; q.Cin = Cin[k]; q.taps = ks[k] * ks[k];
-            q.CinP = kdim_pad(Cin[k], ks[k]); q.CoutP = ndim_pad(Cout[k]); q.CoutPk = kdim_pad(Cout[k], ks[k]); q.CinPn = ndim_pad(Cin[k]);
-            const long e = (long)q.taps * ((long)q.CinP * q.CoutP + (long)q.CoutPk * q.CinPn);
+            if (((uintptr_t)wf[k] | (uintptr_t)wb[k]) % 16) return UAPS_EINVAL;
+            pb.d[i] = make_pack_desc(w[k], wf[k], wb[k], Cout[k], Cin[k], ks[k]);
+            const long e = conv_pack_elems(pb.d[i]);
             if (e > most) most = e;
         }
         const int bx = (int)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);
@@ -209,6 +299,8 @@ extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int
     const int rc = plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
     if (!buf || buflen < 64) return UAPS_EINVAL;
-    snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);
+    if (p.s32) snprintf(buf, buflen, "conv_s32_kernel<%d>", p.sbn);
+    else if (p.split) snprintf(buf, buflen, "conv_sfwd_kernel<%d, %d, %d, %d, %d>", ks, p.th, p.tw, p.sbn, p.sck);
+    else snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);
     return UAPS_OK;
 }

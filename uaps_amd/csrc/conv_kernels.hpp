@@ -664,52 +664,6 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __res
     }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Weight packing: w [Cout][Cin][KS][KS] (nn.Conv2d.weight) ->
-//   wf [tap][CinP][CoutP]            wf[t][ci][co] = w[co][ci][t]            (forward)
-//   wb [tap][CoutPk][CinPn]          wb[T-1-t][co][ci] = w[co][ci][t]        (input gradient)
-// zero padded; either output may be null.
-// -------------------------------------------------------------------------------------------------
-static __global__ void conv_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wb,
-                                                int Cout, int Cin, int taps, int CinP, int CoutP, int CoutPk, int CinPn) {
-    const long nf = (long)taps * CinP * CoutP, nbk = (long)taps * CoutPk * CinPn;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nbk; e += (long)gridDim.x * blockDim.x) {
-        if (e < nf) {
-            if (!wf) continue;
-            const int co = (int)(e % CoutP); const long r = e / CoutP;
-            const int ci = (int)(r % CinP), t = (int)(r / CinP);
-            wf[e] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + t] : 0.f;
-        } else {
-            if (!wb) continue;
-            const long f = e - nf;
-            const int ci = (int)(f % CinPn); const long r = f / CinPn;
-            const int co = (int)(r % CoutPk), t = (int)(r / CoutPk);
-            wb[f] = (co < Cout && ci < Cin) ? w[((long)co * Cin + ci) * taps + (taps - 1 - t)] : 0.f;
-        }
-    }
-}
-
-// One launch for up to kPackBatch convolutions (the whole U-Net has 62): blockIdx.y selects the descriptor.
-constexpr int kPackBatch = 64;
-struct PackDesc { const float* w; float* wf; float* wb; int Cout, Cin, taps, CinP, CoutP, CoutPk, CinPn; };
-struct PackBatch { PackDesc d[kPackBatch]; };
-static __global__ void conv_pack_weights_batch_kernel(PackBatch pb) {
-    const PackDesc& q = pb.d[blockIdx.y];
-    const long nf = (long)q.taps * q.CinP * q.CoutP, nbk = (long)q.taps * q.CoutPk * q.CinPn;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nf + nbk; e += (long)gridDim.x * blockDim.x) {
-        if (e < nf) {
-            if (!q.wf) continue;
-            const int co = (int)(e % q.CoutP); const long r = e / q.CoutP;
-            const int ci = (int)(r % q.CinP), t = (int)(r / q.CinP);
-            q.wf[e] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + t] : 0.f;
-        } else {
-            if (!q.wb) continue;
-            const long f = e - nf;
-            const int ci = (int)(f % q.CinPn); const long r = f / q.CinPn;
-            const int co = (int)(r % q.CoutPk), t = (int)(r / q.CoutPk);
-            q.wb[f] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + (q.taps - 1 - t)] : 0.f;
-        }
-    }
-}
+// (weight packing, exact and split layouts: conv_split.hpp)
 
 }  // namespace uaps

@@ -1,0 +1,620 @@
+// fp32 convolutions on the bf16 matrix pipe: every fp32 operand is split EXACTLY into three bf16 pieces
+// (x = x0 + x1 + x2, 8 + 8 + 8 significant bits) and each product a*b is evaluated as the six partial products of weight
+// >= 2^-16 (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0; the dropped a1b2 + a2b1 + a2b2 are <= 3 * 2^-24 |ab|, the size of one fp32
+// rounding), all accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  The result carries the error of an fp32 fmaf chain
+// (tests/test_gpu_conv.py compares both paths with a float64 reference), while six bf16 MFMAs of depth 32 take 96 cycles
+// where eight fp32 MFMAs of depth 4 take 256: 2.67x the contraction rate of v_mfma_f32_16x16x4_f32.
+//
+// Same contract as conv_fwd_kernel (conv_kernels.hpp): NCHW fp32 tensors in and out, replaces the nn.Conv2d forward /
+// input gradient of utilities/UAPS_unet.py:36-44, 73, 138.  GEMM view M = pixels, N = output channels, K = (tap, channel).
+//   * a k-group (the 8 consecutive k of one lane, `8*(lane>>4)+j`) is 8 input channels at one tap; an MFMA step is 4
+//     k-groups.  LDS image of the haloed input tile: [piece][channel group][row][column] of 16-byte units (8 channels
+//     of one pixel), so the A fragment of 16 consecutive pixels is one conflict-free ds_read_b128 per piece: the four
+//     16-lane groups the hardware services together read 256 contiguous bytes when their bases agree modulo 256 B,
+//     which holds for k-groups that differ in the channel group only (plane size is a multiple of 256 B);
+//   * weights are pre-split and pre-packed [piece][tap][channel group][Cout][8] once per optimizer step, a chunk's
+//     slice is a plain copy into LDS [piece][k-group][BN];
+//   * the split happens once per staged element (5.5 VALU operations, conv_split3) and is reused by all BN output
+//     channels and all taps.
+#pragma once
+#include "conv_kernels.hpp"
+
+namespace uaps {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> three dwords of packed bf16 pairs (low half = a's piece, high half = b's) with a = a0 + a1 + a2 exactly
+// (round-to-nearest pieces: the residual of an 8-bit rounding has at most 16 significant bits, the next at most 8).
+__device__ __forceinline__ void conv_split3(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    p0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+    const float ra = a - __builtin_bit_cast(float, p0 << 16), rb = b - __builtin_bit_cast(float, p0 & 0xffff0000u);
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{ra, rb}, bf16x2));
+    const float sa = ra - __builtin_bit_cast(float, p1 << 16), sb = rb - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
+}
+
+// number of 8-channel groups of the packed split weights for C contraction channels: padded to a multiple of 4 groups so
+// that any channel chunk (8, 16 or 32 channels) stays inside one tap's rows and reads zeros past the last channel
+__host__ __device__ constexpr int split_cgroups(int C) { return ((C + 7) / 8 + 3) / 4 * 4; }
+
+// Two workgroups share a CU (one wave of each per SIMD) and run the same program from the same start: with fair
+// arbitration they stay in lockstep -- both in their MFMA phase (sharing the matrix pipe), then both in their staging phase
+// (pipe idle; measured: 49 % MFMA busy, SQ_WAIT_INST_ANY 63 % of a wave's life).  A static priority for the wave in the odd
+// hardware slot of each SIMD lets that workgroup run its MFMA phase at full rate while the other takes the pipe during the
+// first one's staging phase: the two fall into opposite phases.  Speed only.
+__device__ __forceinline__ void stagger_by_wave_slot() {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);     // HW_REG_HW_ID[3:0] = WAVE_ID
+    if (wave_slot & 1) __builtin_amdgcn_s_setprio(1);
+}
+
+template <int KS, int TH, int TW> struct SplitGeom {
+    static constexpr int PAD = KS / 2;
+    static constexpr int XOFF = PAD ? 4 : 0;
+    static constexpr int IH = TH + 2 * PAD, IW = TW + 2 * XOFF;
+    static constexpr int PLANE = IH * IW;                 // 16-byte units of one (piece, channel group) plane
+    static constexpr int UPR = IW / 4, NUNITS_PER_CG = IH * UPR;
+    static_assert(PLANE % 16 == 0, "planes must be multiples of 256 bytes");
+};
+
+// CK = channels per chunk (8, 16, 32); BN = output channels per workgroup (16, 32); XF as in conv_fwd_body
+template <int KS, int TH, int TW, int BN, int CK, bool XF>
+__device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
+    using G = SplitGeom<KS, TH, TW>;
+    constexpr int TAPS = KS * KS, NCG = CK / 8, NQ = TAPS * NCG, NSTEP = (NQ + 3) / 4, NQP = NSTEP * 4;
+    constexpr int IW = G::IW, PLANE = G::PLANE, XS = G::XOFF - G::PAD;
+    constexpr int MT = TH * TW / 16, MW = MT / 4, NW = BN / 16, XB = TW / 16;
+    constexpr int NUNITS = NCG * G::NUNITS_PER_CG;
+    constexpr int NWU = 3 * NQP * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
+    static_assert(NUNITS <= kConvThreads, "one staging unit (4 pixels x 8 channels) per thread");
+    static_assert(MT % 4 == 0 && BN % 16 == 0, "tile shape");
+    static_assert(3 * NCG * PLANE * 16 >= 16 * BN * 2 * 4, "the statistics epilogue reuses sIn");
+
+    __shared__ __attribute__((aligned(16))) u32x4 sIn[3 * NCG * PLANE];
+    __shared__ __attribute__((aligned(16))) u32x4 sW[3 * NQP * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (bid >= a.B * a.tiles_x * a.tiles_y * a.nblk) return;
+    stagger_by_wave_slot();
+    const int nb = bid % a.nblk; bid /= a.nblk;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, co0 = nb * BN;
+    const int HW = a.H * a.W;
+    const uint32_t HW4 = (uint32_t)HW * 4u;
+
+    // ---- staging plan: this thread's unit = 4 consecutive pixels x the 8 channels of one channel group ----
+    const bool has_unit = tid < NUNITS;
+    const int ucg = tid / G::NUNITS_PER_CG, urem = tid % G::NUNITS_PER_CG, ur = urem / G::UPR, ucu = urem % G::UPR;
+    const int ugy = y0 - G::PAD + ur, ugx = x0 - G::XOFF + ucu * 4;
+    const bool uin = has_unit && (unsigned)ugy < (unsigned)a.H && (unsigned)ugx < (unsigned)a.W;
+    const uint32_t ugoff = (uint32_t)(ucg * 8 * HW + ugy * a.W + ugx) * 4u;
+    const int uloff = (ucg * G::IH + ur) * IW + ucu * 4;
+    // weights: unit e = (piece, k-group q, n); the chunk advances the channel group by NCG rows of CoutP units
+    const int CGP = a.CinP;                           // for the split kernels ConvFwdArgs::CinP carries the padded group count
+    uint32_t wgoff[NWT];
+    int wloff[NWT];
+#pragma unroll
+    for (int n = 0; n < NWT; ++n) {
+        const int e = tid + n * kConvThreads;
+        const int col = e % BN, row = e / BN, piece = row / NQP, q = row % NQP, tap = q / NCG, cg = q % NCG;
+        const bool ok = e < NWU && q < NQ;
+        wgoff[n] = ok ? (uint32_t)(((piece * TAPS + tap) * CGP + cg) * a.CoutP + co0 + col) * 16u : kOob;
+        wloff[n] = e < NWU ? e : -1;
+    }
+    const float* in_b = a.in + (size_t)b * a.Csplit * HW;
+    const float* in2_b = a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(3 * TAPS) * CGP * a.CoutP * 16u);
+    const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u)
+                                            : make_rsrc(a.wp, 0);
+
+    float rin[8][4];
+    u32x4 rw[NWT];
+    f32x2 rxf[XF ? 8 : 1];
+
+    auto load_chunk = [&](int ci0) {
+        const bool second = ci0 >= a.Csplit;        // the chunk lies in one source (Csplit % CK == 0)
+        const __amdgpu_buffer_rsrc_t rs_in = second
+            ? make_rsrc(in2_b + (size_t)(ci0 - a.Csplit) * HW, (uint32_t)(a.Cin - ci0) * HW4)
+            : make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Csplit - ci0) * HW4);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) buf_load<4>(rs_in, uin ? ugoff + (uint32_t)c * HW4 : kOob, rin[c]);
+        if constexpr (XF) {                          // padding pixels and channels past Cin read (0, 0): the unit stays zero
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                    rs_xf, uin ? (int)((uint32_t)(ci0 + ucg * 8 + c) * 8u) : (int)kOob, 0, 0));
+        }
+        const uint32_t wbase = (uint32_t)(ci0 / 8) * a.CoutP * 16u;
+#pragma unroll
+        for (int n = 0; n < NWT; ++n)
+            rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wgoff[n] == kOob ? kOob : wgoff[n] + wbase), 0, 0));
+    };
+    // split of the fetched unit into packed pieces pk[piece][pixel] (16 bytes = 8 channels each); one call handles the channel
+    // pair c2 of pixel p.  XF: leaky_relu(fma(y, scale, shift)) first; leaky_relu(z) = max(z, slope * z)
+    u32x4 pk[3][4];
+    auto split_pair = [&](int idx) {
+        const int p = idx / 4, c2 = idx % 4;
+        float v0 = rin[2 * c2][p], v1 = rin[2 * c2 + 1][p];
+        if constexpr (XF) {
+            const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
+            v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
+        }
+        unsigned q0, q1, q2;
+        conv_split3(v0, v1, q0, q1, q2);
+        pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+    };
+    auto store_chunk = [&]() {
+        if (has_unit) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                sIn[uloff + p] = pk[0][p];
+                sIn[NCG * PLANE + uloff + p] = pk[1][p];
+                sIn[2 * NCG * PLANE + uloff + p] = pk[2][p];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NWT; ++n)
+            if (wloff[n] >= 0) sW[wloff[n]] = rw[n];
+    };
+
+    f32x4 acc[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int n = 0; n < NW; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // A operand: lane (pixel j, k-group kq) of M tile mt reads unit abase[m] + astep[s] (+ piece plane)
+    int abase[MW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+        const int mt = wave * MW + m;
+        abase[m] = (mt / XB) * IW + (mt % XB) * 16 + j + XS;
+    }
+    int astep[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int q = 4 * s + kq, tap = q / NCG, cg = q % NCG;
+        astep[s] = q < NQ ? cg * PLANE + (tap / KS) * IW + (tap % KS) : 0;     // padded k-groups meet zero weights
+    }
+    const int boff = kq * BN + j;
+
+    // The MFMA phase of a chunk is NSTEP * MW units (step s, M tile m) of 6 * NW MFMAs.  The A fragments of unit u + 1 (and,
+    // at a step boundary, the B fragments of the next step) are read from LDS before the MFMAs of unit u issue, and the split
+    // of the NEXT chunk's fetched unit (16 channel pairs) is spread over the units behind step 0, in the matrix pipe's shadow.
+    constexpr int NU = NSTEP * MW;
+    constexpr int U0 = NSTEP > 1 ? MW : NU;          // first unit that carries split work (loads were issued NU - U0 units ago)
+    constexpr bool SPLIT_IN_LOOP = NSTEP > 1;
+    const int nchunks = (a.Cin + CK - 1) / CK;
+    load_chunk(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) split_pair(i);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk((ch + 1) * CK);
+        bf16x8 af[2][3], bfr[2][NW][3];
+        auto read_a = [&](int u, bf16x8 (&dst)[3]) {
+            const int s = u / MW, m = u % MW;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * NCG * PLANE + abase[m] + astep[s]]);
+        };
+        auto read_b = [&](int s, bf16x8 (&dst)[NW][3]) {
+#pragma unroll
+            for (int n = 0; n < NW; ++n)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 4 * s) * BN + boff + n * 16]);
+        };
+        read_b(0, bfr[0]);
+        read_a(0, af[0]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int s = u / MW, m = u % MW;
+            const bool new_b = u + 1 < NU && (u + 1) % MW == 0;
+            if (u + 1 < NU) read_a(u + 1, af[(u + 1) & 1]);
+            if (new_b) read_b(s + 1, bfr[(s + 1) & 1]);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {           // smallest partial products first
+                f32x4 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], bfr[s & 1][n][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], bfr[s & 1][n][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], bfr[s & 1][n][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], bfr[s & 1][n][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], bfr[s & 1][n][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], bfr[s & 1][n][0], c, 0, 0, 0);
+                acc[m][n] = c;
+            }
+            if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * NW, 0);                            // next unit's DS reads first ...
+            else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NW, 0);                                          // ... then this unit's MFMAs
+            if constexpr (SPLIT_IN_LOOP) {           // unconditional (stale registers when no chunk follows): straight-line code
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (u == U0 + i * (NU - U0) / 16) split_pair(i);
+            }
+        }
+        if constexpr (!SPLIT_IN_LOOP) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) split_pair(i);
+        }
+        __syncthreads();
+        if (more) store_chunk();
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every tile (same C/D map as 16x16x4) ----
+    float st_s[NW], st_q[NW];
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+        st_s[n] = 0.f; st_q[n] = 0.f;
+        const int co = co0 + n * 16 + j;
+        const bool co_ok = co < a.Cout;
+        const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+        const int coc = co_ok ? co : 0;
+        float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
+                                      : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int mt = wave * MW + m;
+            const int gy = y0 + mt / XB, gx = x0 + (mt % XB) * 16 + kq * 4;
+            f32x4 v = acc[m][n];
+            v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+            const bool ok = co_ok && gy < a.H && gx < a.W;      // W % 4 == 0: the 4 pixels are all inside or all outside
+            if (ok) {
+                *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
+                st_s[n] += (v.x + v.y) + (v.z + v.w);
+                st_q[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        }
+    }
+    if (a.stats != nullptr) {                    // per-tile BatchNorm partial sums, fixed order (see conv_fwd_body)
+        float* red = reinterpret_cast<float*>(sIn);
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            red[((wave * 4 + kq) * BN + n * 16 + j) * 2 + 0] = st_s[n];
+            red[((wave * 4 + kq) * BN + n * 16 + j) * 2 + 1] = st_q[n];
+        }
+        __syncthreads();
+        if (tid < BN && co0 + tid < a.Cout) {
+            float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0 += red[(r * BN + tid) * 2]; q0 += red[(r * BN + tid) * 2 + 1]; }
+            const int tpi = a.tiles_x * a.tiles_y;
+            a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
+        }
+    }
+}
+
+template <int KS, int TH, int TW, int BN, int CK>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_sfwd_kernel(ConvFwdArgs a) {
+    conv_sfwd_body<KS, TH, TW, BN, CK, false>(a);
+}
+template <int KS, int TH, int TW, int BN, int CK>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_sfwd_bn_kernel(ConvFwdArgs a) {
+    conv_sfwd_body<KS, TH, TW, BN, CK, true>(a);
+}
+
+// -------------------------------------------------------------------------------------------------
+// 3x3 forward / input gradient for >= 32 output channels on v_mfma_f32_32x32x16_bf16 (same split arithmetic).
+// The limit of the 16x16x32 kernel above is not the matrix pipe but the SIMD's instruction issue: each MFMA holds it for 8
+// of its 16 cycles and the LDS fragment reads, the split VALU work and the staging stores of two co-resident waves fill the
+// rest.  This form issues half as many MFMAs for the same work (32 cycles each), stages 8 channels per chunk (the 9 taps
+// are 9 k-groups = 4.5 -> 5 MFMA depths of 2 k-groups, 90 % of the pipe instead of 75 %), gives every wave a 64-pixel x BN
+// block (BN = 64: 0.5 LDS fragment reads per MFMA instead of 0.75) and lets two threads share a staging unit (88 split
+// operations per wave and chunk instead of 176).  M tile = the 32 consecutive pixels of one tile row: a fragment read is
+// 512 contiguous bytes per k-group, conflict-free for any tap offset.
+// Tile 8 x 32 pixels, 4 waves = 2 rows each; LDS 19.2 KB input + 3 * 10 * BN * 16 B weights (30.7 KB at BN = 64).
+// -------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int BN, bool XF>
+__device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 8, PLANE = IH * IW, XS = 3;     // rows start 4 floats left of the tile
+    constexpr int NQ = 9, NKS = 5, NQP = 2 * NKS;
+    constexpr int NT = BN / 32;                       // 32-channel N tiles per wave (every wave covers all BN channels)
+    constexpr int NHU = IH * (IW / 2);                // staging half-units: 2 consecutive pixels x 8 channels
+    constexpr int NWU = 3 * NQ * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
+    static_assert(NHU <= kConvThreads, "one half-unit per thread");
+
+    __shared__ __attribute__((aligned(16))) u32x4 sIn[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) u32x4 sW[3 * NQP * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (bid >= a.B * a.tiles_x * a.tiles_y * a.nblk) return;
+    stagger_by_wave_slot();
+    const int nb = bid % a.nblk; bid /= a.nblk;
+    const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty = bid % a.tiles_y;
+    const int b = bid / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, co0 = nb * BN;
+    const int HW = a.H * a.W;
+    const uint32_t HW4 = (uint32_t)HW * 4u;
+
+    // ---- staging plan ----
+    const bool has_unit = tid < NHU;
+    const int ur = tid / (IW / 2), uc = tid % (IW / 2);
+    const int ugy = y0 - 1 + ur, ugx = x0 - 4 + uc * 2;
+    const bool uin = has_unit && (unsigned)ugy < (unsigned)a.H && (unsigned)ugx < (unsigned)a.W;      // W % 4 == 0: both pixels in or out
+    const uint32_t ugoff = (uint32_t)(ugy * a.W + ugx) * 4u;
+    const int uloff = ur * IW + uc * 2;
+    const int CGP = a.CinP;
+    uint32_t wgoff[NWT];
+    int wloff[NWT];
+#pragma unroll
+    for (int n = 0; n < NWT; ++n) {
+        const int e = tid + n * kConvThreads;
+        const int col = e % BN, row = e / BN, piece = row / NQ, q = row % NQ;
+        wgoff[n] = e < NWU ? (uint32_t)(((piece * NQ + q) * CGP) * a.CoutP + co0 + col) * 16u : kOob;
+        wloff[n] = e < NWU ? (piece * NQP + q) * BN + col : -1;
+    }
+    // the padded k-group (slot 9 of every piece) meets zero weights: written once
+    for (int e = tid; e < 3 * BN; e += kConvThreads) sW[((e / BN) * NQP + NQ) * BN + e % BN] = u32x4{0u, 0u, 0u, 0u};
+
+    const float* in_b = a.in + (size_t)b * a.Csplit * HW;
+    const float* in2_b = a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW;
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(3 * NQ) * CGP * a.CoutP * 16u);
+    const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u)
+                                            : make_rsrc(a.wp, 0);
+
+    f32x2 rin[8];
+    u32x4 rw[NWT];
+    f32x2 rxf[XF ? 8 : 1];
+    u32x4 pk[3][2];
+
+    auto load_chunk = [&](int ci0) {
+        const bool second = ci0 >= a.Csplit;        // the chunk lies in one source (Csplit % 8 == 0)
+        const __amdgpu_buffer_rsrc_t rs_in = second
+            ? make_rsrc(in2_b + (size_t)(ci0 - a.Csplit) * HW, (uint32_t)(a.Cin - ci0) * HW4)
+            : make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Csplit - ci0) * HW4);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            rin[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, uin ? (int)(ugoff + (uint32_t)c * HW4) : (int)kOob, 0, 0));
+        if constexpr (XF) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                    rs_xf, uin ? (int)((uint32_t)(ci0 + c) * 8u) : (int)kOob, 0, 0));
+        }
+        const uint32_t wbase = (uint32_t)(ci0 / 8) * a.CoutP * 16u;
+#pragma unroll
+        for (int n = 0; n < NWT; ++n)
+            rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wgoff[n] == kOob ? kOob : wgoff[n] + wbase), 0, 0));
+    };
+    auto split_pair = [&](int idx) {                 // channel pair c2 of pixel p
+        const int p = idx / 4, c2 = idx % 4;
+        float v0 = rin[2 * c2][p], v1 = rin[2 * c2 + 1][p];
+        if constexpr (XF) {
+            const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
+            v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
+        }
+        unsigned q0, q1, q2;
+        conv_split3(v0, v1, q0, q1, q2);
+        pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+    };
+    auto store_chunk = [&]() {
+        if (has_unit) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                sIn[uloff + p] = pk[0][p];
+                sIn[PLANE + uloff + p] = pk[1][p];
+                sIn[2 * PLANE + uloff + p] = pk[2][p];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NWT; ++n)
+            if (wloff[n] >= 0) sW[wloff[n]] = rw[n];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    // A: lane (pixel r, half h) of the wave's row m reads unit abase[m] + kstep[ks]; k-group q = 2 ks + h is tap q
+    int abase[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) abase[m] = (wave * 2 + m) * IW + r + XS;
+    int kstep[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int q = 2 * ks + h;
+        kstep[ks] = q < NQ ? (q / 3) * IW + (q % 3) : 0;
+    }
+    const int boff = h * BN + r;
+
+    constexpr int NU = NKS * 2;                       // units (k-step, row) of 6 * NT MFMAs
+    const int nchunks = (a.Cin + 7) / 8;
+    load_chunk(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split_pair(i);
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk((ch + 1) * 8);
+        bf16x8 af[2][3], bfr[2][NT][3];
+        auto read_a = [&](int u, bf16x8 (&dst)[3]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * PLANE + abase[u % 2] + kstep[u / 2]]);
+        };
+        auto read_b = [&](int ks, bf16x8 (&dst)[NT][3]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 2 * ks) * BN + boff + n * 32]);
+        };
+        read_b(0, bfr[0]);
+        read_a(0, af[0]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int ks = u / 2, m = u % 2;
+            const bool new_b = u + 1 < NU && (u + 1) % 2 == 0;
+            if (u + 1 < NU) read_a(u + 1, af[(u + 1) & 1]);
+            if (new_b) read_b(ks + 1, bfr[(ks + 1) & 1]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {           // smallest partial products first
+                f32x16 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][2], bfr[ks & 1][n][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][0], bfr[ks & 1][n][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][1], bfr[ks & 1][n][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][1], bfr[ks & 1][n][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][0], bfr[ks & 1][n][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][0], bfr[ks & 1][n][0], c, 0, 0, 0);
+                acc[m][n] = c;
+            }
+            if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * NT, 0);
+            else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+            if (u >= 2) split_pair(u - 2);            // the next chunk's 8 channel pairs, one per unit behind the first k-step
+        }
+        __syncthreads();
+        if (more) store_chunk();
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D of 32x32: lane (n = r, h) register i holds pixel 8 (i >> 2) + 4 h + (i & 3) of channel n ----
+    float st_s[NT], st_q[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        st_s[n] = 0.f; st_q[n] = 0.f;
+        const int co = co0 + n * 32 + r;
+        const bool co_ok = co < a.Cout;
+        const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+        const int coc = co_ok ? co : 0;
+        float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
+                                      : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int gy = y0 + wave * 2 + m;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int gx = x0 + 8 * g + 4 * h;
+                f32x4 v = f32x4{acc[m][n][4 * g] + bv, acc[m][n][4 * g + 1] + bv, acc[m][n][4 * g + 2] + bv, acc[m][n][4 * g + 3] + bv};
+                if (co_ok && gy < a.H && gx < a.W) {
+                    *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
+                    st_s[n] += (v.x + v.y) + (v.z + v.w);
+                    st_q[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+            }
+        }
+    }
+    if (a.stats != nullptr) {                    // per-tile BatchNorm partial sums: 8 partials (4 waves x 2 halves) per channel, fixed order
+        float* red = reinterpret_cast<float*>(sIn);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            red[((wave * 2 + h) * BN + n * 32 + r) * 2 + 0] = st_s[n];
+            red[((wave * 2 + h) * BN + n * 32 + r) * 2 + 1] = st_q[n];
+        }
+        __syncthreads();
+        if (tid < BN && co0 + tid < a.Cout) {
+            float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s0 += red[(k * BN + tid) * 2]; q0 += red[(k * BN + tid) * 2 + 1]; }
+            const int tpi = a.tiles_x * a.tiles_y;
+            a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
+        }
+    }
+}
+
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_s32_kernel(ConvFwdArgs a) { conv_s32_body<BN, false>(a); }
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_s32_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true>(a); }
+
+// -------------------------------------------------------------------------------------------------
+// Split weight packing: w [Cout][Cin][KS][KS] fp32 ->
+//   sf [piece][tap][CGP(Cin)][CoutP][8]     sf[p][t][g][co][j] = piece p of w[co][8g+j][t]            (forward)
+//   sb [piece][tap][CGP(Cout)][CinPn][8]    sb[p][T-1-t][g][ci][j] = piece p of w[8g+j][ci][t]       (input gradient)
+// zero padded; 16-byte units of 8 bf16.  One thread per (unit, pair of channels).
+// -------------------------------------------------------------------------------------------------
+struct SplitPackDesc { const float* w; unsigned* sf; unsigned* sb; int Cout, Cin, taps, CGf, CoutP, CGb, CinPn; };
+__device__ __forceinline__ void conv_pack_split_elem(const SplitPackDesc& q, long e) {
+    // dword index space: forward part [tap][CGf][CoutP][4 dwords], then backward part [tap][CGb][CinPn][4]
+    const long nf = (long)q.taps * q.CGf * q.CoutP * 4, nbk = (long)q.taps * q.CGb * q.CinPn * 4;
+    float v0 = 0.f, v1 = 0.f;
+    unsigned* dst;
+    long piece_stride, idx;
+    if (e < nf) {
+        if (!q.sf) return;
+        const int d = (int)(e % 4); long r = e / 4;
+        const int co = (int)(r % q.CoutP); r /= q.CoutP;
+        const int g = (int)(r % q.CGf), t = (int)(r / q.CGf);
+        const int ci = g * 8 + d * 2;
+        if (co < q.Cout && ci < q.Cin) v0 = q.w[((long)co * q.Cin + ci) * q.taps + t];
+        if (co < q.Cout && ci + 1 < q.Cin) v1 = q.w[((long)co * q.Cin + ci + 1) * q.taps + t];
+        dst = q.sf; piece_stride = nf; idx = e;
+    } else if (e < nf + nbk) {
+        if (!q.sb) return;
+        const long f = e - nf;
+        const int d = (int)(f % 4); long r = f / 4;
+        const int ci = (int)(r % q.CinPn); r /= q.CinPn;
+        const int g = (int)(r % q.CGb), t = (int)(r / q.CGb);
+        const int co = g * 8 + d * 2, tt = q.taps - 1 - t;
+        if (ci < q.Cin && co < q.Cout) v0 = q.w[((long)co * q.Cin + ci) * q.taps + tt];
+        if (ci < q.Cin && co + 1 < q.Cout) v1 = q.w[((long)(co + 1) * q.Cin + ci) * q.taps + tt];
+        dst = q.sb; piece_stride = nbk; idx = f;
+    } else {
+        return;
+    }
+    unsigned p0, p1, p2;
+    conv_split3(v0, v1, p0, p1, p2);
+    dst[idx] = p0; dst[piece_stride + idx] = p1; dst[2 * piece_stride + idx] = p2;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Weight packing, all layouts of one convolution by one kernel: w [Cout][Cin][KS][KS] (nn.Conv2d.weight) ->
+//   wf [tap][CinP][CoutP]            wf[t][ci][co] = w[co][ci][t]            (exact forward)
+//   wb [tap][CoutPk][CinPn]          wb[T-1-t][co][ci] = w[co][ci][t]        (exact input gradient)
+//   sf / sb                          the split layouts above; they FOLLOW wf / wb in the same buffers
+// zero padded; wf / wb may be null (then nothing of that direction is written).
+// -------------------------------------------------------------------------------------------------
+struct PackDesc { const float* w; float* wf; float* wb; int Cout, Cin, taps, CinP, CoutP, CoutPk, CinPn, CGf, CGb; };
+__device__ __forceinline__ void conv_pack_elem(const PackDesc& q, long e) {
+    const long nf = (long)q.taps * q.CinP * q.CoutP, nbk = (long)q.taps * q.CoutPk * q.CinPn;
+    if (e < nf) {
+        if (!q.wf) return;
+        const int co = (int)(e % q.CoutP); const long r = e / q.CoutP;
+        const int ci = (int)(r % q.CinP), t = (int)(r / q.CinP);
+        q.wf[e] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + t] : 0.f;
+    } else if (e < nf + nbk) {
+        if (!q.wb) return;
+        const long f = e - nf;
+        const int ci = (int)(f % q.CinPn); const long r = f / q.CinPn;
+        const int co = (int)(r % q.CoutPk), t = (int)(r / q.CoutPk);
+        q.wb[f] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + (q.taps - 1 - t)] : 0.f;
+    } else {
+        SplitPackDesc sp{q.w, q.wf ? reinterpret_cast<unsigned*>(q.wf + nf) : nullptr, q.wb ? reinterpret_cast<unsigned*>(q.wb + nbk) : nullptr,
+                         q.Cout, q.Cin, q.taps, q.CGf, q.CoutP, q.CGb, q.CinPn};
+        conv_pack_split_elem(sp, e - nf - nbk);
+    }
+}
+__host__ __device__ inline long conv_pack_elems(const PackDesc& q) {
+    return (long)q.taps * ((long)q.CinP * q.CoutP + (long)q.CoutPk * q.CinPn + 4L * q.CGf * q.CoutP + 4L * q.CGb * q.CinPn);
+}
+static __global__ void conv_pack_weights_kernel(PackDesc q) {
+    const long n = conv_pack_elems(q);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) conv_pack_elem(q, e);
+}
+
+// One launch for up to kPackBatch convolutions (the whole U-Net has 62): blockIdx.y selects the descriptor.
+constexpr int kPackBatch = 48;
+struct PackBatch { PackDesc d[kPackBatch]; };
+static __global__ void conv_pack_weights_batch_kernel(PackBatch pb) {
+    const PackDesc& q = pb.d[blockIdx.y];
+    const long n = conv_pack_elems(q);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) conv_pack_elem(q, e);
+}
+
+}  // namespace uaps
