@@ -39,9 +39,11 @@ def test_null_and_empty_arguments_are_refused(L):
 def test_pack_sizes_and_workspace_queries(L):
     nf, nb = C.c_size_t(), C.c_size_t()
     assert L.uaps_conv_pack_floats(16, 3, 3, C.byref(nf), C.byref(nb)) == OK
-    assert nf.value == 9 * 4 * 16 and nb.value == 9 * 16 * 16          # K padded to 4 (Cin <= 4) / 16, N padded to 16
+    # exact layout: K padded to 4 (Cin <= 4) / 16, N padded to 16; then the three-piece bf16 layout: 3 pieces x taps x
+    # channel groups (8 channels each, padded to a multiple of 4 groups) x N x 16 bytes
+    assert nf.value == 9 * 4 * 16 + 3 * 9 * 4 * 16 * 4 and nb.value == 9 * 16 * 16 + 3 * 9 * 4 * 16 * 4
     assert L.uaps_conv_pack_floats(64, 128, 1, C.byref(nf), C.byref(nb)) == OK
-    assert nf.value == 128 * 64 and nb.value == 64 * 128
+    assert nf.value == 128 * 64 + 3 * 16 * 64 * 4 and nb.value == 64 * 128 + 3 * 8 * 128 * 4
     assert L.uaps_conv_pack_floats(0, 3, 3, C.byref(nf), C.byref(nb)) == EINVAL
     assert L.uaps_conv_pack_floats(16, 3, 5, C.byref(nf), C.byref(nb)) == EINVAL          # only 1x1 and 3x3 exist
     n = C.c_size_t()
@@ -53,8 +55,15 @@ def test_pack_sizes_and_workspace_queries(L):
 
 def test_kernel_plan_names_and_statistics_tiles(L):
     buf = C.create_string_buffer(96)
+    assert L.uaps_conv_set_mode(0) == OK and L.uaps_conv_get_mode() == 0
     assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
-    assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # the bench's dominant instantiation
+    assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # exact mode: the fp32 matrix instruction
+    assert L.uaps_conv_set_mode(1) == OK and L.uaps_conv_get_mode() == 1
+    assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
+    assert buf.value.decode() == "conv_s32_kernel<32>"                                   # split mode (default): 32x32x16 bf16 form
+    assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 1 << 28, buf, 96) == OK
+    assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # cfg bit 28: exact kernels for this call
+    assert L.uaps_conv_set_mode(7) == EINVAL
     assert L.uaps_conv_fwd_variant(32, 3, 16, 256, 256, 3, 0, buf, 96) == OK
     assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 16, 4, 4, 1>"                # 3 input channels: 4-channel chunks
     assert L.uaps_conv_fwd_variant(2, 16, 16, 16, 16, 3, 0, buf, 96) == OK
