@@ -109,14 +109,17 @@ def test_bn_in_staging_convolutions_at_bench_batch_vs_torch_cpu(B, Cin, Cout, H,
         y = y.detach().requires_grad_(True)
         z = fused.bn_act_conv(y, st, None, bng, 0.01, w2g, b2g)
     z.backward(dz.to(DEV))
-    # CPU: the same raw y (copied back, so only the second stage is compared), one BatchNorm call per half
-    yc = y.detach().cpu().requires_grad_(True)
-    w2c, b2c = w2.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+    # CPU, float64 (the sums behind dgamma / dbeta / dw run over 10^6..10^7 terms: an fp32 reference would carry more error
+    # than the kernels): the same raw y (copied back, so only the second stage is compared), one BatchNorm call per half
+    bnd = copy.deepcopy(bn).double()
+    yc = y.detach().cpu().double().requires_grad_(True)
+    w2c, b2c = w2.double().requires_grad_(True), b2.double().requires_grad_(True)
     h = B // 2
-    pre = torch.cat([bn(yc[:h]), bn(yc[h:])], 0)
+    pre = torch.cat([bnd(yc[:h]), bnd(yc[h:])], 0)
     a = F.leaky_relu(pre, 0.01)
     zc = F.conv2d(a, w2c, b2c, padding=ks // 2)
-    zc.backward(dz)
+    zc.backward(dz.double())
+    bn = bnd
     _close(z, zc.detach(), "z", 3e-5)
     # LeakyReLU's derivative jumps from 0.01 to 1 at 0: where the normalised value is within rounding of 0 (a handful of the
     # 10^7..10^8 elements) the two evaluations may legitimately sit on different sides; everything else must agree

@@ -156,9 +156,12 @@ def test_checkpoint_layout_round_trip(tmp_path):
     net = uaps_amd.UNet_UAPS(3, 4)
     tr = uaps_amd.UAPSTrainer(net, loss_fn=lambda *a: None)
     path = str(tmp_path / "Checkpoints" / "UAPS_NEU_10P.pth")
+    tr.iter_num = 1234
+    tr.scheduler.step(0.4)
     tr.save_checkpoint(path, epoch=7, best_dice=0.5)
     ck = torch.load(path, weights_only=False)
-    assert set(ck) == {"epoch", "best_dice_1", "state_dict", "optimizer"}
+    # the reference's four keys (UAPS_train.py:443-448) + the resume extras its loaders ignore
+    assert {"epoch", "best_dice_1", "state_dict", "optimizer"} <= set(ck) <= {"epoch", "best_dice_1", "state_dict", "optimizer", "iter_num", "scheduler"}
     assert all(k.startswith("module.") for k in ck["state_dict"]) and len(ck["state_dict"]) == 334
     assert "module.encoder.in_conv.conv_conv.0.weight" in ck["state_dict"]
     # the reference's way of consuming it: DataParallel(model).load_state_dict(ckpt['state_dict'])
@@ -170,6 +173,8 @@ def test_checkpoint_layout_round_trip(tmp_path):
         assert torch.equal(a, b), k
     tr3 = uaps_amd.UAPSTrainer(net3, loss_fn=lambda *a: None)
     assert tr3.load_checkpoint(path)["epoch"] == 7
+    assert tr3.iter_num == 1234 and tr3.scheduler.best == 0.4              # the ramp and the plateau state resume
+    assert abs(tr3.consistency_weights()[0] - tr.consistency_weights()[0]) < 1e-15
     # scheduler surface of UAPS_train.py:113, 402
     tr.scheduler.step(0.3)
     assert tr.optimizer.param_groups[0]["lr"] == 1e-3
@@ -183,3 +188,25 @@ def test_synthetic_batches_shapes():
     assert yl.dtype == torch.int64 and 0 <= int(yl.min()) and int(yl.max()) <= 3
     frac = float((yl > 0).float().mean())
     assert 0.01 < frac < 0.5
+
+
+def test_mean_batch_metrics_follow_the_reference_loop():
+    """UAPS_train.py:388-399 averages per-batch mIoU / mDice (NaN-mean over the classes present in each batch); pooling the
+    confusion matrices over the batches is a different number as soon as a class is missing from one batch."""
+    import uaps_amd
+    from oracle import uaps_oracle as O
+    rng = np.random.default_rng(5)
+    cms = []
+    for i in range(4):
+        lg = torch.tensor(rng.standard_normal((2, 4, 16, 16)).astype(np.float32))
+        y = torch.tensor(rng.integers(0, 4, (2, 16, 16)))
+        if i % 2:
+            y[y == 3] = 1                                   # class 3 absent from every other batch
+        cms.append(O.confusion(lg, y, 4).numpy())
+    cms = np.stack(cms)
+    m = uaps_amd.mean_batch_metrics(cms)
+    per = [O.metrics_from_confusion(c) for c in cms]
+    for k in ("miou", "mdice", "acc"):
+        assert abs(m[k] - np.mean([p[k] for p in per])) < 1e-12
+    pooled = uaps_amd.metrics_from_confusion(cms.sum(0))
+    assert abs(pooled["mdice"] - m["mdice"]) > 1e-6      # the two conventions differ on this data

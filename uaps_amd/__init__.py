@@ -16,12 +16,12 @@ from .ramps import sigmoid_rampup, get_current_consistency_weight
 from .losses import (dice_loss, ce_loss, uaps_sup_loss, uaps_unsup_loss, uaps_step_loss, uaps_pair_loss, unsup_scalars,
                      sup_scalars)
 from .perturb import FeatureNoise, Dropout, FeatureDropout, manual_seed as perturb_manual_seed
-from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, seg_confusion_per_image, metrics_from_confusion
+from .metrics import mIoU, mDice, pixel_accuracy, seg_confusion, seg_confusion_per_image, metrics_from_confusion, mean_batch_metrics
 from .unet import UNet, UNet_UAPS
 from .res_uaps import ResUAPS, ResNet, resnet50
 from .net_factory import net_factory
 from .consistency import (softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization, uncertainty_map)
-from .trainer import UAPSTrainer
+from .trainer import UAPSTrainer, BaselineTrainer
 from . import augment, conv, data, dist, inference, optim, sibling
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -78,6 +78,17 @@ def metrics_from_confusion(cm, smooth: float = 1e-10):
     return {"miou": miou, "mdice": mdice, "acc": float(np.trace(cm) / tot) if tot else float("nan")}
 
 
+def mean_batch_metrics(cms, smooth: float = 1e-10):
+    """What the reference's training / validation loops log (UAPS_train.py:305-306, 320-321, 388-399): mIoU / mDice /
+    accuracy of EACH batch (NaN-mean over the classes present in that batch), arithmetically averaged over the batches (a
+    batch whose classes 1..C-1 are all absent contributes NaN, as `running += mDice(...)` does).  `cms`: [N, C, C]."""
+    if isinstance(cms, torch.Tensor):
+        cms = cms.cpu().numpy()
+    per = [metrics_from_confusion(c, smooth) for c in cms]
+    n = len(per)
+    return {k: float(sum(p[k] for p in per) / n) if n else float("nan") for k in ("miou", "mdice", "acc")}
+
+
 def pixel_accuracy(output, mask):
     """utilities/metrics.py:8-13."""
     return metrics_from_confusion(seg_confusion(output, mask))["acc"]

@@ -46,7 +46,7 @@ class UAPSTrainer:
         self.pair_forward = pair_forward and on_gpu and loss_fn is None and hasattr(model, "forward_pair")
         self.track_metrics = track_metrics and loss_fn is None
         self.buckets = udist.GradBuckets(model, overlap=overlap_comm) if self.world > 1 else None
-        self.confusion = None
+        self._cms = []                                        # one on-device C x C confusion matrix per training step
         self.last: Dict[str, torch.Tensor] = {}
 
     # -- schedule (UAPS_train.py:279-280) --
@@ -79,38 +79,54 @@ class UAPSTrainer:
             self.buckets.finish()
         self.optimizer.step()                                                     # :292
         if self.track_metrics:                                                    # :305-306 (main head, labelled batch)
-            cm = metrics.seg_confusion(lab[0], y_l)
-            self.confusion = cm if self.confusion is None else self.confusion + cm
+            self._cms.append(metrics.seg_confusion(lab[0], y_l))
         self.iter_num += 1
         self.last = {"loss": out.loss.detach(), "sup": out.sup.detach(), "unsup": out.unsup.detach(),
                      "cw1": cw1, "cw2": cw2, "w": w}
         return self.last
 
-    def epoch_metrics(self, reset: bool = True) -> Dict[str, float]:
-        """mIoU / mDice / accuracy over the labelled batches seen since the last reset (one D2H copy)."""
-        if self.confusion is None:
+    def epoch_metrics(self, reset: bool = True, pooled: bool = False) -> Dict[str, float]:
+        """mIoU / mDice / accuracy of the main head on the labelled batches seen since the last reset, as the reference
+        accumulates them: the metric of EACH batch (NaN-mean over the classes present in that batch, utilities/metrics.py:
+        16-61) averaged over the batches (UAPS_train.py:305-306, 320-321).  The per-step confusion matrices stay on the
+        device; this is the one device->host copy.  `pooled=True` instead scores the summed confusion matrix (not what the
+        reference logs: the two differ whenever a class is absent from some batches)."""
+        if not self._cms:
             return {"miou": float("nan"), "mdice": float("nan"), "acc": float("nan")}
-        m = metrics.metrics_from_confusion(self.confusion)
+        cms = torch.stack(self._cms).cpu().numpy()
         if reset:
-            self.confusion = None
-        return m
+            self._cms = []
+        return metrics.metrics_from_confusion(cms.sum(0)) if pooled else metrics.mean_batch_metrics(cms)
 
     @torch.no_grad()
-    def validate(self, batches) -> Dict[str, float]:
-        """UAPS_train.py:367-393: eval mode, main head only, CE + (1 - mDice), mIoU, accuracy."""
+    def validate(self, batches, pooled: bool = False) -> Dict[str, float]:
+        """UAPS_train.py:367-399: eval mode, main head only; per batch CE, 1 - mDice, their half-sum, mIoU, accuracy and
+        mDice, each averaged over the batches -- the mDice returned here is what the reference feeds to
+        ReduceLROnPlateau.step (:402) and to the best-checkpoint test (:427).  One device->host copy at the end.
+        `pooled=True`: metrics of the summed confusion matrix instead (a different number, see epoch_metrics)."""
         self.model.eval()
-        cm, ce_sum, n = None, None, 0
+        cms, ces = [], []
         for x, y in batches:
             out = self.model(x)
             main = out[0] if isinstance(out, (tuple, list)) else out
-            ce = losses.ce_loss(main, y)
-            ce_sum = ce if ce_sum is None else ce_sum + ce
-            c = metrics.seg_confusion(main, y)
-            cm = c if cm is None else cm + c
-            n += 1
-        m = metrics.metrics_from_confusion(cm)
-        m["ce"] = float(ce_sum) / max(n, 1)
-        m["loss"] = 0.5 * ((1 - m["mdice"]) + m["ce"])
+            ces.append(losses.ce_loss(main, y))
+            cms.append(metrics.seg_confusion(main, y))
+        if not cms:
+            return {"miou": float("nan"), "mdice": float("nan"), "acc": float("nan"), "ce": float("nan"), "loss": float("nan")}
+        cm = torch.stack(cms).cpu().numpy()
+        ce = torch.stack(ces).double().cpu().numpy()
+        if pooled:
+            m = metrics.metrics_from_confusion(cm.sum(0))
+            m["ce"] = float(ce.mean())
+            m["dice_loss"] = 1 - m["mdice"]
+            m["loss"] = 0.5 * (m["dice_loss"] + m["ce"])
+            return m
+        per = [metrics.metrics_from_confusion(c) for c in cm]
+        n = len(per)
+        m = {k: float(sum(p[k] for p in per) / n) for k in ("miou", "mdice", "acc")}                      # :394-399
+        m["ce"] = float(ce.mean())
+        m["dice_loss"] = float(sum(1 - p["mdice"] for p in per) / n)                                       # :385, 396
+        m["loss"] = float(sum(0.5 * ((1 - p["mdice"]) + c) for p, c in zip(per, ce)) / n)                  # :386, 394
         return m
 
     # -- checkpoint (UAPS_train.py:437-450) --
@@ -118,7 +134,9 @@ class UAPSTrainer:
         sd = self.model.state_dict()
         if dataparallel_prefix and not any(k.startswith("module.") for k in sd):
             sd = {"module." + k: v for k, v in sd.items()}     # the reference saves nn.DataParallel(model).state_dict()
-        return {"epoch": epoch, "best_dice_1": best_dice, "state_dict": sd, "optimizer": self.optimizer.state_dict()}
+        # the reference's four keys (UAPS_train.py:443-448) + what a resume needs (its loaders ignore unknown keys)
+        return {"epoch": epoch, "best_dice_1": best_dice, "state_dict": sd, "optimizer": self.optimizer.state_dict(),
+                "iter_num": self.iter_num, "scheduler": self.scheduler.state_dict()}
 
     def save_checkpoint(self, path: str, epoch: int, best_dice: float):
         if self.rank == 0:
@@ -126,11 +144,51 @@ class UAPSTrainer:
             torch.save(self.state_for_checkpoint(epoch, best_dice), path)
 
     def load_checkpoint(self, path: str, load_optimizer: bool = True) -> Dict:
-        ck = torch.load(path, map_location=self.device, weights_only=False)
+        # map to the CPU: load_state_dict moves the Adam moments to the parameters' device itself, while the per-parameter
+        # `step` counters must stay host tensors (optim.Adam reads them without a device sync)
+        ck = torch.load(path, map_location="cpu", weights_only=False)
         load_state_dict_any_prefix(self.model, ck["state_dict"])
         if load_optimizer and "optimizer" in ck:
             self.optimizer.load_state_dict(ck["optimizer"])
+            for st in self.optimizer.state.values():
+                if torch.is_tensor(st.get("step")) and st["step"].device.type != "cpu":
+                    st["step"] = st["step"].cpu()
+            if "iter_num" in ck:                                   # resume the consistency ramp and the LR plateau state
+                self.iter_num = int(ck["iter_num"])
+            if "scheduler" in ck:
+                self.scheduler.load_state_dict(ck["scheduler"])
         return ck
+
+
+class BaselineTrainer(UAPSTrainer):
+    """The supervised baseline of BASELINE.json configs[0] (baseline/baseline_train.py:100-173): a single-decoder
+    U-Net (`net_factory("unet")`), loss = 0.5 * (dice_loss + CrossEntropy) on the labelled batch only, Adam(lr) and
+    ReduceLROnPlateau(max, min_lr 1e-7, patience 40) (:102-105).  It is the D = 1 case of the same kernels: no
+    perturbations, no mixing, no unlabelled branch."""
+
+    def __init__(self, model: torch.nn.Module, base_lr: float = 1e-3, seed: int = 1337, overlap_comm: bool = True,
+                 track_metrics: bool = True):
+        super().__init__(model, base_lr=base_lr, seed=seed, overlap_comm=overlap_comm, track_metrics=track_metrics, pair_forward=False)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="max", min_lr=1e-7, patience=40)
+        self.n_heads = 1
+
+    def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u=None, w=None) -> Dict[str, torch.Tensor]:
+        if not self.model.training:
+            self.model.train()
+        out = self.model(x_l)                                                     # baseline_train.py:158
+        main = out[0] if isinstance(out, (tuple, list)) else out
+        s = losses.uaps_sup_loss((main,), y_l)                                    # :161-164, 0.5 * (dice + CE)
+        self.optimizer.zero_grad(set_to_none=True)                                # :166
+        s.loss.backward()                                                         # :168
+        if self.buckets is not None:
+            self.buckets.finish()
+        self.optimizer.step()                                                     # :173
+        if self.track_metrics:                                                    # :181-182
+            self._cms.append(metrics.seg_confusion(main, y_l))
+        self.iter_num += 1
+        sc = losses.sup_scalars(s.scalars, 1, main.shape[1])
+        self.last = {"loss": s.loss.detach(), "ce": sc["ce"][0], "dice": sc["dice"][0]}
+        return self.last
 
 
 def load_state_dict_any_prefix(model: torch.nn.Module, sd: Dict[str, torch.Tensor]):
