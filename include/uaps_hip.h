@@ -107,6 +107,34 @@ int uaps_sup_bwd(const float* const* logits_host, const int64_t* labels, const f
                  float* const* dlogits_host, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The whole loss block of one training step -- UAPS_train.py:194-218 on the labelled logits and :186-189, 223-282 on the
+ * unlabelled logits -- as ONE forward launch (+ a one-block finalize) and ONE backward launch: the first blocks of the
+ * grid run the supervised branch, the rest the unsupervised branch; results are bit-identical to uaps_sup_* +
+ * uaps_unsup_* (same per-branch block partitioning and fixed-order reductions).  lab_logits / un_logits: D host pointers
+ * each, [B,C,H,W] fp32; ce_coef = dice_coef = 0.5 / D (UAPS_train.py:208-218).  `cfg` = 0, or a cap on the blocks per branch.
+ *
+ * Gathered-batch semantics.  The reference's nn.DataParallel (UAPS_model.py:13) gathers the logits of all GPUs and computes
+ * every CE mean, Dice sum and uncertainty mean over that global batch (UAPS_train.py:194-277).  One process per GPU
+ * reproduces it with a 1-step exchange: pass `sums_out` (device, uaps_pairloss_num_sums doubles) to uaps_pairloss_fwd -- it
+ * then writes this rank's raw sums and no scalars --, sum the buffers over the ranks (one tiny all-reduce), call
+ * uaps_pairloss_finalize_sums with the global pixel count, and give that count to uaps_pairloss_bwd as `n_pixels_loss`
+ * (0 = the local B*H*W).  The parameter gradients of the ranks then ADD up to the gradient of the global loss.
+ * ------------------------------------------------------------------------------------------- */
+int uaps_pairloss_workspace_bytes(int D, int C, size_t* bytes_host);
+int uaps_pairloss_num_sums(int D, int C, int* count_host);
+int uaps_pairloss_fwd(const float* const* lab_logits_host, const float* const* un_logits_host, const int64_t* labels,
+                      const double* w_host, int D, int B, int C, int H, int W, float cw1, float cw2, float eps,
+                      int64_t* pseudo, float* var /* [D,B,H,W] or NULL */, float* sup_scalars, float* unsup_scalars,
+                      double* sums_out /* NULL: finalise locally */, void* workspace, size_t workspace_bytes, int cfg,
+                      uaps_stream_t stream);
+int uaps_pairloss_finalize_sums(const double* sums, int D, int C, long n_pixels, float cw1, float cw2, float eps,
+                                float* sup_scalars, float* unsup_scalars, uaps_stream_t stream);
+int uaps_pairloss_bwd(const float* const* lab_logits_host, const float* const* un_logits_host, const int64_t* labels,
+                      const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1, float cw2,
+                      const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss,
+                      float* const* dlab_host, float* const* dun_host, int cfg, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Feature perturbations of the auxiliary decoders: utilities/UAPS_unet.py:156-185, applied to all
  * five encoder scales at UAPS_unet.py:227-231.  Random numbers: Philox4x32-10 keyed by `seed`,
  * counter = element index + `offset` (the reference draws from the unseeded CPU generators, so

@@ -20,11 +20,29 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _oracle_loss(lab, y, un, w, cw1, cw2):
+def _oracle_loss(lab, y, un, w, cw1, cw2, exchange=None):
+    """Stand-in for the HIP loss block on the CPU.  With `exchange` it follows the product's gathered-batch protocol
+    (losses._PairLoss): raw sums of this shard -> summed over the ranks -> loss from the global sums and pixel count; the
+    gradient flows through this rank's own contribution to the sums."""
     from oracle import uaps_oracle as O
     from uaps_amd.losses import StepLoss
-    r = O.step_loss(list(un), list(lab), y, w, cw1, cw2)
-    return StepLoss(r["loss"], r["sup"], r["loss"] - r["sup"], r["pseudo"], None, None, None)
+    if exchange is None:
+        r = O.step_loss(list(un), list(lab), y, w, cw1, cw2)
+        return StepLoss(r["loss"], r["sup"], r["loss"] - r["sup"], r["pseudo"], None, None, None)
+    t = O.loss_sums(list(un), list(lab), y, w)
+    keys = [k for k in t if k != "pseudo"]
+    flat = torch.cat([t[k].reshape(-1).double() for k in keys])
+    summed = flat.detach().clone()
+    world = exchange(summed)
+    flat = flat + (summed - flat.detach())                 # value = global sums, derivative = d(local sums)
+    tot, off = {}, 0
+    for k in keys:
+        n = t[k].numel()
+        tot[k] = flat[off:off + n].view_as(t[k]).to(t[k].dtype)
+        off += n
+    n_pix = y.numel() * world
+    r = O.loss_from_sums(tot, n_pix, cw1, cw2)
+    return StepLoss(r["loss"], r["sup"], r["loss"] - r["sup"], t["pseudo"], None, None, None)
 
 
 def _make_model(seed):
@@ -42,7 +60,7 @@ def _batch(rank):
     return (torch.randn(2, 3, 32, 32, generator=g), torch.randint(0, 4, (2, 32, 32), generator=g), torch.randn(2, 3, 32, 32, generator=g))
 
 
-def _worker(rank, world, port, overlap, out_dir):
+def _worker(rank, world, port, overlap, out_dir, gathered=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,11 +68,11 @@ def _worker(rank, world, port, overlap, out_dir):
     import uaps_amd
     model = _make_model(seed=rank)                 # different init per rank: broadcast must fix it
     uaps_amd.dist.broadcast_model(model)
-    tr = uaps_amd.UAPSTrainer(model, loss_fn=_oracle_loss, overlap_comm=overlap, seed=5)
+    tr = uaps_amd.UAPSTrainer(model, loss_fn=_oracle_loss, overlap_comm=overlap, seed=5, gathered_loss=gathered)
     grads = {}
     xl, yl, xu = _batch(rank)
     res = tr.train_step(xl, yl, xu)
-    torch.save({"w": res["w"], "grads": {n: p.grad.clone() for n, p in model.named_parameters()},
+    torch.save({"w": res["w"], "loss": float(res["loss"]), "grads": {n: p.grad.clone() for n, p in model.named_parameters()},
                 "params": {k: v.clone() for k, v in model.state_dict().items()}, "buckets": tr.buckets.names},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -88,3 +106,64 @@ def test_two_rank_step_matches_single_process_average(tmp_path, overlap):
         ref = captured if ref is None else {n: (ref[n] + captured[n]) / 2 for n in ref}
     for n, gr in ref.items():
         torch.testing.assert_close(r[0]["grads"][n], gr, rtol=1e-5, atol=1e-7, msg=n)
+
+
+def test_four_ranks_bucket_order_and_average(tmp_path):
+    """world_size 4: the buckets follow the order in which the product's backward finishes them (auxiliary decoders last
+    created first, encoder last), every rank ends with identical averaged gradients and parameters."""
+    world, port = 4, _free_port()
+    mp.spawn(_worker, args=(world, port, True, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt"), weights_only=False) for i in range(world)]
+    assert r[0]["buckets"] == ["aux_decoder3", "aux_decoder2", "aux_decoder1", "main_decoder", "encoder"]
+    for i in range(1, world):
+        assert np.array_equal(r[0]["w"], r[i]["w"])
+        for n in r[0]["grads"]:
+            assert torch.equal(r[0]["grads"][n], r[i]["grads"][n]), n
+    sys.path.insert(0, ROOT)
+    import uaps_amd
+    torch.set_num_threads(1)
+    ref = None
+    for rank in range(world):
+        m = _make_model(seed=0)
+        tr = uaps_amd.UAPSTrainer(m, loss_fn=_oracle_loss, seed=5)
+        captured = {}
+        hooks = [p.register_hook(lambda g, n=n: captured.__setitem__(n, g.clone())) for n, p in m.named_parameters()]
+        tr.train_step(*_batch(rank))
+        ref = captured if ref is None else {n: ref[n] + captured[n] for n in ref}
+    for n, gr in ref.items():
+        torch.testing.assert_close(r[0]["grads"][n], gr / world, rtol=1e-5, atol=1e-7, msg=n)
+
+
+def test_gathered_loss_two_ranks_equals_the_gathered_batch(tmp_path):
+    """gathered_loss=True (SURVEY 8e's optional exactness step): the loss statistics run over the batch of both ranks, as
+    on the reference's gathered logits (UAPS_model.py:13 + UAPS_train.py:194-277): the loss value on every rank and the
+    SUMMED gradients must equal a single process that forwards each shard (per-replica BatchNorm statistics, as
+    DataParallel replicas have) and computes one loss on the concatenated logits."""
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, True, str(tmp_path), True), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt"), weights_only=False) for i in range(world)]
+    assert abs(r[0]["loss"] - r[1]["loss"]) < 1e-7
+    for n in r[0]["grads"]:
+        assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n
+    sys.path.insert(0, ROOT)
+    import uaps_amd
+    from oracle import uaps_oracle as O
+    torch.set_num_threads(1)
+    m = _make_model(seed=0)
+    tr = uaps_amd.UAPSTrainer(m, loss_fn=_oracle_loss, seed=5)
+    m.train()
+    labs, uns, ys = [], [], []
+    for rank in range(world):
+        xl, yl, xu = _batch(rank)
+        labs.append(m(xl)); uns.append(m(xu)); ys.append(yl)
+    D = len(labs[0])
+    w = tr.mix_rng.dirichlet(np.ones(D), size=1)[0]
+    cw1, cw2 = tr.consistency_weights()
+    lab_all = [torch.cat([l[k] for l in labs]) for k in range(D)]
+    un_all = [torch.cat([u[k] for u in uns]) for k in range(D)]
+    ref = O.step_loss(un_all, lab_all, torch.cat(ys), w, cw1, cw2)
+    ref["loss"].backward()
+    assert np.array_equal(w, r[0]["w"])
+    np.testing.assert_allclose(r[0]["loss"], float(ref["loss"]), rtol=1e-6)
+    for n, p in m.named_parameters():
+        torch.testing.assert_close(r[0]["grads"][n], p.grad, rtol=2e-4, atol=1e-7, msg=n)

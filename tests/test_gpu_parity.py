@@ -476,7 +476,6 @@ def test_grad_buckets_over_rccl_single_rank():
             if with_buckets:
                 buckets = udist.GradBuckets(model)
                 buckets.world = 2                                   # divisor of the average; one rank contributes the sum
-                buckets.remove()
                 for bi, params in enumerate(buckets.buckets):       # register the hooks the world > 1 constructor would
                     for p in params:
                         buckets._hooks.append(p.register_post_accumulate_grad_hook(buckets._make_hook(bi)))
@@ -486,8 +485,14 @@ def test_grad_buckets_over_rccl_single_rank():
             out.loss.backward()
             if buckets is not None:
                 buckets.finish()
+                for bi, params in enumerate(buckets.buckets):       # the kernels wrote into the flat buffers, RCCL reduced in place
+                    for k, p in enumerate(params):
+                        assert p.grad.data_ptr() == buckets._view(bi, k).data_ptr()
             torch.cuda.synchronize()
-            return [p.grad.clone() for p in model.parameters()]
+            out = [p.grad.clone() for p in model.parameters()]
+            if buckets is not None:
+                buckets.remove()
+            return out
 
         ref, got = grads(False), grads(True)
         assert len(ref) == len(got) == 208

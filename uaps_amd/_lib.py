@@ -31,6 +31,11 @@ SIGNATURES = {
     "uaps_unsup_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_float, C.c_float, _PTR] + [C.c_int] * 5 + [_PTR, _PTR]),
     "uaps_sup_fwd": (C.c_int, [_PTR, _PTR] + [C.c_int] * 5 + [C.c_float] * 3 + [_PTR, _PTR, C.c_size_t, _PTR]),
     "uaps_sup_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_float, C.c_float, _PTR] + [C.c_int] * 5 + [_PTR, _PTR]),
+    "uaps_pairloss_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "uaps_pairloss_num_sums": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "uaps_pairloss_fwd": (C.c_int, [_PTR] * 4 + [C.c_int] * 5 + [C.c_float] * 3 + [_PTR] * 6 + [C.c_size_t, C.c_int, _PTR]),
+    "uaps_pairloss_finalize_sums": (C.c_int, [_PTR, C.c_int, C.c_int, C.c_long] + [C.c_float] * 3 + [_PTR] * 3),
+    "uaps_pairloss_bwd": (C.c_int, [_PTR] * 6 + [C.c_float] * 2 + [_PTR] + [C.c_int] * 5 + [C.c_long, _PTR, _PTR, C.c_int, _PTR]),
     "uaps_feat_noise": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [C.c_uint64, C.c_uint64, C.c_float, _PTR, _PTR]),
     "uaps_feat_noise_apply": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, C.c_long, _PTR]),
     "uaps_feat_bernoulli": (C.c_int, [_PTR, _PTR, C.c_long, C.c_uint64, C.c_uint64, C.c_float, _PTR, _PTR]),

@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
-from . import _lib
+from . import _graddest, _lib
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 # packed weights per parameter: id(weight) -> (weakref, version, generation, wf, wb)
@@ -227,7 +227,8 @@ def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg
     return dx
 
 
-def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0):
+def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None):
+    """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest)."""
     B, Cout, H, W = dy.shape
     Cin = x.shape[1]
     dev = dy.device
@@ -235,8 +236,8 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     n = C.c_size_t()
     _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
     ws = _workspace(dev, n.value)
-    dw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=dev)
-    db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_bias else None
+    dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
+    db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
     with _lib.device_guard(dev):
         st = _lib.current_stream(dev)
         with _timed("wrw", B, Cin, Cout, H, W, ks, cfg):
@@ -271,6 +272,7 @@ class _Conv2d(torch.autograd.Function):
         cfg = _dil_cfg(dilation)
         ctx.save_for_backward(x, wb)
         ctx.meta = (Cin, Cout, ks, bias is not None, cfg)
+        ctx.keys = (id(weight), id(bias) if bias is not None else None)
         if want_stats:
             y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True)
             ctx.mark_non_differentiable(stats)
@@ -287,7 +289,7 @@ class _Conv2d(torch.autograd.Function):
         dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg)
+            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys)
         return dx, dw, db, None, None
 
 
@@ -332,6 +334,7 @@ class _Conv2dCat(torch.autograd.Function):
         _lib.check(rc, "uaps_conv_fwd_cat")
         ctx.save_for_backward(x1, x2, wb)
         ctx.meta = (C1, C2, Cout, ks, bias is not None)
+        ctx.keys = (id(weight), id(bias) if bias is not None else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -362,8 +365,8 @@ class _Conv2dCat(torch.autograd.Function):
                 n = C.c_size_t()
                 _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
                 ws = _workspace(dev, n.value)
-                dw = torch.empty((Cout, C1 + C2, ks, ks), dtype=torch.float32, device=dev)
-                db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
+                dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
+                db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
                 with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0):
                     rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
                                                             H, W, ks, 0, ws.data_ptr(), ws.numel(), st)

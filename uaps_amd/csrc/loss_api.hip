@@ -74,3 +74,72 @@ extern "C" int uaps_sup_bwd(const float* const* logits, const int64_t* labels, c
     a.cw1 = ce_coef; a.cw2 = dice_coef; a.cscalars = scalars; a.gscale = gscale; a.stream = (hipStream_t)stream;
     return launch_sup_bwd(a);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The whole loss block of a step (supervised branch on the labelled logits + unsupervised branch on the unlabelled ones)
+// as one forward launch + one finalize + one backward launch.
+// ---------------------------------------------------------------------------------------------
+static size_t pairloss_ws_bytes(int D, int C) {
+    return (size_t)kMaxBlocks * (size_t)(sup_nsums(D, C) + unsup_nsums(D, C)) * sizeof(float);
+}
+
+extern "C" int uaps_pairloss_workspace_bytes(int D, int C, size_t* out) {
+    if (!out) return UAPS_EINVAL;
+    if (D < 1 || D > UAPS_MAX_HEADS || C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    *out = pairloss_ws_bytes(D, C);
+    return UAPS_OK;
+}
+
+extern "C" int uaps_pairloss_num_sums(int D, int C, int* out) {
+    if (!out) return UAPS_EINVAL;
+    if (D < 1 || D > UAPS_MAX_HEADS || C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    *out = sup_nsums(D, C) + unsup_nsums(D, C);
+    return UAPS_OK;
+}
+
+static int check_heads(const float* const* p, int D) {
+    if (!p) return UAPS_EINVAL;
+    for (int k = 0; k < D; ++k) if (!p[k]) return UAPS_EINVAL;
+    return UAPS_OK;
+}
+
+extern "C" int uaps_pairloss_fwd(const float* const* lab_logits, const float* const* un_logits, const int64_t* labels, const double* w,
+                                 int D, int B, int C, int H, int W, float cw1, float cw2, float eps, int64_t* pseudo, float* var,
+                                 float* sup_scalars, float* unsup_scalars, double* sums_out, void* ws, size_t ws_bytes, int cfg,
+                                 uaps_stream_t stream) {
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    if ((rc = check_heads(lab_logits, D)) || (rc = check_heads(un_logits, D))) return rc;
+    if (!labels || !w || !pseudo || !ws || (!sums_out && (!sup_scalars || !unsup_scalars))) return UAPS_EINVAL;
+    if (ws_bytes < pairloss_ws_bytes(D, C)) return UAPS_EWORKSPACE;
+    PairArgs a{}; a.lab = lab_logits; a.un = un_logits; a.w = w; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W;
+    a.ce_coef = 0.5f / D; a.dice_coef = 0.5f / D; a.cw1 = cw1; a.cw2 = cw2; a.eps = eps; a.labels = labels; a.pseudo = pseudo;
+    a.var = var; a.sscal = sup_scalars; a.uscal = unsup_scalars; a.sums = sums_out; a.partials = (float*)ws; a.cfg = cfg;
+    a.stream = (hipStream_t)stream;
+    return launch_pair_fwd(a);
+}
+
+extern "C" int uaps_pairloss_finalize_sums(const double* sums, int D, int C, long n_pixels, float cw1, float cw2, float eps,
+                                           float* sup_scalars, float* unsup_scalars, uaps_stream_t stream) {
+    if (D < 1 || D > UAPS_MAX_HEADS || C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
+    if (!sums || !sup_scalars || !unsup_scalars || n_pixels <= 0) return UAPS_EINVAL;
+    hipLaunchKernelGGL(pair_finalize_sums_kernel, dim3(1), dim3(kFinalizeThreads), 0, (hipStream_t)stream, sums, D, C, n_pixels, 0.5f / D,
+                       0.5f / D, cw1, cw2, eps, sup_scalars, unsup_scalars);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_pairloss_bwd(const float* const* lab_logits, const float* const* un_logits, const int64_t* labels,
+                                 const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1, float cw2,
+                                 const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss, float* const* dlab,
+                                 float* const* dun, int cfg, uaps_stream_t stream) {
+    int rc = check_dims(D, B, C, H, W);
+    if (rc) return rc;
+    if ((rc = check_heads(lab_logits, D)) || (rc = check_heads(un_logits, D))) return rc;
+    if (!dlab || !dun || !labels || !pseudo || !sup_scalars || !unsup_scalars) return UAPS_EINVAL;
+    for (int k = 0; k < D; ++k) if (!dlab[k] || !dun[k]) return UAPS_EINVAL;
+    PairArgs a{}; a.lab = lab_logits; a.un = un_logits; a.dlab = dlab; a.dun = dun; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W;
+    a.ce_coef = 0.5f / D; a.dice_coef = 0.5f / D; a.cw1 = cw1; a.cw2 = cw2; a.labels = labels; a.cpseudo = pseudo;
+    a.sscal = const_cast<float*>(sup_scalars); a.uscal = const_cast<float*>(unsup_scalars);
+    a.Nloss = n_pixels_loss > 0 ? n_pixels_loss : (long)B * H * W; a.gscale = gscale; a.cfg = cfg; a.stream = (hipStream_t)stream;
+    return launch_pair_bwd(a);
+}

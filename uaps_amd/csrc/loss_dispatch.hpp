@@ -74,6 +74,36 @@ inline bool vec_ok(const LossArgs& a, int vec, bool outs) {
         default: return UAPS_ERANGE;               \
     }
 
+// both branches of a step (labelled logits `lab`, unlabelled logits `un`, D pointers each)
+struct PairArgs {
+    const float* const* lab; const float* const* un; float* const* dlab; float* const* dun; const double* w;
+    int D, B, C, H, W; float ce_coef, dice_coef, cw1, cw2, eps;
+    const int64_t* labels; int64_t* pseudo; const int64_t* cpseudo; float* var; float* sscal; float* uscal; double* sums;
+    long Nloss; const float* gscale; float* partials; int cfg; hipStream_t stream;
+};
+// 16-byte access to every plane of both branches?
+inline bool pair_vec_ok(const PairArgs& a, int vec, bool outs) {
+    const long HW = (long)a.H * a.W;
+    if (HW % vec) return false;
+    for (int k = 0; k < a.D; ++k) {
+        if (!aligned_to(a.lab[k], 16) || !aligned_to(a.un[k], 16)) return false;
+        if (outs && (!aligned_to(a.dlab[k], 16) || !aligned_to(a.dun[k], 16))) return false;
+    }
+    if (!aligned_to(a.labels, 16)) return false;
+    if (a.pseudo && !aligned_to(a.pseudo, 16)) return false;
+    if (a.cpseudo && !aligned_to(a.cpseudo, 16)) return false;
+    if (a.var && !aligned_to(a.var, 16)) return false;
+    return true;
+}
+// blocks of one branch: one group per thread up to kMaxBlocks; cfg > 0 caps the count (tuning: fewer, longer-lived blocks)
+inline int pair_grid(long ngroups, int cfg) {
+    int b = grid_for(ngroups);
+    if (cfg > 0 && b > cfg) b = cfg;
+    return b;
+}
+
+int launch_pair_fwd(const PairArgs& a);
+int launch_pair_bwd(const PairArgs& a);
 int launch_unsup_fwd(const LossArgs& a);
 int launch_unsup_bwd(const LossArgs& a);
 int launch_sup_fwd(const LossArgs& a);

@@ -104,7 +104,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Block reduction of NS per-thread partial sums into column `blockIdx.x` of `partials` ([NS][gridDim.x], sum-major so
 // that the finalize kernel reads each sum's block partials as one coalesced run).
-template <int NS> __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], float* partials) {
+template <int NS> __device__ __forceinline__ void block_reduce_store(float (&acc)[NS], float* partials, int bid, int nblk) {
     __shared__ float red[kThreads / 64][NS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -117,7 +117,7 @@ template <int NS> __device__ __forceinline__ void block_reduce_store(float (&acc
         float s = red[0][i];
 #pragma unroll
         for (int w = 1; w < kThreads / 64; ++w) s += red[w][i];
-        partials[(size_t)i * gridDim.x + blockIdx.x] = s;
+        partials[(size_t)i * nblk + bid] = s;
     }
 }
 
@@ -136,16 +136,18 @@ template <int D, int C> struct SupLayout {
 // --------------------------------------------------------------------------------------------------
 // F1: unsupervised forward.  Algorithmic HBM bytes per pixel: 4DC (logits) + 8 (pseudo) + 4D (var).
 // --------------------------------------------------------------------------------------------------
+// (bid, nblk): this block's index among the nblk blocks that share the work -- blockIdx.x / gridDim.x for the stand-alone
+// kernels, a sub-range of the grid for the pair kernels below
 template <int D, int C, int VEC>
-__global__ __launch_bounds__(kThreads) void unsup_fwd_kernel(HeadPtrs<D> z, HeadWeights<D> w, int HW, long ngroups,
-                                                             long N, int64_t* __restrict__ pseudo,
-                                                             float* __restrict__ var, float* __restrict__ partials) {
+__device__ __forceinline__ void unsup_fwd_body(const HeadPtrs<D>& z, const HeadWeights<D>& w, int HW, long ngroups,
+                                               long N, int64_t* __restrict__ pseudo,
+                                               float* __restrict__ var, float* __restrict__ partials, int bid, int nblk) {
     using L = UnsupLayout<D, C>;
     float acc[L::NS];
 #pragma unroll
     for (int i = 0; i < L::NS; ++i) acc[i] = 0.f;
 
-    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+    for (long g = (long)bid * kThreads + threadIdx.x; g < ngroups; g += (long)nblk * kThreads) {
         const long n0 = g * VEC;
         const long b = n0 / HW;
         const long hw = n0 - b * HW;
@@ -209,21 +211,27 @@ __global__ __launch_bounds__(kThreads) void unsup_fwd_kernel(HeadPtrs<D> z, Head
             for (int k = 0; k < D; ++k) store_vec<VEC>(var + (long)k * N + n0, varv[k]);
         }
     }
-    block_reduce_store<L::NS>(acc, partials);
+    block_reduce_store<L::NS>(acc, partials, bid, nblk);
+}
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void unsup_fwd_kernel(HeadPtrs<D> z, HeadWeights<D> w, int HW, long ngroups,
+                                                             long N, int64_t* __restrict__ pseudo,
+                                                             float* __restrict__ var, float* __restrict__ partials) {
+    unsup_fwd_body<D, C, VEC>(z, w, HW, ngroups, N, pseudo, var, partials, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // --------------------------------------------------------------------------------------------------
 // F3 forward: supervised branch.  Bytes per pixel: 4DC + 8.
 // --------------------------------------------------------------------------------------------------
 template <int D, int C, int VEC>
-__global__ __launch_bounds__(kThreads) void sup_fwd_kernel(HeadPtrs<D> z, int HW, long ngroups,
-                                                           const int64_t* __restrict__ labels,
-                                                           float* __restrict__ partials) {
+__device__ __forceinline__ void sup_fwd_body(const HeadPtrs<D>& z, int HW, long ngroups,
+                                             const int64_t* __restrict__ labels,
+                                             float* __restrict__ partials, int bid, int nblk) {
     using L = SupLayout<D, C>;
     float acc[L::NS];
 #pragma unroll
     for (int i = 0; i < L::NS; ++i) acc[i] = 0.f;
-    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+    for (long g = (long)bid * kThreads + threadIdx.x; g < ngroups; g += (long)nblk * kThreads) {
         const long n0 = g * VEC;
         const long b = n0 / HW;
         const long hw = n0 - b * HW;
@@ -260,7 +268,13 @@ __global__ __launch_bounds__(kThreads) void sup_fwd_kernel(HeadPtrs<D> z, int HW
             acc[L::BAD] += (y < 0 || y >= C) ? 1.f : 0.f;
         }
     }
-    block_reduce_store<L::NS>(acc, partials);
+    block_reduce_store<L::NS>(acc, partials, bid, nblk);
+}
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void sup_fwd_kernel(HeadPtrs<D> z, int HW, long ngroups,
+                                                           const int64_t* __restrict__ labels,
+                                                           float* __restrict__ partials) {
+    sup_fwd_body<D, C, VEC>(z, HW, ngroups, labels, partials, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -273,15 +287,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-template <bool UNSUP>
-__global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const float* __restrict__ partials, int nrows, int D, int C,
-                                                            long N, float cw1, float cw2, float eps,
-                                                            float* __restrict__ out) {
-    __shared__ double tot[4 * UAPS_MAX_HEADS + 2 * UAPS_MAX_HEADS * UAPS_MAX_CLASSES + UAPS_MAX_CLASSES + 1];
-    __shared__ double dice_s[UAPS_MAX_HEADS];
-    const int NS = UNSUP ? (D + 2 * D * C + C + 2 * D) : (D + 2 * D * C + C + 1);
-    // kFinalizeThreads / 64 waves, one sum per wave at a time: coalesced reads of that sum's nrows block partials,
-    // lane-strided double accumulation, then a fixed-order wave reduction
+constexpr int kMaxSums = 4 * UAPS_MAX_HEADS + 2 * UAPS_MAX_HEADS * UAPS_MAX_CLASSES + UAPS_MAX_CLASSES + 1;
+
+// fixed-order double reduction of the block partials [NS][nrows] into tot[NS]: kFinalizeThreads / 64 waves, one sum per wave at
+// a time: coalesced reads of that sum's nrows block partials, lane-strided double accumulation, fixed-order wave reduction
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nrows, int NS, double* tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = wave; i < NS; i += kFinalizeThreads / 64) {
         const float* src = partials + (size_t)i * nrows;
@@ -294,7 +304,14 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const float*
         const double s = wave_sum_d((s0 + s1) + (s2 + s3));
         if (lane == 0) tot[i] = s;
     }
-    __syncthreads();
+}
+
+// tot[NS] (shared, already complete: call after a barrier) -> the scalar losses and the Dice gradient coefficients the
+// backward kernels need.  N = number of pixels the sums run over (the local batch, or the gathered global batch when the
+// sums were exchanged between ranks).  Ends with a barrier-free tail: only thread 0 writes the loss scalars.
+template <bool UNSUP>
+__device__ __forceinline__ void finalize_from_tot(const double* tot, double* dice_s, int D, int C, long N, float cw1, float cw2,
+                                                  float eps, float* __restrict__ out) {
     const double *CE = tot, *I = tot + D, *P = I + D * C, *cnt = P + D * C;
     const int oA1 = UNSUP ? UAPS_U_A1(D, C) : UAPS_S_A1(D, C);
     const int oA2 = UNSUP ? UAPS_U_A2(D, C) : UAPS_S_A2(D, C);
@@ -351,14 +368,68 @@ __global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const float*
     }
 }
 
+__host__ __device__ constexpr int unsup_nsums(int D, int C) { return D + 2 * D * C + C + 2 * D; }
+__host__ __device__ constexpr int sup_nsums(int D, int C) { return D + 2 * D * C + C + 1; }
+
+// one block: reduce the block rows, then the scalars
+template <bool UNSUP>
+__global__ __launch_bounds__(kFinalizeThreads) void finalize_kernel(const float* __restrict__ partials, int nrows, int D, int C,
+                                                            long N, float cw1, float cw2, float eps,
+                                                            float* __restrict__ out) {
+    __shared__ double tot[kMaxSums];
+    __shared__ double dice_s[UAPS_MAX_HEADS];
+    reduce_partials(partials, nrows, UNSUP ? unsup_nsums(D, C) : sup_nsums(D, C), tot);
+    __syncthreads();
+    finalize_from_tot<UNSUP>(tot, dice_s, D, C, N, cw1, cw2, eps, out);
+}
+
+// Both halves of a step's loss block (supervised partials, then unsupervised partials) by ONE block.  With `sums_out` the
+// raw double sums [sup_nsums | unsup_nsums] are written instead and nothing is finalised: the caller exchanges them between
+// ranks (sum) and runs pair_finalize_sums_kernel with the global pixel count -- the reference computes every mean and Dice
+// sum over the gathered batch of all GPUs (UAPS_model.py:13 nn.DataParallel gather, UAPS_train.py:194-277).
+static __global__ __launch_bounds__(kFinalizeThreads) void pair_finalize_kernel(const float* __restrict__ part_s, int nrows_s,
+                                                                         const float* __restrict__ part_u, int nrows_u, int D, int C,
+                                                                         long N, float ce_coef, float dice_coef, float cw1, float cw2,
+                                                                         float eps, float* __restrict__ sscal, float* __restrict__ uscal,
+                                                                         double* __restrict__ sums_out) {
+    __shared__ double tot_s[kMaxSums], tot_u[kMaxSums];
+    __shared__ double dice_s[UAPS_MAX_HEADS];
+    const int ns = sup_nsums(D, C), nu = unsup_nsums(D, C);
+    reduce_partials(part_s, nrows_s, ns, tot_s);
+    reduce_partials(part_u, nrows_u, nu, tot_u);
+    __syncthreads();
+    if (sums_out != nullptr) {
+        for (int i = threadIdx.x; i < ns + nu; i += kFinalizeThreads) sums_out[i] = i < ns ? tot_s[i] : tot_u[i - ns];
+        return;
+    }
+    finalize_from_tot<false>(tot_s, dice_s, D, C, N, ce_coef, dice_coef, eps, sscal);
+    __syncthreads();
+    finalize_from_tot<true>(tot_u, dice_s, D, C, N, cw1, cw2, eps, uscal);
+}
+static __global__ __launch_bounds__(kFinalizeThreads) void pair_finalize_sums_kernel(const double* __restrict__ sums, int D, int C, long N,
+                                                                              float ce_coef, float dice_coef, float cw1, float cw2,
+                                                                              float eps, float* __restrict__ sscal, float* __restrict__ uscal) {
+    __shared__ double tot_s[kMaxSums], tot_u[kMaxSums];
+    __shared__ double dice_s[UAPS_MAX_HEADS];
+    const int ns = sup_nsums(D, C), nu = unsup_nsums(D, C);
+    for (int i = threadIdx.x; i < ns + nu; i += kFinalizeThreads) {
+        if (i < ns) tot_s[i] = sums[i]; else tot_u[i - ns] = sums[i];
+    }
+    __syncthreads();
+    finalize_from_tot<false>(tot_s, dice_s, D, C, N, ce_coef, dice_coef, eps, sscal);
+    __syncthreads();
+    finalize_from_tot<true>(tot_u, dice_s, D, C, N, cw1, cw2, eps, uscal);
+}
+
 // --------------------------------------------------------------------------------------------------
 // F2: unsupervised backward.  Bytes per pixel: 4DC + 8 read, 4DC written.
 // --------------------------------------------------------------------------------------------------
+// N: the pixel count the loss was averaged over (local batch, or the gathered global batch)
 template <int D, int C, int VEC>
-__global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, HeadOutPtrs<D> dz, int HW, long ngroups, long N,
-                                                             const int64_t* __restrict__ pseudo,
-                                                             const float* __restrict__ sc, float cw1, float cw2,
-                                                             const float* __restrict__ gscale) {
+__device__ __forceinline__ void unsup_bwd_body(const HeadPtrs<D>& z, const HeadOutPtrs<D>& dz, int HW, long ngroups, long N,
+                                               const int64_t* __restrict__ pseudo,
+                                               const float* __restrict__ sc, float cw1, float cw2,
+                                               const float* __restrict__ gscale, int bid, int nblk) {
     const float gs = gscale ? gscale[0] : 1.f;
     const float invN = 1.f / (float)N;
     // per-head constants: coefficient of exp(-v_k) in g_k, and of the (CE + Dice) term
@@ -372,7 +443,7 @@ __global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, Head
     const float* __restrict__ A1 = sc + UAPS_U_A1(D, C);
     const float* __restrict__ A2 = sc + UAPS_U_A2(D, C);
 
-    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+    for (long g = (long)bid * kThreads + threadIdx.x; g < ngroups; g += (long)nblk * kThreads) {
         const long n0 = g * VEC;
         const long b = n0 / HW;
         const long hw = n0 - b * HW;
@@ -443,20 +514,27 @@ __global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, Head
             for (int c = 0; c < C; ++c) store_vec<VEC>(dz.p[k] + base + (long)c * HW, zv[k][c]);
     }
 }
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, HeadOutPtrs<D> dz, int HW, long ngroups, long N,
+                                                             const int64_t* __restrict__ pseudo,
+                                                             const float* __restrict__ sc, float cw1, float cw2,
+                                                             const float* __restrict__ gscale) {
+    unsup_bwd_body<D, C, VEC>(z, dz, HW, ngroups, N, pseudo, sc, cw1, cw2, gscale, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // --------------------------------------------------------------------------------------------------
 // F3 backward.  Bytes per pixel: 4DC + 8 read, 4DC written.
 // --------------------------------------------------------------------------------------------------
 template <int D, int C, int VEC>
-__global__ __launch_bounds__(kThreads) void sup_bwd_kernel(HeadPtrs<D> z, HeadOutPtrs<D> dz, int HW, long ngroups, long N,
-                                                           const int64_t* __restrict__ labels,
-                                                           const float* __restrict__ sc, float ce_coef,
-                                                           float dice_coef, const float* __restrict__ gscale) {
+__device__ __forceinline__ void sup_bwd_body(const HeadPtrs<D>& z, const HeadOutPtrs<D>& dz, int HW, long ngroups, long N,
+                                             const int64_t* __restrict__ labels,
+                                             const float* __restrict__ sc, float ce_coef,
+                                             float dice_coef, const float* __restrict__ gscale, int bid, int nblk) {
     const float gs0 = gscale ? gscale[0] : 1.f;
     const float gce = gs0 * ce_coef / (float)N, gdc = gs0 * dice_coef;
     const float* __restrict__ A1 = sc + UAPS_S_A1(D, C);
     const float* __restrict__ A2 = sc + UAPS_S_A2(D, C);
-    for (long g = (long)blockIdx.x * kThreads + threadIdx.x; g < ngroups; g += (long)gridDim.x * kThreads) {
+    for (long g = (long)bid * kThreads + threadIdx.x; g < ngroups; g += (long)nblk * kThreads) {
         const long n0 = g * VEC;
         const long b = n0 / HW;
         const long hw = n0 - b * HW;
@@ -490,6 +568,37 @@ __global__ __launch_bounds__(kThreads) void sup_bwd_kernel(HeadPtrs<D> z, HeadOu
             for (int c = 0; c < C; ++c) store_vec<VEC>(dz.p[k] + base + (long)c * HW, zv[c]);
         }
     }
+}
+template <int D, int C, int VEC>
+__global__ __launch_bounds__(kThreads) void sup_bwd_kernel(HeadPtrs<D> z, HeadOutPtrs<D> dz, int HW, long ngroups, long N,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ sc, float ce_coef,
+                                                           float dice_coef, const float* __restrict__ gscale) {
+    sup_bwd_body<D, C, VEC>(z, dz, HW, ngroups, N, labels, sc, ce_coef, dice_coef, gscale, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// --------------------------------------------------------------------------------------------------
+// The loss block of a training step as ONE forward and ONE backward launch: blocks [0, nb_s) run the supervised branch
+// on the labelled logits, blocks [nb_s, gridDim.x) the unsupervised branch on the unlabelled logits (UAPS_train.py:
+// 194-218 and 186-189, 223-277).  VS / VU: pixels per thread of the two branches.
+// --------------------------------------------------------------------------------------------------
+template <int D, int C, int VS, int VU>
+__global__ __launch_bounds__(kThreads) void pair_fwd_kernel(HeadPtrs<D> zl, HeadPtrs<D> zu, HeadWeights<D> w, int HW, long N,
+                                                            const int64_t* __restrict__ labels, int64_t* __restrict__ pseudo,
+                                                            float* __restrict__ var, float* __restrict__ part_s,
+                                                            float* __restrict__ part_u, int nb_s) {
+    if ((int)blockIdx.x < nb_s) sup_fwd_body<D, C, VS>(zl, HW, N / VS, labels, part_s, (int)blockIdx.x, nb_s);
+    else unsup_fwd_body<D, C, VU>(zu, w, HW, N / VU, N, pseudo, var, part_u, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
+}
+// Nloss: the pixel count the scalars were finalised with (= N, or the global count after an exchange of the sums)
+template <int D, int C, int VS, int VU>
+__global__ __launch_bounds__(kThreads) void pair_bwd_kernel(HeadPtrs<D> zl, HeadPtrs<D> zu, HeadOutPtrs<D> dl, HeadOutPtrs<D> du, int HW,
+                                                            long N, long Nloss, const int64_t* __restrict__ labels,
+                                                            const int64_t* __restrict__ pseudo, const float* __restrict__ sscal,
+                                                            const float* __restrict__ uscal, float ce_coef, float dice_coef, float cw1,
+                                                            float cw2, const float* __restrict__ gscale, int nb_s) {
+    if ((int)blockIdx.x < nb_s) sup_bwd_body<D, C, VS>(zl, dl, HW, N / VS, Nloss, labels, sscal, ce_coef, dice_coef, gscale, (int)blockIdx.x, nb_s);
+    else unsup_bwd_body<D, C, VU>(zu, du, HW, N / VU, Nloss, pseudo, uscal, cw1, cw2, gscale, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
 }
 
 }  // namespace uaps

@@ -1,4 +1,4 @@
-"""Data-parallel gradient exchange for the UAPS step: one process per GPU, RCCL over xGMI.
+"""Data-parallel exchange steps of the UAPS step: one process per GPU, RCCL over xGMI.
 
 The reference only has single-process nn.DataParallel (UAPS_model.py:13), whose backward does an
 implicit reduce-add of the 208 gradient tensors onto GPU 0.  Here every rank runs the whole step
@@ -32,14 +32,32 @@ def rank() -> int:
     return dist.get_rank() if is_dist() else 0
 
 
-class GradBuckets:
-    """Flattens each bucket's gradients with one `cat`, all-reduces it asynchronously, and re-points
-    `.grad` of every parameter at its slice of the reduced flat buffer (no copy back)."""
+def exchange_sums(group=None):
+    """The `exchange` callable of losses.uaps_pair_loss for gathered-batch loss statistics: sums the tensor of raw loss sums
+    over the ranks in place and returns the number of ranks (a second, latency-only collective of
+    D (2C + 3) + ... doubles between the loss block's forward and its finalize)."""
+    def _x(t: torch.Tensor) -> int:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return dist.get_world_size(group)
+    return _x
 
-    def __init__(self, model: torch.nn.Module, process_group=None, overlap: bool = True):
+
+class GradBuckets:
+    """One flat gradient buffer per bucket, allocated once.  Every parameter's slice (16-byte aligned) is registered as the
+    destination of its gradient (_graddest): the backward kernels write there, autograd adopts the view as `.grad`, and the
+    bucket's asynchronous all-reduce runs on the flat buffer in place as soon as the bucket's last gradient exists -- no
+    per-step concatenation, no copy back.  A gradient that arrives elsewhere (an op without destination support) is copied
+    into its slice first, so the result never depends on which path produced it.
+
+    average=True divides by the world size (standard data parallelism: every rank's loss is a mean over its own shard);
+    average=False leaves the SUM, for losses already normalised by the global pixel count (losses._PairLoss exchange)."""
+
+    def __init__(self, model: torch.nn.Module, process_group=None, overlap: bool = True, average: bool = True):
+        from . import _graddest
         self.group = process_group
         self.world = dist.get_world_size(process_group) if is_dist() else 1
         self.overlap = overlap
+        self.average = average
         groups: "OrderedDict[str, List[torch.nn.Parameter]]" = OrderedDict()
         for name, p in model.named_parameters():
             if not p.requires_grad:
@@ -52,7 +70,18 @@ class GradBuckets:
         self.names = order
         self._pending = [0] * len(self.buckets)
         self._handles: List = []
-        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        self._flat: List[torch.Tensor] = []
+        self._offsets: List[List[int]] = []
+        for params in self.buckets:
+            offs, off = [], 0
+            for p in params:
+                offs.append(off)
+                off += (p.numel() + 3) // 4 * 4                      # 16-byte aligned slices (vector loads in the Adam kernel)
+            flat = torch.zeros(off, dtype=params[0].dtype, device=params[0].device)
+            self._flat.append(flat)
+            self._offsets.append(offs)
+            for p, o in zip(params, offs):
+                _graddest.register(p, flat, o)
         self._hooks = []
         if self.world > 1 and overlap:
             for bi, params in enumerate(self.buckets):
@@ -71,15 +100,25 @@ class GradBuckets:
                 self._launch(bi)
         return hook
 
+    def _view(self, bi: int, k: int) -> torch.Tensor:
+        p = self.buckets[bi][k]
+        o = self._offsets[bi][k]
+        return self._flat[bi][o:o + p.numel()].view_as(p)
+
     def _launch(self, bi: int):
-        params = self.buckets[bi]
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        self._flat[bi] = flat
+        flat = self._flat[bi]
+        for k, p in enumerate(self.buckets[bi]):
+            v = self._view(bi, k)
+            if p.grad is None:
+                raise RuntimeError(f"bucket {self.names[bi]}: a parameter got no gradient this step")
+            if p.grad.data_ptr() != v.data_ptr():                    # produced outside the flat buffer: copy in, re-point
+                v.copy_(p.grad)
+                p.grad = v
         h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append((bi, h))
 
     def finish(self):
-        """Call after backward(): waits for the collectives, averages, re-points the gradients."""
+        """Call after backward(): waits for the collectives and (average=True) divides by the world size."""
         if self.world == 1:
             return
         if not self.overlap:
@@ -92,19 +131,18 @@ class GradBuckets:
         inv = 1.0 / self.world
         for bi, h in self._handles:
             h.wait()
-            flat = self._flat[bi]
-            flat.mul_(inv)
-            off = 0
-            for p in self.buckets[bi]:
-                n = p.numel()
-                p.grad = flat[off:off + n].view_as(p)
-                off += n
+            if self.average:
+                self._flat[bi].mul_(inv)
         self.reset()
 
     def remove(self):
+        from . import _graddest
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for params in self.buckets:
+            for p in params:
+                _graddest.unregister(p)
 
 
 def broadcast_model(model: torch.nn.Module, src: int = 0, group=None):

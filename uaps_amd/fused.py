@@ -9,7 +9,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _graddest, _lib
 from .perturb import _RngState
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -84,6 +84,7 @@ class _BnActTrain(torch.autograd.Function):
         _lib.check(rc, "uaps_bn_act_fwd_train_grouped")
         ctx.save_for_backward(y, gamma, beta, stats)
         ctx.meta = (float(slope), float(drop_p), seed, offset, conv_bias is not None, groups)
+        ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None)
         return out
 
     @staticmethod
@@ -94,9 +95,9 @@ class _BnActTrain(torch.autograd.Function):
         B, Cc, H, W = y.shape
         dev = y.device
         dy = torch.empty_like(y)
-        # rows: dgamma, dbeta, d(conv bias); the conv bias feeds a train-mode BatchNorm, so its gradient (the sum of dy
+        # dgamma, dbeta, d(conv bias); the conv bias feeds a train-mode BatchNorm, so its gradient (the sum of dy
         # over a channel) is exactly zero -- written by the same finalize kernel instead of a fill launch
-        dgb = torch.empty((3, Cc), dtype=torch.float32, device=dev)
+        dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys]
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
             rc = _lib.lib().uaps_bn_act_bwd_grouped_bias(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
@@ -204,6 +205,7 @@ class _BnActConv(torch.autograd.Function):
             _lib.check(rc, "uaps_conv_fwd_bn")
         ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks)
+        ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
         if want_stats:
             ctx.mark_non_differentiable(zstats)
             return z, zstats
@@ -224,11 +226,11 @@ class _BnActConv(torch.autograd.Function):
         n = C.c_size_t()
         _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
         cws = _conv._workspace(dev, n.value)
-        dw = torch.empty((Cout, Cc, ks, ks), dtype=torch.float32, device=dev)
+        dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
         want_db = has_bias and ctx.needs_input_grad[13]
-        db = torch.empty(Cout, dtype=torch.float32, device=dev) if want_db else None
+        db = _graddest.take(ctx.keys[4], (Cout,), dev) if want_db else None
         dy = torch.empty_like(y)
-        dgb = torch.empty((3, Cc), dtype=torch.float32, device=dev)     # dgamma, dbeta, d(conv bias) = 0
+        dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys[:3]]      # dgamma, dbeta, d(conv bias) = 0
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)

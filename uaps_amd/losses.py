@@ -7,6 +7,8 @@ PyTorch ops or to the CPU.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
 
@@ -37,6 +39,10 @@ _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 # bench.py sets this to a dict {kernel name: [(start_event, end_event), ...]} to time individual
 # launches with HIP events on the stream they run on; None (the default) records nothing.
 KERNEL_EVENTS: Optional[Dict[str, list]] = None
+
+
+# tuning knob of the pair-loss kernels (cap on the blocks per branch; 0 = one group of pixels per thread)
+PAIR_CFG = int(os.environ.get("UAPS_PAIR_CFG", "0"))
 
 
 class _timed:
@@ -246,45 +252,72 @@ def ce_loss(logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
 
 class _PairLoss(torch.autograd.Function):
     """Supervised branch on rows [:B] and unsupervised branch on rows [B:] of D logit tensors [2B,C,H,W] (the output
-    of UNet_UAPS.forward_pair); the backward writes both halves of the D gradient tensors directly."""
+    of UNet_UAPS.forward_pair) as ONE forward launch (+ finalize) and ONE backward launch (uaps_pairloss_*); the backward
+    writes both halves of the D gradient tensors directly.
+
+    `exchange`: None, or a callable that sums a float64 device tensor of raw loss sums over the ranks IN PLACE and returns the
+    number of ranks: the CE means, Dice sums and uncertainty means are then those of the gathered global batch, which is what
+    the reference's nn.DataParallel computes (UAPS_model.py:13, UAPS_train.py:194-277); the parameter gradients of the ranks
+    must then be ADDED (not averaged), see uaps_amd.dist.GradBuckets(average=False)."""
 
     @staticmethod
-    def forward(ctx, labels, w, cw1, cw2, eps, want_var, *logits):
+    def forward(ctx, labels, w, cw1, cw2, eps, want_var, exchange, halves, *logits):
+        """halves=True: `logits` = D tensors [2B,C,H,W], rows [:B] labelled / rows [B:] unlabelled (forward_pair);
+        halves=False: `logits` = D labelled tensors followed by D unlabelled tensors, [B,C,H,W] each."""
         ctx.set_materialize_grads(False)
-        zs, D, B2, Cc, H, W = _check_heads(logits, "uaps_pair_loss")
-        if B2 % 2:
-            raise ValueError("uaps_pair_loss: the batch must hold a labelled and an unlabelled half of equal size")
-        B = B2 // 2
+        if halves:
+            zs, D, B2, Cc, H, W = _check_heads(logits, "uaps_pair_loss")
+            if B2 % 2:
+                raise ValueError("uaps_pair_loss: the batch must hold a labelled and an unlabelled half of equal size")
+            B = B2 // 2
+            half = B * Cc * H * W * 4
+            lab_addr, un_addr = [z.data_ptr() for z in zs], [z.data_ptr() + half for z in zs]
+        else:
+            if len(logits) % 2:
+                raise ValueError("uaps_step_loss: as many labelled as unlabelled heads")
+            zl, D, B, Cc, H, W = _check_heads(logits[: len(logits) // 2], "uaps_step_loss")
+            zu, D2, Bu, Cu, Hu, Wu = _check_heads(logits[len(logits) // 2:], "uaps_step_loss")
+            if (D2, Bu, Cu, Hu, Wu) != (D, B, Cc, H, W):
+                raise ValueError("uaps_step_loss: labelled and unlabelled logits must have the same shape for the one-launch form")
+            zs = list(zl) + list(zu)
+            lab_addr, un_addr = [z.data_ptr() for z in zl], [z.data_ptr() for z in zu]
         dev = zs[0].device
         if labels.shape != (B, H, W) or labels.device != dev:
             raise ValueError(f"labels must be [B,H,W]={B, H, W} on {dev}, got {tuple(labels.shape)} on {labels.device}")
         y = labels.to(torch.int64).contiguous()
         L = _lib.lib()
-        half = B * Cc * H * W * 4
-        lab_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs])
-        un_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in zs])
+        lab_p = (C.c_void_p * D)(*lab_addr)
+        un_p = (C.c_void_p * D)(*un_addr)
         need = C.c_size_t()
-        _lib.check(L.uaps_loss_workspace_bytes(D, B, Cc, H, W, C.byref(need)), "uaps_loss_workspace_bytes")
+        _lib.check(L.uaps_pairloss_workspace_bytes(D, Cc, C.byref(need)), "uaps_pairloss_workspace_bytes")
         ws = _workspace(dev, need.value)
         so, uo = _s_off(D, Cc), _u_off(D, Cc)
         sscal = torch.empty(so["n"], dtype=torch.float32, device=dev)
         uscal = torch.empty(uo["n"], dtype=torch.float32, device=dev)
         pseudo = torch.empty((B, H, W), dtype=torch.int64, device=dev)
         var = torch.empty((D, B, H, W), dtype=torch.float32, device=dev) if want_var else None
+        sums = None
+        if exchange is not None:
+            ns = C.c_int()
+            _lib.check(L.uaps_pairloss_num_sums(D, Cc, C.byref(ns)), "uaps_pairloss_num_sums")
+            sums = torch.empty(ns.value, dtype=torch.float64, device=dev)
         w64 = (C.c_double * D)(*[float(x) for x in w])
         st = _lib.current_stream(dev)
+        n_loss = B * H * W
         with _lib.device_guard(dev):
-            with _timed("uaps_sup_fwd"):
-                rc = L.uaps_sup_fwd(lab_p, y.data_ptr(), D, B, Cc, H, W, 0.5 / D, 0.5 / D, float(eps), sscal.data_ptr(),
-                                    ws.data_ptr(), ws.numel(), st)
-            _lib.check(rc, "uaps_sup_fwd")
-            with _timed("uaps_unsup_fwd"):
-                rc = L.uaps_unsup_fwd(un_p, w64, D, B, Cc, H, W, float(cw1), float(cw2), float(eps), pseudo.data_ptr(),
-                                      var.data_ptr() if want_var else None, uscal.data_ptr(), ws.data_ptr(), ws.numel(), st)
-            _lib.check(rc, "uaps_unsup_fwd")
+            with _timed("uaps_pair_fwd"):
+                rc = L.uaps_pairloss_fwd(lab_p, un_p, y.data_ptr(), w64, D, B, Cc, H, W, float(cw1), float(cw2), float(eps),
+                                         pseudo.data_ptr(), var.data_ptr() if want_var else None, sscal.data_ptr(), uscal.data_ptr(),
+                                         sums.data_ptr() if sums is not None else None, ws.data_ptr(), ws.numel(), PAIR_CFG, st)
+            _lib.check(rc, "uaps_pairloss_fwd")
+            if sums is not None:
+                n_loss *= int(exchange(sums))                 # the one exchange step of the loss block (SURVEY 8e)
+                rc = L.uaps_pairloss_finalize_sums(sums.data_ptr(), D, Cc, n_loss, float(cw1), float(cw2), float(eps), sscal.data_ptr(),
+                                                   uscal.data_ptr(), st)
+                _lib.check(rc, "uaps_pairloss_finalize_sums")
         sup, unsup = sscal[so["sup"]].clone(), uscal[uo["loss"]].clone()
         ctx.save_for_backward(y, pseudo, sscal, uscal, *zs)
-        ctx.meta = (D, B, Cc, H, W, float(cw1), float(cw2))
+        ctx.meta = (D, B, Cc, H, W, float(cw1), float(cw2), n_loss, bool(halves))
         outs = (sup + unsup, sup, unsup, pseudo, sscal, uscal) + ((var,) if want_var else ())
         ctx.mark_non_differentiable(*outs[1:])
         return outs
@@ -292,27 +325,30 @@ class _PairLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *unused):
         y, pseudo, sscal, uscal, *zs = ctx.saved_tensors
-        D, B, Cc, H, W, cw1, cw2 = ctx.meta
+        D, B, Cc, H, W, cw1, cw2, n_loss, halves = ctx.meta
         if g_loss is None:
-            return (None,) * (6 + D)
+            return (None,) * (8 + len(zs))
         dev = zs[0].device
         g = g_loss.contiguous().to(torch.float32)
-        half = B * Cc * H * W * 4
         dz = [torch.empty_like(z) for z in zs]
         L = _lib.lib()
         st = _lib.current_stream(dev)
-        lab_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs])
-        un_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in zs])
-        dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz])
-        dun_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in dz])
-        with _lib.device_guard(dev):
-            with _timed("uaps_sup_bwd"):
-                rc = L.uaps_sup_bwd(lab_p, y.data_ptr(), sscal.data_ptr(), 0.5 / D, 0.5 / D, g.data_ptr(), D, B, Cc, H, W, dlab_p, st)
-            _lib.check(rc, "uaps_sup_bwd")
-            with _timed("uaps_unsup_bwd"):
-                rc = L.uaps_unsup_bwd(un_p, pseudo.data_ptr(), uscal.data_ptr(), cw1, cw2, g.data_ptr(), D, B, Cc, H, W, dun_p, st)
-            _lib.check(rc, "uaps_unsup_bwd")
-        return (None, None, None, None, None, None) + tuple(dz)
+        if halves:
+            half = B * Cc * H * W * 4
+            lab_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs])
+            un_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in zs])
+            dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz])
+            dun_p = (C.c_void_p * D)(*[z.data_ptr() + half for z in dz])
+        else:
+            lab_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs[:D]])
+            un_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs[D:]])
+            dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz[:D]])
+            dun_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz[D:]])
+        with _lib.device_guard(dev), _timed("uaps_pair_bwd"):
+            rc = L.uaps_pairloss_bwd(lab_p, un_p, y.data_ptr(), pseudo.data_ptr(), sscal.data_ptr(), uscal.data_ptr(), cw1, cw2,
+                                     g.data_ptr(), D, B, Cc, H, W, n_loss, dlab_p, dun_p, PAIR_CFG, st)
+        _lib.check(rc, "uaps_pairloss_bwd")
+        return (None, None, None, None, None, None, None, None) + tuple(dz)
 
 
 class StepLoss(NamedTuple):
@@ -325,17 +361,25 @@ class StepLoss(NamedTuple):
     unsup_scalars: torch.Tensor
 
 
-def uaps_pair_loss(pair_logits, labels, w, cw1, cw2, eps=1e-7, return_var=False) -> StepLoss:
+def uaps_pair_loss(pair_logits, labels, w, cw1, cw2, eps=1e-7, return_var=False, exchange=None) -> StepLoss:
     """uaps_step_loss for the output of UNet_UAPS.forward_pair: D tensors [2B,C,H,W] whose rows [:B] are the labelled
-    batch (supervised branch, UAPS_train.py:194-218) and rows [B:] the unlabelled one (:186-189, 223-282)."""
+    batch (supervised branch, UAPS_train.py:194-218) and rows [B:] the unlabelled one (:186-189, 223-282).
+    `exchange`: see _PairLoss (gathered-batch loss statistics across ranks)."""
     if len(w) != len(pair_logits):
         raise ValueError("one mixing weight per head")
-    out = _PairLoss.apply(labels, tuple(float(x) for x in w), cw1, cw2, eps, bool(return_var), *pair_logits)
+    out = _PairLoss.apply(labels, tuple(float(x) for x in w), cw1, cw2, eps, bool(return_var), exchange, True, *pair_logits)
     return StepLoss(out[0], out[1], out[2], out[3], out[6] if return_var else None, out[4], out[5])
 
 
-def uaps_step_loss(lab_logits, labels, un_logits, w, cw1, cw2, eps=1e-7, return_var=False) -> StepLoss:
-    """loss = supervised_loss + cw1*ps_loss + cw2*l_uncert  (UAPS_train.py:282)."""
+def uaps_step_loss(lab_logits, labels, un_logits, w, cw1, cw2, eps=1e-7, return_var=False, exchange=None) -> StepLoss:
+    """loss = supervised_loss + cw1*ps_loss + cw2*l_uncert  (UAPS_train.py:282).  With `exchange` (gathered-batch statistics
+    across ranks, see _PairLoss) the one-launch pair kernels run on the two logit sets; otherwise the two branch kernels."""
+    if exchange is not None:
+        if len(w) != len(un_logits):
+            raise ValueError("one mixing weight per head")
+        out = _PairLoss.apply(labels, tuple(float(x) for x in w), cw1, cw2, eps, bool(return_var), exchange, False,
+                              *(tuple(lab_logits) + tuple(un_logits)))
+        return StepLoss(out[0], out[1], out[2], out[3], out[6] if return_var else None, out[4], out[5])
     s = uaps_sup_loss(lab_logits, labels, eps)
     u = uaps_unsup_loss(un_logits, w, cw1, cw2, eps, return_var)
     return StepLoss(s.loss + u.loss, s.loss, u.loss, u.pseudo, u.var, s.scalars, u.scalars)

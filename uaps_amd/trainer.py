@@ -23,7 +23,7 @@ class UAPSTrainer:
     def __init__(self, model: torch.nn.Module, base_lr: float = 1e-3, consistency1: float = 0.1,
                  consistency2: float = 0.1, consistency_rampup: float = 200, ramp_divisor: int = 80,
                  seed: int = 1337, loss_fn: Optional[Callable] = None, overlap_comm: bool = True,
-                 track_metrics: bool = True, pair_forward: bool = True):
+                 track_metrics: bool = True, pair_forward: bool = True, gathered_loss: bool = False):
         self.model = model
         params = list(model.parameters())
         self.device = params[0].device
@@ -45,7 +45,13 @@ class UAPSTrainer:
         # draws keep the two-forward semantics) instead of two forwards; needs the HIP kernels, i.e. a GPU model
         self.pair_forward = pair_forward and on_gpu and loss_fn is None and hasattr(model, "forward_pair")
         self.track_metrics = track_metrics and loss_fn is None
-        self.buckets = udist.GradBuckets(model, overlap=overlap_comm) if self.world > 1 else None
+        # gathered_loss: CE means / Dice sums / uncertainty means over the batch of ALL ranks, as the reference's
+        # nn.DataParallel computes them on the gathered logits (UAPS_model.py:13, UAPS_train.py:194-277): one extra
+        # latency-only all-reduce of the raw loss sums per step, and the ranks' gradients are added instead of averaged.
+        # Default off = standard data parallelism (every rank's loss is normalised over its own shard).
+        self.gathered_loss = bool(gathered_loss) and self.world > 1
+        self.exchange = udist.exchange_sums() if self.gathered_loss else None
+        self.buckets = udist.GradBuckets(model, overlap=overlap_comm, average=not self.gathered_loss) if self.world > 1 else None
         self._cms = []                                        # one on-device C x C confusion matrix per training step
         self.last: Dict[str, torch.Tensor] = {}
 
@@ -63,7 +69,7 @@ class UAPSTrainer:
             both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
             if w is None:
                 w = self.mix_rng.dirichlet(np.ones(len(both)), size=1)[0]        # :251
-            out = losses.uaps_pair_loss(both, y_l, w, cw1, cw2)                   # :186-282
+            out = losses.uaps_pair_loss(both, y_l, w, cw1, cw2, exchange=self.exchange)   # :186-282
             lab = tuple(z[: x_l.shape[0]] for z in both)
         else:
             lab = self.model(x_l)                                                 # UAPS_train.py:177
@@ -72,7 +78,10 @@ class UAPSTrainer:
                 lab, un = (lab,), (un,)
             if w is None:
                 w = self.mix_rng.dirichlet(np.ones(len(un)), size=1)[0]          # :251
-            out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                         # :186-282
+            if self.exchange is not None:
+                out = self.loss_fn(lab, y_l, un, w, cw1, cw2, exchange=self.exchange)
+            else:
+                out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
         self.optimizer.zero_grad(set_to_none=True)                                # :285
         out.loss.backward()                                                       # :287
         if self.buckets is not None:
