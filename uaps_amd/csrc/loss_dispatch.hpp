@@ -25,6 +25,9 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 // widest per-thread pixel vector the register budget allows for D*C live logits per pixel
 template <int D, int C> constexpr int unsup_vec() { return D * C <= 16 ? 4 : (D * C <= 32 ? 2 : 1); }
 
+// pixels per thread of the double-buffered unsupervised forward of the pair kernel (two register sets of D*C*VEC logits)
+template <int D, int C> constexpr int unsup_vec_pf() { return D * C <= 16 ? 2 : 1; }
+
 inline int grid_for(long ngroups) {
     long b = (ngroups + kThreads - 1) / kThreads;
     if (b > kMaxBlocks) b = kMaxBlocks;
@@ -95,12 +98,17 @@ inline bool pair_vec_ok(const PairArgs& a, int vec, bool outs) {
     if (a.var && !aligned_to(a.var, 16)) return false;
     return true;
 }
-// blocks of one branch: one group per thread up to kMaxBlocks; cfg > 0 caps the count (tuning: fewer, longer-lived blocks)
-inline int pair_grid(long ngroups, int cfg) {
+// blocks of one branch: persistent blocks, a few groups of pixels per thread (the forward prefetches the next group while it
+// computes the current one); `cap` <= kMaxBlocks
+inline int pair_grid(long ngroups, int cap) {
     int b = grid_for(ngroups);
-    if (cfg > 0 && b > cfg) b = cfg;
+    if (cap > 0 && b > cap) b = cap;
     return b;
 }
+// default split of the 2 x 256 resident blocks (two per CU at two waves per SIMD) between the branches, by their work;
+// cfg = (supervised cap << 16) | unsupervised cap overrides it (tools/bench_loss.py)
+inline int pair_cap_s(int cfg) { return (cfg >> 16) & 0xfff ? (cfg >> 16) & 0xfff : 192; }      // bits 28-30: experiment variants
+inline int pair_cap_u(int cfg) { return cfg & 0xfff ? cfg & 0xfff : 320; }
 
 int launch_pair_fwd(const PairArgs& a);
 int launch_pair_bwd(const PairArgs& a);

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rn_math.hpp"
 
 namespace uaps {
@@ -138,6 +139,59 @@ template <int D, int C> struct SupLayout {
 // --------------------------------------------------------------------------------------------------
 // (bid, nblk): this block's index among the nblk blocks that share the work -- blockIdx.x / gridDim.x for the stand-alone
 // kernels, a sub-range of the grid for the pair kernels below
+// the per-pixel arithmetic of one group of VEC pixels: zv -> pseudo-labels yv, variance maps varv, running sums acc
+template <int D, int C, int VEC>
+__device__ __forceinline__ void unsup_fwd_group(const float (&zv)[D][C][VEC], const HeadWeights<D>& w, float (&acc)[UnsupLayout<D, C>::NS],
+                                                int (&yv)[VEC], float (&varv)[D][VEC]) {
+    using L = UnsupLayout<D, C>;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float p[D][C], lp[D][C], m[C];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float zz[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) zz[c] = zv[k][c][v];
+            softmax_regs<C>(zz, p[k], lp[k]);
+        }
+        // mean prediction (UAPS_train.py:223) and the mixture that feeds arg-max (:252-255):
+        // separate multiply and add roundings, left to right, like the reference's tensor ops.
+        float xm = 0.f;
+        int y = 0;
+        float best = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float s = p[0][c];
+            float mix = mul_rn(w.w[0], p[0][c]);
+#pragma unroll
+            for (int k = 1; k < D; ++k) { s = add_rn(s, p[k][c]); mix = add_rn(mix, mul_rn(w.w[k], p[k][c])); }
+            m[c] = s / (float)D;
+            xm += (m[c] > 0.f) ? m[c] * flog(m[c]) : 0.f;           // xlogy(m, m)
+            if (c == 0 || mix > best) { best = mix; y = c; }          // first maximum wins, as torch.argmax
+        }
+        yv[v] = y;
+        float oh[C];                                 // one-hot of the pseudo-label: one compare + select per class, then plain
+#pragma unroll                                       // multiply-adds (p * 1 and p * 0 are exact, so the sums are unchanged)
+        for (int c = 0; c < C; ++c) { oh[c] = (y == c) ? 1.f : 0.f; acc[L::CNT + c] += oh[c]; }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            float dot = 0.f, lpy = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                dot += m[c] * lp[k][c];
+                acc[L::P + k * C + c] += p[k][c];
+                acc[L::I + k * C + c] = __builtin_fmaf(oh[c], p[k][c], acc[L::I + k * C + c]);
+                lpy = __builtin_fmaf(oh[c], lp[k][c], lpy);
+            }
+            const float vk = xm - dot;                               // sum_c KL(m || p_k)  (:226)
+            varv[k][v] = vk;
+            acc[L::V + k] += vk;
+            acc[L::E + k] += fexp(-vk);                              // :227
+            acc[L::CE + k] -= lpy;
+        }
+    }
+}
+
 template <int D, int C, int VEC>
 __device__ __forceinline__ void unsup_fwd_body(const HeadPtrs<D>& z, const HeadWeights<D>& w, int HW, long ngroups,
                                                long N, int64_t* __restrict__ pseudo,
@@ -157,59 +211,60 @@ __device__ __forceinline__ void unsup_fwd_body(const HeadPtrs<D>& z, const HeadW
         for (int k = 0; k < D; ++k)
 #pragma unroll
             for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[k][c]);
-
         int yv[VEC];
         float varv[D][VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            float p[D][C], lp[D][C], m[C];
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                float zz[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c) zz[c] = zv[k][c][v];
-                softmax_regs<C>(zz, p[k], lp[k]);
-            }
-            // mean prediction (UAPS_train.py:223) and the mixture that feeds arg-max (:252-255):
-            // separate multiply and add roundings, left to right, like the reference's tensor ops.
-            float xm = 0.f;
-            int y = 0;
-            float best = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float s = p[0][c];
-                float mix = mul_rn(w.w[0], p[0][c]);
-#pragma unroll
-                for (int k = 1; k < D; ++k) { s = add_rn(s, p[k][c]); mix = add_rn(mix, mul_rn(w.w[k], p[k][c])); }
-                m[c] = s / (float)D;
-                xm += (m[c] > 0.f) ? m[c] * flog(m[c]) : 0.f;           // xlogy(m, m)
-                if (c == 0 || mix > best) { best = mix; y = c; }          // first maximum wins, as torch.argmax
-            }
-            yv[v] = y;
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[L::CNT + c] += (y == c) ? 1.f : 0.f;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                float dot = 0.f, lpy = lp[k][0];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    dot += m[c] * lp[k][c];
-                    acc[L::P + k * C + c] += p[k][c];
-                    acc[L::I + k * C + c] += (y == c) ? p[k][c] : 0.f;
-                    if (c > 0) lpy = (y == c) ? lp[k][c] : lpy;
-                }
-                const float vk = xm - dot;                               // sum_c KL(m || p_k)  (:226)
-                varv[k][v] = vk;
-                acc[L::V + k] += vk;
-                acc[L::E + k] += fexp(-vk);                              // :227
-                acc[L::CE + k] -= lpy;
-            }
-        }
+        unsup_fwd_group<D, C, VEC>(zv, w, acc, yv, varv);
         store_labels<VEC>(pseudo + n0, yv);
         if (var != nullptr) {
 #pragma unroll
             for (int k = 0; k < D; ++k) store_vec<VEC>(var + (long)k * N + n0, varv[k]);
         }
+    }
+    block_reduce_store<L::NS>(acc, partials, bid, nblk);
+}
+
+// The same with the logits of the thread's NEXT group fetched while the current group is computed (two register sets, the
+// loop body written out for both): these kernels hold ~200 registers (48 running sums + the D*C*VEC logits), i.e. two waves
+// per SIMD, and a thread that loads, waits, computes and only then loads again leaves HBM idle for the ~1700 instructions
+// of a group.  For the persistent pair kernels (a few groups per thread).
+template <int D, int C, int VEC>
+__device__ __forceinline__ void unsup_fwd_body_pf(const HeadPtrs<D>& z, const HeadWeights<D>& w, int HW, long ngroups,
+                                                  long N, int64_t* __restrict__ pseudo,
+                                                  float* __restrict__ var, float* __restrict__ partials, int bid, int nblk) {
+    using L = UnsupLayout<D, C>;
+    float acc[L::NS];
+#pragma unroll
+    for (int i = 0; i < L::NS; ++i) acc[i] = 0.f;
+    const long stride = (long)nblk * kThreads;
+    auto load_group = [&](long g, float (&zv)[D][C][VEC]) {
+        const long n0 = g * VEC, b = n0 / HW, hw = n0 - b * HW, base = b * C * (long)HW + hw;
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[k][c]);
+    };
+    auto finish_group = [&](long g, const float (&zv)[D][C][VEC]) {
+        int yv[VEC];
+        float varv[D][VEC];
+        unsup_fwd_group<D, C, VEC>(zv, w, acc, yv, varv);
+        const long n0 = g * VEC;
+        store_labels<VEC>(pseudo + n0, yv);
+        if (var != nullptr) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) store_vec<VEC>(var + (long)k * N + n0, varv[k]);
+        }
+    };
+    float za[D][C][VEC], zb[D][C][VEC];
+    long g = (long)bid * kThreads + threadIdx.x;
+    if (g < ngroups) load_group(g, za);
+    while (g < ngroups) {
+        if (g + stride < ngroups) load_group(g + stride, zb);
+        finish_group(g, za);
+        g += stride;
+        if (g >= ngroups) break;
+        if (g + stride < ngroups) load_group(g + stride, za);
+        finish_group(g, zb);
+        g += stride;
     }
     block_reduce_store<L::NS>(acc, partials, bid, nblk);
 }
@@ -270,6 +325,79 @@ __device__ __forceinline__ void sup_fwd_body(const HeadPtrs<D>& z, int HW, long 
     }
     block_reduce_store<L::NS>(acc, partials, bid, nblk);
 }
+// The supervised forward with the next head's logits (and, behind the last head, the next group's labels and first head)
+// fetched while the current head is computed: the pair kernel runs this branch at the register budget of the
+// unsupervised one (two waves per SIMD), where the plain loop above would wait out every load.
+template <int D, int C, int VEC>
+__device__ __forceinline__ void sup_fwd_body_pf(const HeadPtrs<D>& z, int HW, long ngroups,
+                                                const int64_t* __restrict__ labels,
+                                                float* __restrict__ partials, int bid, int nblk) {
+    using L = SupLayout<D, C>;
+    float acc[L::NS];
+#pragma unroll
+    for (int i = 0; i < L::NS; ++i) acc[i] = 0.f;
+    const long stride = (long)nblk * kThreads;
+    auto load_head = [&](long g, int k, float (&zv)[C][VEC]) {
+        const long n0 = g * VEC, b = n0 / HW, hw = n0 - b * HW, base = b * C * (long)HW + hw;
+#pragma unroll
+        for (int c = 0; c < C; ++c) load_vec<VEC>(z.p[k] + base + (long)c * HW, zv[c]);
+    };
+    auto head = [&](const float (&zv)[C][VEC], const int (&yv)[VEC], int k) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float zz[C], p[C], lp[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) zz[c] = zv[c][v];
+            softmax_regs<C>(zz, p, lp);
+            const int y = yv[v];
+            float lpy = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                acc[L::P + k * C + c] += p[c];
+                acc[L::I + k * C + c] += (y == c) ? p[c] : 0.f;
+                lpy = (y == c) ? lp[c] : lpy;
+            }
+            acc[L::CE + k] -= lpy;
+        }
+    };
+    // buffers alternate head by head; PAR = which buffer holds head 0 of this group (flips per group when D is odd)
+    float za[C][VEC], zb[C][VEC];
+    int yv[VEC], yn[VEC];
+    auto group = [&](long g, auto par) {
+        constexpr int PAR = decltype(par)::value;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const bool cur_a = ((k + PAR) & 1) == 0;
+            if (k + 1 < D) {
+                if (cur_a) load_head(g, k + 1, zb); else load_head(g, k + 1, za);
+            } else if (g + stride < ngroups) {
+                load_labels<VEC>(labels + (g + stride) * VEC, yn);
+                if (cur_a) load_head(g + stride, 0, zb); else load_head(g + stride, 0, za);
+            }
+            if (cur_a) head(za, yv, k); else head(zb, yv, k);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int y = yv[v];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[L::CNT + c] += (y == c) ? 1.f : 0.f;
+            acc[L::BAD] += (y < 0 || y >= C) ? 1.f : 0.f;
+            yv[v] = yn[v];
+        }
+    };
+    long g = (long)bid * kThreads + threadIdx.x;
+    if (g < ngroups) { load_labels<VEC>(labels + g * VEC, yv); load_head(g, 0, za); }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) yn[v] = 0;
+    while (g < ngroups) {
+        group(g, std::integral_constant<int, 0>{});
+        g += stride;
+        if (g >= ngroups) break;
+        group(g, std::integral_constant<int, D & 1>{});      // odd D: head 0 of every other group sits in the second buffer
+        g += stride;
+    }
+    block_reduce_store<L::NS>(acc, partials, bid, nblk);
+}
 template <int D, int C, int VEC>
 __global__ __launch_bounds__(kThreads) void sup_fwd_kernel(HeadPtrs<D> z, int HW, long ngroups,
                                                            const int64_t* __restrict__ labels,
@@ -292,17 +420,23 @@ constexpr int kMaxSums = 4 * UAPS_MAX_HEADS + 2 * UAPS_MAX_HEADS * UAPS_MAX_CLAS
 // fixed-order double reduction of the block partials [NS][nrows] into tot[NS]: kFinalizeThreads / 64 waves, one sum per wave at
 // a time: coalesced reads of that sum's nrows block partials, lane-strided double accumulation, fixed-order wave reduction
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ partials, int nrows, int NS, double* tot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < NS; i += kFinalizeThreads / 64) {
+    // 8 lanes per sum: lane j of the group adds rows j, j + 8, ... with four independent double chains (all loads of a thread
+    // are independent: one trip through the memory pipeline instead of one per sum), then the 8 lanes are combined in a
+    // fixed order.  1024 threads = 128 groups >= the 89 sums of D = C = 8.
+    const int grp = threadIdx.x >> 3, j = threadIdx.x & 7;
+    for (int i = grp; i < NS; i += kFinalizeThreads / 8) {
         const float* src = partials + (size_t)i * nrows;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int r = lane;
-        for (; r + 192 < nrows; r += 256) {
-            s0 += (double)src[r]; s1 += (double)src[r + 64]; s2 += (double)src[r + 128]; s3 += (double)src[r + 192];
+        int r = j;
+        for (; r + 24 < nrows; r += 32) {
+            s0 += (double)src[r]; s1 += (double)src[r + 8]; s2 += (double)src[r + 16]; s3 += (double)src[r + 24];
         }
-        for (; r < nrows; r += 64) s0 += (double)src[r];
-        const double s = wave_sum_d((s0 + s1) + (s2 + s3));
-        if (lane == 0) tot[i] = s;
+        for (; r < nrows; r += 8) s0 += (double)src[r];
+        double s = (s0 + s1) + (s2 + s3);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (j == 0) tot[i] = s;
     }
 }
 
@@ -582,13 +716,24 @@ __global__ __launch_bounds__(kThreads) void sup_bwd_kernel(HeadPtrs<D> z, HeadOu
 // on the labelled logits, blocks [nb_s, gridDim.x) the unsupervised branch on the unlabelled logits (UAPS_train.py:
 // 194-218 and 186-189, 223-277).  VS / VU: pixels per thread of the two branches.
 // --------------------------------------------------------------------------------------------------
-template <int D, int C, int VS, int VU>
-__global__ __launch_bounds__(kThreads) void pair_fwd_kernel(HeadPtrs<D> zl, HeadPtrs<D> zu, HeadWeights<D> w, int HW, long N,
-                                                            const int64_t* __restrict__ labels, int64_t* __restrict__ pseudo,
-                                                            float* __restrict__ var, float* __restrict__ part_s,
-                                                            float* __restrict__ part_u, int nb_s) {
-    if ((int)blockIdx.x < nb_s) sup_fwd_body<D, C, VS>(zl, HW, N / VS, labels, part_s, (int)blockIdx.x, nb_s);
-    else unsup_fwd_body<D, C, VU>(zu, w, HW, N / VU, N, pseudo, var, part_u, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
+// PFS / PFU: the prefetching form of the supervised / unsupervised body; MINW: waves per SIMD the register allocation must allow
+template <int D, int C, int VS, int VU, bool PFS, bool PFU, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void pair_fwd_kernel(HeadPtrs<D> zl, HeadPtrs<D> zu, HeadWeights<D> w, int HW, long N,
+                                                                  const int64_t* __restrict__ labels, int64_t* __restrict__ pseudo,
+                                                                  float* __restrict__ var, float* __restrict__ part_s,
+                                                                  float* __restrict__ part_u, int nb_s) {
+#ifdef UAPS_LOSS_STAGGER
+    // two waves per SIMD running the same load -> compute loop from the same start stay in lockstep (both wait for memory,
+    // then both compete for the VALU): delay the wave in the odd hardware slot by about half a group's period
+    if (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1) __builtin_amdgcn_s_sleep(UAPS_LOSS_STAGGER);
+#endif
+    if ((int)blockIdx.x < nb_s) {
+        if constexpr (PFS) sup_fwd_body_pf<D, C, VS>(zl, HW, N / VS, labels, part_s, (int)blockIdx.x, nb_s);
+        else sup_fwd_body<D, C, VS>(zl, HW, N / VS, labels, part_s, (int)blockIdx.x, nb_s);
+    } else {
+        if constexpr (PFU) unsup_fwd_body_pf<D, C, VU>(zu, w, HW, N / VU, N, pseudo, var, part_u, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
+        else unsup_fwd_body<D, C, VU>(zu, w, HW, N / VU, N, pseudo, var, part_u, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
+    }
 }
 // Nloss: the pixel count the scalars were finalised with (= N, or the global count after an exchange of the sums)
 template <int D, int C, int VS, int VU>

@@ -7,13 +7,13 @@ template <int D, int C> static int run_pair_bwd(const PairArgs& a) {
     HeadPtrs<D> zl = in_ptrs<D>(a.lab), zu = in_ptrs<D>(a.un);
     HeadOutPtrs<D> dl = out_ptrs<D>(a.dlab), du = out_ptrs<D>(a.dun);
     if (pair_vec_ok(a, 4, true)) {
-        const int nb_s = pair_grid(N / 4, a.cfg), nb_u = pair_grid(N / VU, a.cfg);
+        const int nb_s = pair_grid(N / 4, pair_cap_s(a.cfg)), nb_u = pair_grid(N / VU, pair_cap_u(a.cfg));
         hipLaunchKernelGGL((pair_bwd_kernel<D, C, 4, VU>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
                            a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb_s);
     } else {
-        const int nb = pair_grid(N, a.cfg);
-        hipLaunchKernelGGL((pair_bwd_kernel<D, C, 1, 1>), dim3(2 * nb), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
-                           a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb);
+        const int nb_s = pair_grid(N, pair_cap_s(a.cfg)), nb_u = pair_grid(N, pair_cap_u(a.cfg));
+        hipLaunchKernelGGL((pair_bwd_kernel<D, C, 1, 1>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
+                           a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb_s);
     }
     return (int)hipGetLastError();
 }
