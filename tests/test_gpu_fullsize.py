@@ -213,8 +213,8 @@ def test_real_width_step_256_vs_cpu_oracle(pair, monkeypatch):
         if scale < 1e-7:
             assert err < 1e-6, n
         else:
-            # elementwise 0.5 % + a floor: BatchNorm weight gradients are sums of ~10^5 terms of mixed sign (a few 1e-6 absolute)
-            assert err <= max(5e-3 * scale, 3e-6), f"{n}: max err {err:.3e} vs scale {scale:.3e}"
+            # elementwise 0.5 % + a floor: BatchNorm weight gradients are sums of ~10^5 terms of mixed sign ; one LeakyReLU derivative flip at a pre-activation within rounding of 0 moves an element by ~1e-6..1e-5: absolute floor 1e-5
+            assert err <= max(5e-3 * scale, 1e-5), f"{n}: max err {err:.3e} vs scale {scale:.3e}"
     print(f"worst relative gradient error {worst[0]:.2e} ({worst[1]})")
     # BatchNorm running statistics after the two forwards (updated twice, labelled batch first)
     sd_g = model.state_dict()
