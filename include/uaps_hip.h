@@ -107,6 +107,28 @@ int uaps_sup_bwd(const float* const* logits_host, const int64_t* labels, const f
                  float* const* dlogits_host, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * General strided convolutions and the stem max-pool of the reference's ResNet (utilities/resnet.py:120 conv 7x7 / 2 pad 3,
+ * :124 max-pool 3x3 / 2 pad 1, :8-14 + :147 layer2's 3x3 / 2 and 1x1 / 2): odd kernel sizes <= 7, stride 1 or 2, bias-free,
+ * fp32 NCHW, on the exact-f32 matrix instruction (csrc/conv_strided.hip).  They replace aten::convolution(_backward) and
+ * aten::max_pool2d_with_indices(_backward) for those layers.  Packed weights: wf [ks*ks][Cin4][Cout16], wb [ks*ks][Cout4][Cin16]
+ * (sizes in floats from uaps_convs_pack_floats).  Output size: OH = (H + 2 pad - ks) / stride + 1.
+ * ------------------------------------------------------------------------------------------- */
+int uaps_convs_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);
+int uaps_convs_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream);
+int uaps_convs_out_size(int H, int W, int ks, int stride, int pad, int* OH_host, int* OW_host);
+int uaps_convs_fwd(const float* x, const float* wf, float* y, int B, int Cin, int Cout, int H, int W, int ks, int stride, int pad,
+                   uaps_stream_t stream);
+int uaps_convs_bwd_data(const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H, int W, int ks, int stride,
+                        int pad, uaps_stream_t stream);
+int uaps_convs_wrw_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks, int stride, int pad, size_t* bytes_host);
+int uaps_convs_bwd_weight(const float* dy, const float* x, float* dw, int B, int Cin, int Cout, int H, int W, int ks, int stride,
+                          int pad, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+/* planes = B*C; y [planes, OH, OW] with OH = (H - 1) / 2 + 1; idx: uint8 [planes, OH, OW], the window position of each arg-max
+ * (first maximum wins, NaN propagates: torch.nn.MaxPool2d(3, 2, 1)) */
+int uaps_maxpool3x3s2_fwd(const float* x, float* y, void* idx, long planes, int H, int W, uaps_stream_t stream);
+int uaps_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, long planes, int H, int W, uaps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The whole loss block of one training step -- UAPS_train.py:194-218 on the labelled logits and :186-189, 223-282 on the
  * unlabelled logits -- as ONE forward launch (+ a one-block finalize) and ONE backward launch: the first blocks of the
  * grid run the supervised branch, the rest the unsupervised branch; results are bit-identical to uaps_sup_* +

@@ -75,6 +75,15 @@ SIGNATURES = {
     "uaps_conv_fwd_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_wrw_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
+    "uaps_convs_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "uaps_convs_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
+    "uaps_convs_out_size": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "uaps_convs_fwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 8 + [_PTR]),
+    "uaps_convs_bwd_data": (C.c_int, [_PTR] * 3 + [C.c_int] * 8 + [_PTR]),
+    "uaps_convs_wrw_workspace_bytes": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_size_t)]),
+    "uaps_convs_bwd_weight": (C.c_int, [_PTR] * 3 + [C.c_int] * 8 + [_PTR, C.c_size_t, _PTR]),
+    "uaps_maxpool3x3s2_fwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, C.c_int, C.c_int, _PTR]),
+    "uaps_maxpool3x3s2_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, C.c_int, C.c_int, _PTR]),
     "uaps_sum_tensors": (C.c_int, [_PTR, C.c_int, _PTR, C.c_long, _PTR]),
     "uaps_pair_workspace_bytes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "uaps_feat_dropout_stats": (C.c_int, [_PTR] + [C.c_int] * 4 + [_PTR, C.c_size_t, _PTR]),

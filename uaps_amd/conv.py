@@ -381,3 +381,117 @@ def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: O
                with_stats: bool = False):
     """F.conv2d(torch.cat([x1, x2], 1), weight, bias, padding=k//2) reading the two tensors in place."""
     return _Conv2dCat.apply(x1, x2, weight, bias, with_stats)
+
+
+# ---- general strided convolutions + the stem max-pool (csrc/conv_strided.hip) --------------------------------------------------
+
+_spacked: Dict[int, tuple] = {}
+
+
+def _pack_strided(weight: torch.Tensor):
+    key = id(weight)
+    ent = _spacked.get(key)
+    if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2] == _generation and ent[3].device == weight.device:
+        return ent[3], ent[4]
+    Cout, Cin, ks, ks2 = weight.shape
+    nf, nb = C.c_size_t(), C.c_size_t()
+    L = _lib.lib()
+    _lib.check(L.uaps_convs_pack_floats(Cout, Cin, ks, C.byref(nf), C.byref(nb)), "uaps_convs_pack_floats")
+    dev = weight.device
+    wf = torch.empty(nf.value, dtype=torch.float32, device=dev)
+    wb = torch.empty(nb.value, dtype=torch.float32, device=dev)
+    w = weight.detach().contiguous()
+    with _lib.device_guard(dev):
+        rc = L.uaps_convs_pack_weights(w.data_ptr(), Cout, Cin, ks, wf.data_ptr(), wb.data_ptr(), _lib.current_stream(dev))
+    _lib.check(rc, "uaps_convs_pack_weights")
+    _spacked[key] = (weakref.ref(weight), weight._version, _generation, wf, wb)
+    return wf, wb
+
+
+class _ConvStrided(torch.autograd.Function):
+    """F.conv2d(x, weight, None, stride, padding) for odd kernels <= 7 and stride 1 / 2 (utilities/resnet.py:120, 147, 8-14)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        _lib.require_device(x, "conv2d_strided")
+        if x.dtype != torch.float32 or weight.dtype != torch.float32:
+            raise TypeError("conv2d_strided: fp32 only")
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        Cout, Cin2, ks, ks2 = weight.shape
+        if Cin2 != Cin or ks != ks2:
+            raise ValueError(f"conv2d_strided: input has {Cin} channels, weight is {tuple(weight.shape)}")
+        wf, wb = _pack_strided(weight)
+        L = _lib.lib()
+        oh, ow = C.c_int(), C.c_int()
+        _lib.check(L.uaps_convs_out_size(H, W, ks, stride, padding, C.byref(oh), C.byref(ow)), "uaps_convs_out_size")
+        y = torch.empty((B, Cout, oh.value, ow.value), dtype=torch.float32, device=x.device)
+        with _lib.device_guard(x.device):
+            rc = L.uaps_convs_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), B, Cin, Cout, H, W, ks, stride, padding, _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_convs_fwd")
+        ctx.save_for_backward(x, wb)
+        ctx.meta = (Cout, ks, stride, padding, id(weight))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        Cout, ks, stride, padding, wkey = ctx.meta
+        B, Cin, H, W = x.shape
+        dy = dy.contiguous()
+        dev = x.device
+        L = _lib.lib()
+        dx = dw = None
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(L.uaps_convs_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, stride, padding, st),
+                           "uaps_convs_bwd_data")
+            if ctx.needs_input_grad[1]:
+                n = C.c_size_t()
+                _lib.check(L.uaps_convs_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, stride, padding, C.byref(n)), "uaps_convs_wrw_workspace_bytes")
+                ws = _workspace(dev, n.value)
+                dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
+                _lib.check(L.uaps_convs_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, Cin, Cout, H, W, ks, stride, padding,
+                                                   ws.data_ptr(), ws.numel(), st), "uaps_convs_bwd_weight")
+        return dx, dw, None, None
+
+
+def conv2d_strided(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
+    """Bias-free F.conv2d(x, weight, None, stride, padding), odd kernel sizes <= 7 (1, 3, 7 for the weight gradient), stride 1 or 2."""
+    return _ConvStrided.apply(x, weight, int(stride), int(padding))
+
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_device(x, "maxpool3x3s2")
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, Cc, OH, OW), dtype=torch.float32, device=x.device)
+        idx = torch.empty((B, Cc, OH, OW), dtype=torch.uint8, device=x.device)
+        with _lib.device_guard(x.device):
+            rc = _lib.lib().uaps_maxpool3x3s2_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), B * Cc, H, W, _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, Cc, H, W)
+        ctx.mark_non_differentiable(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, Cc, H, W = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=dy.device)
+        with _lib.device_guard(dy.device):
+            rc = _lib.lib().uaps_maxpool3x3s2_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), B * Cc, H, W, _lib.current_stream(dy.device))
+        _lib.check(rc, "uaps_maxpool3x3s2_bwd")
+        return dx
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (utilities/resnet.py:124)."""
+    return _MaxPool3x3s2.apply(x)

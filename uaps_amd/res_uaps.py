@@ -7,8 +7,8 @@ for the Bottleneck nets (resnet.py:201-203: c1..c4 = 256/512/1024/2048 channels 
 device every stride-1 convolution (all 1x1 projections, all dilated and plain 3x3) runs on the MFMA kernels of
 csrc/conv_kernels.hpp with the BatchNorm statistics in their epilogue, BatchNorm + ReLU are the fused kernels of
 csrc/norm_act.hip (LeakyReLU slope 0 = ReLU, slope 1 = identity) and the residual joins one `relu(a + b)` kernel.  The
-three strided convolutions of the net (7x7 stem, layer2's 3x3 and its 1x1 shortcut) and the stem's 3x3 max-pool still
-go through PyTorch's library ops: they are the bring-up remainder of this variant, not part of the measured UAPS step.
+three strided convolutions of the net (7x7 stem, layer2's 3x3 and its 1x1 shortcut) and the stem's 3x3 max-pool run on the
+general strided kernels of csrc/conv_strided.hip: no library convolution or pooling is left on this path.
 
 The reference has no UAPS model on this backbone (`utilities/base.py` is abstract), so the
 decoder below is this build's design: parity is pinned for the backbone only (tests/golden/g7_resnet.npz).
@@ -56,8 +56,8 @@ def add_relu(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, training: bool) -> torch.Tensor:
-    """[relu](bn(conv(x))) for a bias-free convolution.  GPU: own kernels for every stride-1 1x1 / 3x3 (dilation 1, 2, 4)
-    convolution, PyTorch's convolution for the strided ones; BatchNorm(+ReLU) always the fused HIP kernels."""
+    """[relu](bn(conv(x))) for a bias-free convolution.  GPU: the tiled MFMA kernels for every stride-1 1x1 / 3x3 (dilation 1, 2,
+    4) convolution, the general strided kernels for the rest; BatchNorm(+ReLU) always the fused HIP kernels."""
     if not x.is_cuda:
         y = bn(cv(x))
         return F.relu(y) if relu else y
@@ -68,7 +68,12 @@ def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, 
     if own and training:
         y, st = conv.conv2d_with_stats(x, cv.weight, None, dilation=d)
         return fused.bn_act(y, None, bn, slope, 0.0, True, st)
-    y = conv.conv2d(x, cv.weight, None, dilation=d) if own else F.conv2d(x, cv.weight, None, cv.stride, cv.padding, cv.dilation)
+    if own:
+        y = conv.conv2d(x, cv.weight, None, dilation=d)
+    else:             # the strided layers (7x7 / 2 stem, 3x3 / 2, 1x1 / 2 shortcut) and odd shapes: the general kernels of csrc/conv_strided.hip
+        if cv.groups != 1 or d != 1 or cv.stride[0] != cv.stride[1] or cv.padding[0] != cv.padding[1] or cv.bias is not None:
+            raise ValueError("conv_bn_act: grouped / dilated-strided / asymmetric convolutions are not part of the reference's ResNet")
+        y = conv.conv2d_strided(x, cv.weight, cv.stride[0], cv.padding[0])
     return fused.bn_act(y, None, bn, slope, 0.0, training)
 
 
@@ -172,7 +177,7 @@ class ResNet(nn.Module):
     def base_forward(self, x):
         """(c1, c2, c3, c4), resnet.py:171-182."""
         x = conv_bn_act(x, self.conv1, self.bn1, True, self.training)
-        x = self.maxpool(x)
+        x = conv.maxpool3x3s2(x) if x.is_cuda else self.maxpool(x)
         c1 = self.layer1(x)
         c2 = self.layer2(c1)
         c3 = self.layer3(c2)
