@@ -72,7 +72,9 @@ def test_kernel_plan_names_and_statistics_tiles(L):
     assert buf.value.decode().endswith(", 2>")                                           # dilation 2 (ResNet stages)
     assert L.uaps_conv_fwd_variant(32, 64, 64, 64, 64, 3, 3 << 24, buf, 96) == ERANGE     # dilation 3 does not exist
     assert L.uaps_conv_wrw_variant(32, 64, 64, 64, 64, 3, 0, buf, 96) == OK
-    assert buf.value.decode() == "conv_wrw_kernel<3, 4, 32, 2, 2, 4, 1>"
+    assert buf.value.decode() == "conv_swrw_kernel<4, 2, 2>"                             # split mode: 32 x 32 channel blocks, 4-row tiles
+    assert L.uaps_conv_wrw_variant(32, 64, 64, 64, 64, 3, 1 << 28, buf, 96) == OK
+    assert buf.value.decode() == "conv_wrw_kernel<3, 4, 32, 2, 2, 4, 1>"                 # cfg bit 28: the fp32 matrix instruction
     parts = C.c_int()
     assert L.uaps_conv_fwd_stats_parts(32, 16, 16, 256, 256, 3, 0, C.byref(parts)) == OK and parts.value == 32 * 8
     assert L.uaps_conv_fwd_stats_parts(4, 128, 128, 16, 16, 3, 0, C.byref(parts)) == OK and parts.value == 1

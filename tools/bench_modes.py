@@ -39,7 +39,14 @@ def main():
             row = []
             for vname, mode, cfg in VARIANTS:
                 C.set_mode(mode)
-                fn = (lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, cfg)) if d == "fwd" else (lambda: C.conv_bwd_data_raw(dy, wb, Cin, ks, cfg))
+                if d == "wrw":
+                    if vname in ("s16", "s32/32", "s32/64"):
+                        row.append(float("nan"))
+                        continue
+                    wcfg = 0          # the mode decides (exact kernels in exact mode, split where the plan takes them)
+                    fn = lambda: C.conv_bwd_weight_raw(dy, x, ks, False, wcfg)
+                else:
+                    fn = (lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, cfg)) if d == "fwd" else (lambda: C.conv_bwd_data_raw(dy, wb, Cin, ks, cfg))
                 try:
                     t = timeit(fn, iters=20)
                 except Exception:

@@ -1,0 +1,284 @@
+// Weight gradient of the 3x3 convolutions on the bf16 matrix pipe with the exact three-way operand split of conv_split.hpp
+// (six partial products per multiply, fp32 accumulation: the error of an fp32 fma chain).
+//
+//   dw[co][ci][ky][kx] = sum_{b,y,x} dy[b][co][y][x] * in[b][ci][y + ky - 1][x + kx - 1]
+//
+// GEMM view: M = 16 output channels, N = 16 input channels, K = pixels, one accumulator tile per tap.  v_mfma_f32_16x16x32_bf16
+// takes 8 consecutive k per lane (k-group g = lane >> 4): a k-group is 8 consecutive pixels of a tile row, an MFMA covers one
+// 32-pixel tile row.
+//   * LDS holds the dy tile and the haloed input tile already split: [piece][channel][row][32 pixels] bf16, a fragment is one
+//     ds_read_b128; channel planes are padded to stride == 32 (mod 64) bytes, which makes the four 16-lane groups the
+//     hardware services together hit disjoint banks (lane (c, g) -> 16-byte slot 2c + g (mod 16));
+//   * the three column taps need the input fragment shifted by -1 / 0 / +1 pixels = 16 bits of packed bf16: five
+//     v_alignbit_b32 per piece build both shifted fragments from the aligned one and one "edge" dword per k-group that the
+//     staging pass stores beside the row (high half = the pixel left of the group, low half = the pixel right of it);
+//   * a wave owns one (16 co, 16 ci) block (and a share of the tile rows when the workgroup's block is smaller than 32 x 32):
+//     every staged input row is turned into its 9 fragments (3 pieces x 3 shifts) once and used for the three row taps.
+// Partials go to per-split slabs [split][tap][CoutS][CinS] like conv_wrw_kernel; conv_wrw_reduce_kernel sums them.
+#pragma once
+#include "conv_split.hpp"
+
+namespace uaps {
+
+template <int TH, int WCO, int WCI> struct SWrwCfg {
+    static constexpr int TW = 32, WR = 4 / (WCO * WCI), RPW = TH / WR;          // rows of the tile per wave
+    static constexpr int BCO = 16 * WCO, BCI = 16 * WCI;
+    static constexpr int DPLU = TH * 4 + 2;                                      // dy plane stride in 16-byte units (== 2 mod 4)
+    static constexpr int XPLU = (TH + 2) * 4 + 2;                                // input plane stride in 16-byte units
+    static constexpr int EPL = (TH + 2) * 4 + 1;                                 // edge dwords per input channel (odd stride)
+    static constexpr int ND = (BCO * TH * 4 + kConvThreads - 1) / kConvThreads;  // dy staging units per thread (8 pixels each)
+    static constexpr int NX = (BCI * (TH + 2) * 4 + kConvThreads - 1) / kConvThreads;
+    static_assert(WCO * WCI * WR == 4 && TH % WR == 0, "wave arrangement");
+};
+
+// 8 consecutive floats -> three 16-byte rows of packed bf16 pieces
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned a, b, c;
+        conv_split3(v[2 * i], v[2 * i + 1], a, b, c);
+        p0[i] = a; p1[i] = b; p2[i] = c;
+    }
+}
+
+template <int TH, int WCO, int WCI, bool XF>
+__device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
+    using Cfg = SWrwCfg<TH, WCO, WCI>;
+    constexpr int TW = 32, WR = Cfg::WR, RPW = Cfg::RPW, BCO = Cfg::BCO, BCI = Cfg::BCI;
+    constexpr int DPLU = Cfg::DPLU, XPLU = Cfg::XPLU, EPL = Cfg::EPL, ND = Cfg::ND, NX = Cfg::NX;
+    constexpr int RED_FLOATS = WR > 1 ? (WR / 2) * WCO * WCI * 10 * 256 : 0;
+    constexpr int STAGE_UNITS = 3 * BCO * DPLU + 3 * BCI * XPLU;
+    constexpr int LDS_UNITS = STAGE_UNITS > RED_FLOATS / 4 ? STAGE_UNITS : RED_FLOATS / 4;
+
+    __shared__ __attribute__((aligned(16))) u32x4 smem[LDS_UNITS];
+    __shared__ unsigned sE[3 * BCI * EPL];
+    __shared__ f32x2 sXf[XF ? kWrwMaxGroups * BCI + 1 : 1];
+    u32x4* sD = smem;                        // [piece][co][row][4 groups] (+ 2 pad units per plane)
+    u32x4* sX = smem + 3 * BCO * DPLU;       // [piece][ci][row][4 groups] (+ 2 pad units per plane)
+    constexpr int XF_ZERO = kWrwMaxGroups * BCI;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int wr = wave % WR, wci = (wave / WR) % WCI, wco = wave / (WR * WCI);
+
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (bid >= a.nsplit * a.ncob * a.ncib) return;
+    stagger_by_wave_slot();
+    const int cib = bid % a.ncib; bid /= a.ncib;
+    const int cob = bid % a.ncob;
+    const int split = bid / a.ncob;
+    const int co0 = cob * BCO, ci0 = cib * BCI;
+    const int HW = a.H * a.W;
+    const int tiles_per_img = a.tiles_x * a.tiles_y, ntiles = a.B * tiles_per_img;
+    const int t_begin = (int)((long)ntiles * split / a.nsplit), t_end = (int)((long)ntiles * (split + 1) / a.nsplit);
+    const bool want_bias = a.bslab != nullptr && cib == 0;
+
+    // ---- staging units: (channel, row, k-group) -> 8 pixels; tile-independent parts ----
+    int dC[ND], dR[ND], dG[ND];
+    int xC[NX], xR[NX], xG[NX];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+        const int u = tid + n * kConvThreads;
+        dC[n] = u < BCO * TH * 4 ? u / (TH * 4) : -1; dR[n] = (u / 4) % TH; dG[n] = u % 4;
+    }
+#pragma unroll
+    for (int n = 0; n < NX; ++n) {
+        const int u = tid + n * kConvThreads;
+        xC[n] = u < BCI * (TH + 2) * 4 ? u / ((TH + 2) * 4) : -1; xR[n] = (u / 4) % (TH + 2); xG[n] = u % 4;
+    }
+    if constexpr (XF) {
+        const int G = a.B / a.xf_Bg;
+        for (int i = tid; i < G * BCI; i += kConvThreads) {
+            const int g = i / BCI, ch = ci0 + i % BCI;
+            f32x2 v = f32x2{0.f, 0.f};
+            if (ch < a.Cin) { const float2 t = a.xf[(size_t)g * a.Cin + ch]; v = f32x2{t.x, t.y}; }
+            sXf[i] = v;
+        }
+        if (tid == 0) sXf[XF_ZERO] = f32x2{0.f, 0.f};
+    }
+
+    float rd[ND][8];
+    float rx[NX][10];                        // 8 pixels, then the pixel left of the group and the pixel right of it
+    int xf_idx[XF ? NX : 1];
+
+    auto load_tile = [&](int t) {
+        const int b = t / tiles_per_img, tt = t % tiles_per_img;
+        const int y0 = (tt / a.tiles_x) * TH, x0 = (tt % a.tiles_x) * TW;
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            const int c = co0 + dC[n], gy = y0 + dR[n], gx = x0 + dG[n] * 8;
+            const bool ok = dC[n] >= 0 && c < a.Cout && gy < a.H && gx < a.W;             // W % 4 == 0: float4 pieces are all in or all out
+            const float* p = a.dout + ((size_t)b * a.Cout + (ok ? c : 0)) * HW + (ok ? gy * a.W + gx : 0);
+            const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v1 = (ok && gx + 4 < a.W) ? *reinterpret_cast<const f32x4*>(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { rd[n][k] = v0[k]; rd[n][4 + k] = v1[k]; }
+        }
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            const int c = ci0 + xC[n], gy = y0 - 1 + xR[n], gx = x0 + xG[n] * 8;
+            const bool second = c >= a.Csplit;
+            const float* src = second ? a.in2 + ((size_t)b * (a.Cin - a.Csplit) + (c - a.Csplit)) * HW : a.in + ((size_t)b * a.Csplit + c) * HW;
+            const bool okc = xC[n] >= 0 && c < a.Cin && gy >= 0 && gy < a.H;
+            const bool ok = okc && gx < a.W;
+            const float* p = src + (okc ? gy * a.W : 0) + (ok ? gx : 0);
+            const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v1 = (ok && gx + 4 < a.W) ? *reinterpret_cast<const f32x4*>(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { rx[n][k] = v0[k]; rx[n][4 + k] = v1[k]; }
+            rx[n][8] = (okc && gx - 1 >= 0 && gx - 1 < a.W) ? src[gy * a.W + gx - 1] : 0.f;
+            rx[n][9] = (okc && gx + 8 < a.W) ? src[gy * a.W + gx + 8] : 0.f;
+            if constexpr (XF) xf_idx[n] = okc ? (b / a.xf_Bg) * BCI + xC[n] : XF_ZERO;     // padding rows / channels stay zero
+        }
+    };
+    auto store_tile = [&](int t) {
+        const int tt = t % tiles_per_img;
+        const int x0 = (tt % a.tiles_x) * TW;
+#pragma unroll
+        for (int n = 0; n < ND; ++n) {
+            if (dC[n] < 0) continue;
+            u32x4 p0, p1, p2;
+            split8(rd[n], p0, p1, p2);
+            const int u = dC[n] * DPLU + dR[n] * 4 + dG[n];
+            sD[u] = p0; sD[BCO * DPLU + u] = p1; sD[2 * BCO * DPLU + u] = p2;
+        }
+#pragma unroll
+        for (int n = 0; n < NX; ++n) {
+            if (xC[n] < 0) continue;
+            if constexpr (XF) {                  // leaky_relu(fma(y, scale, shift)) of the raw conv output; columns outside the image stay zero
+                const f32x2 cf = sXf[xf_idx[n]];
+                const int gx = x0 + xG[n] * 8;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    const int col = k < 8 ? gx + k : (k == 8 ? gx - 1 : gx + 8);
+                    const float z = __builtin_fmaf(rx[n][k], cf.x, cf.y);
+                    rx[n][k] = (col >= 0 && col < a.W) ? __builtin_fmaxf(z, z * a.xf_slope) : 0.f;
+                }
+            }
+            u32x4 p0, p1, p2;
+            float v8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v8[k] = rx[n][k];
+            split8(v8, p0, p1, p2);
+            const int u = xC[n] * XPLU + xR[n] * 4 + xG[n];
+            sX[u] = p0; sX[BCI * XPLU + u] = p1; sX[2 * BCI * XPLU + u] = p2;
+            unsigned e0, e1, e2;                 // (right neighbour, left neighbour) -> low / high half of the edge dword
+            conv_split3(rx[n][9], rx[n][8], e0, e1, e2);
+            const int eu = xC[n] * EPL + xR[n] * 4 + xG[n];
+            sE[eu] = e0; sE[BCI * EPL + eu] = e1; sE[2 * BCI * EPL + eu] = e2;
+        }
+    };
+
+    f32x4 acc[9];
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones_u = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};      // eight bf16 1.0
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+    const int aoff = (wco * 16 + j) * DPLU + kq;         // + row * 4 (+ piece plane)
+    const int boff = (wci * 16 + j) * XPLU + kq;
+    const int eoff = (wci * 16 + j) * EPL + kq;
+
+    if (t_begin < t_end) { load_tile(t_begin); }
+    if constexpr (XF) __syncthreads();                   // sXf visible
+    if (t_begin < t_end) store_tile(t_begin);
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const bool more = t + 1 < t_end;
+        if (more) load_tile(t + 1);
+        // this wave's dy rows [wr*RPW, wr*RPW + RPW) meet the input rows [wr*RPW, wr*RPW + RPW + 2) (LDS row r = image row y0 - 1 + r)
+#pragma unroll
+        for (int rr = 0; rr < RPW + 2; ++rr) {
+            const int r = wr * RPW + rr;
+            bf16x8 bf[3][3];                              // [shift kx][piece]
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const u32x4 c = sX[p * BCI * XPLU + boff + r * 4];
+                const unsigned e = sE[p * BCI * EPL + eoff + r * 4];
+                const unsigned t01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), t12 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
+                const unsigned t23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
+                const unsigned tE0 = __builtin_amdgcn_alignbit(c[0], e, 16), t3E = __builtin_amdgcn_alignbit(e, c[3], 16);
+                bf[0][p] = __builtin_bit_cast(bf16x8, u32x4{tE0, t01, t12, t23});          // pixels x - 1
+                bf[1][p] = __builtin_bit_cast(bf16x8, c);
+                bf[2][p] = __builtin_bit_cast(bf16x8, u32x4{t01, t12, t23, t3E});          // pixels x + 1
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = rr - ky;                   // dy row (relative to this wave's first) that meets input row r at row tap ky
+                if (yy < 0 || yy >= RPW) continue;
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, sD[p * BCO * DPLU + aoff + (wr * RPW + yy) * 4]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    f32x4 c = acc[ky * 3 + kx];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[kx][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[kx][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[kx][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[kx][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[kx][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[kx][0], c, 0, 0, 0);
+                    acc[ky * 3 + kx] = c;
+                }
+                if (ky == 0 && want_bias && wci == 0) {   // every dy row exactly once
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, accb, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) store_tile(t + 1);
+        __syncthreads();
+    }
+
+    // ---- sum the WR row-split partials of each (wco, wci) block through LDS (fixed order) ----
+    if constexpr (WR > 1) {
+        float* red = reinterpret_cast<float*>(smem);     // [slot][10][4][64]
+#pragma unroll
+        for (int s = WR / 2; s >= 1; s >>= 1) {
+            if (wr >= s && wr < 2 * s) {
+                float* p = red + (size_t)(((wr - s) * WCO + wco) * WCI + wci) * 10 * 256 + lane;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[(t * 4 + r) * 64] = acc[t][r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[(36 + r) * 64] = accb[r];
+            }
+            __syncthreads();
+            if (wr < s) {
+                const float* p = red + (size_t)((wr * WCO + wco) * WCI + wci) * 10 * 256 + lane;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][r] += p[(t * 4 + r) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[r] += p[(36 + r) * 64];
+            }
+            __syncthreads();
+        }
+    }
+    if (wr != 0) return;
+    // lane (j, kq), register r: co = co0 + wco*16 + kq*4 + r, ci = ci0 + wci*16 + j
+    float* slab = a.slab + (size_t)split * 9 * a.CoutS * a.CinS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wco * 16 + kq * 4 + r, ci = ci0 + wci * 16 + j;
+            slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = acc[t][r];
+        }
+    if (want_bias && wci == 0 && j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = accb[r];
+    }
+}
+
+template <int TH, int WCO, int WCI>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_swrw_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, false>(a); }
+template <int TH, int WCO, int WCI>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_swrw_bn_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, true>(a); }
+
+}  // namespace uaps

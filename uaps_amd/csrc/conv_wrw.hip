@@ -2,17 +2,38 @@
 #include "../../include/uaps_hip.h"
 #include <stdio.h>
 #include "conv_kernels.hpp"
+#include "conv_split_wrw.hpp"
 using namespace uaps;
+
+extern "C" int uaps_conv_get_mode(void);
 
 namespace {
 
 // wave arrangement: (WCO, WCI) 16-channel blocks per workgroup, the remaining factor of 4 splits the tile rows
-struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; };
+// split: the bf16-split kernels of conv_split_wrw.hpp (3x3, no dilation, 16-byte rows, >= 16 input channels)
+struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; bool split; };
 
-WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
+WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     WrwPlan p{};
-    p.dil = ((cfg >> 24) & 0xf) ? ((cfg >> 24) & 0xf) : 1;       // bits 24-27: dilation; low bits: pixel splits override
+    p.dil = ((cfg >> 24) & 0xf) ? ((cfg >> 24) & 0xf) : 1;       // bits 24-27: dilation; bit 28: exact kernels; bit 29: split kernels; low bits: pixel splits override
+    const bool force_exact = (cfg >> 28) & 1, force_split = (cfg >> 29) & 1;
     cfg &= 0xffffff;
+    p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() == 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
+    if (p.split) {
+        p.wco = Cout > 16 ? 2 : 1; p.wci = Cin > 16 ? 2 : 1;
+        p.TH = 4; p.TW = 32;
+        p.ncob = (Cout + 16 * p.wco - 1) / (16 * p.wco);
+        p.ncib = (Cin + 16 * p.wci - 1) / (16 * p.wci);
+        p.CoutS = p.ncob * 16 * p.wco; p.CinS = p.ncib * 16 * p.wci;
+        p.tiles = (long)B * ((H + p.TH - 1) / p.TH) * ((W + p.TW - 1) / p.TW);
+        const long blocks = (long)p.ncob * p.ncib;
+        long want = blocks >= 512 ? 1 : 512 / blocks;
+        if (cfg > 0) want = cfg;
+        if (want > p.tiles) want = p.tiles;
+        if (want < 1) want = 1;
+        p.nsplit = (int)want;
+        return p;
+    }
     p.wco = Cout > 16 ? 2 : 1;
     p.wci = Cin > 16 ? 2 : 1;
     if (p.dil > 1) p.wco = p.wci = 2;                             // dilated variants exist for 32 x 32 channel blocks only
@@ -32,6 +53,21 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg) {
     if (want < 1) want = 1;
     p.nsplit = (int)want;
     return p;
+}
+
+template <int TH, int WCO, int WCI>
+int launch_swrw(const ConvWrwArgs& a, hipStream_t s) {
+    const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.xf) hipLaunchKernelGGL((conv_swrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_swrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+int dispatch_swrw(const ConvWrwArgs& a, const WrwPlan& p, hipStream_t s) {
+    if (p.wco == 2 && p.wci == 2) return launch_swrw<4, 2, 2>(a, s);
+    if (p.wco == 2) return launch_swrw<4, 2, 1>(a, s);
+    if (p.wci == 2) return launch_swrw<4, 1, 2>(a, s);
+    return launch_swrw<4, 1, 1>(a, s);
 }
 
 size_t wrw_ws_floats(const WrwPlan& p, int taps) { return (size_t)p.nsplit * ((size_t)taps * p.CoutS * p.CinS + p.CoutS); }
@@ -71,7 +107,7 @@ int dispatch_wrw(const ConvWrwArgs& a, const WrwPlan& p, bool vec, hipStream_t s
 
 extern "C" int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, int W, int ks, int cfg, size_t* out) {
     if (!out || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3)) return UAPS_EINVAL;
-    *out = wrw_ws_floats(plan_wrw(B, Cin, Cout, H, W, cfg), ks * ks) * sizeof(float);
+    *out = wrw_ws_floats(plan_wrw(B, Cin, Cout, H, W, cfg, ks), ks * ks) * sizeof(float);
     return UAPS_OK;
 }
 
@@ -87,7 +123,9 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
     if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
     const int taps = ks * ks;
-    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
+    WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg, ks);
+    const bool vec16 = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!x2 || (uintptr_t)x2 % 16 == 0);
+    if (p.split && !vec16) return UAPS_ERANGE;      // the split kernels stream 16-byte pieces (W % 4 == 0 is part of the plan; pass cfg bit 28 for odd pointers)
     if (p.dil != 1 && (ks != 3 || (p.dil != 2 && p.dil != 4))) return UAPS_ERANGE;
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
     ConvWrwArgs a{};
@@ -96,8 +134,9 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
     a.bslab = want_bias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
-    const bool vec = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!x2 || (uintptr_t)x2 % 16 == 0);
+    const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
+    if (p.split) return dispatch_swrw(a, p, s);
     return ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
 }
 
@@ -130,7 +169,7 @@ extern "C" int uaps_conv_bwd_weight_reduce(const void* ws, float* dw, float* dbi
                                            int cfg, uaps_stream_t stream) {
     if (!ws || !dw || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3)) return UAPS_EINVAL;
     const int taps = ks * ks;
-    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
+    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg, ks);
     const float* slab = (const float*)ws;
     const float* bslab = dbias ? slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -154,7 +193,8 @@ extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, 
 
 extern "C" int uaps_conv_wrw_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf, size_t buflen) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || !buf || buflen < 64) return UAPS_EINVAL;
-    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg);
-    snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1, p.dil);
+    const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg, ks);
+    if (p.split) snprintf(buf, buflen, "conv_swrw_kernel<%d, %d, %d>", p.TH, p.wco, p.wci);
+    else snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1, p.dil);
     return UAPS_OK;
 }
