@@ -20,6 +20,13 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3  # dense fp32 matrix peak (v_mfma_f32_16x16x4_f32, same guide)
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak (same guide); the split kernels issue 6 bf16 MFMA flops per fp32 flop
+
+
+def mfma_peak_for(kernel_name):
+    """Peak in ALGORITHMIC (fp32) TFLOP/s of the matrix pipe a conv kernel runs on: the bf16-split kernels (conv_s*) evaluate
+    every fp32 multiply as six bf16 partial products, so their ceiling is the dense bf16 peak / 6."""
+    return MFMA_BF16_PEAK_TF / 6.0 if kernel_name.startswith("conv_s") else MFMA_F32_PEAK_TF
 
 
 def loss_kernel_bytes(name, D, C, npix):
@@ -27,7 +34,9 @@ def loss_kernel_bytes(name, D, C, npix):
     per_px = {"uaps_unsup_fwd": 4 * D * C + 8,            # var maps not stored in the training step
               "uaps_unsup_bwd": 8 * D * C + 8,
               "uaps_sup_fwd": 4 * D * C + 8,
-              "uaps_sup_bwd": 8 * D * C + 8}[name]
+              "uaps_sup_bwd": 8 * D * C + 8,
+              "uaps_pair_fwd": 2 * (4 * D * C + 8),        # both branches in one launch (+ the one-block finalize)
+              "uaps_pair_bwd": 2 * (8 * D * C + 8)}[name]
     return per_px * npix
 
 
@@ -253,15 +262,18 @@ def main():
         if dominant in timed:
             v = timed[dominant]
             ach = v["work"] / v["total_us"] / 1e6                     # TFLOP/s, algorithmic 2*B*H*W*Cin*Cout*k*k per launch
-            roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_F32_PEAK_TF, 4), "traffic": traffic, "avg_us": round(v["avg_us"], 2),
+            peak = mfma_peak_for(dominant)
+            roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_us": round(v["avg_us"], 2),
                     "launches_per_step": v["calls"] / n_an,
                     "note": "kernel instantiation with the largest share of the step; measured in the single-stream analysis pass "
                             f"of this process ({args.analysis_steps} steps after the timed region; launches of different decoders "
                             "overlap in the headline mode, so a launch's event-to-event time is only that kernel's when single-stream): "
                             "algorithmic flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time on "
                             "the launch stream; traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); "
-                            "peak is the nominal 2.4 GHz fp32 matrix figure (DESIGN.md section 5)"}
+                            "peak: fp32 flops per second the kernel's matrix instruction allows at the nominal 2.4 GHz -- 157.3 for the "
+                            "fp32 MFMA kernels, 2500 / 6 = 416.7 for the bf16-split kernels (conv_s*: six bf16 partial products per "
+                            "fp32 multiply, fp32 accumulation; under bf16 MFMA load the chip holds ~1.66 GHz, DESIGN.md section 5)"}
         elif ev:
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -272,13 +284,16 @@ def main():
             # step level: t_min = max(flops / fp32 matrix peak, HBM bytes / HBM peak) against the measured step
             step_flops = float(sum(v["work"] for v in discover.values()))
             step_bytes = pmc.get("__step_total_bytes")
-            t_mfma = step_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
+            # every conv launch at the peak of the matrix instruction it runs on (fp32 MFMA or the bf16-split form)
+            t_mfma = float(sum(v["work"] / (mfma_peak_for(k) * 1e12) for k, v in discover.items() if v["work"])) * 1e3
+            t_mfma_f32 = step_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
             t_hbm = step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if step_bytes else None
             t_min = max(t_mfma, t_hbm or 0.0)
             roof.update({"step_flops": step_flops, "step_hbm_bytes": step_bytes,
                          "step_hbm_bytes_note": "sum over all kernels of launches x (2*FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 "
                                                 "--pmc passes of this bench command, per step; null when no PMC summary is committed",
                          "t_min_ms": round(t_min, 3), "t_min_mfma_ms": round(t_mfma, 3), "t_min_hbm_ms": round(t_hbm, 3) if t_hbm else None,
+                         "t_min_if_all_fp32_mfma_ms": round(t_mfma_f32, 3),
                          "frac_step": round(t_min / ms_per_step, 4),
                          "frac_step_single_stream": round(t_min / single_ms, 4) if single_ms else None,
                          "step_TFLOPs": round(step_flops / ms_per_step / 1e9, 2),
@@ -290,6 +305,10 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
+               "arithmetic": ("fp32 tensors and fp32 accumulation throughout; 3x3 convolutions with > 8 channels split both fp32 operands exactly "
+                              "into three bf16 pieces and sum the six leading partial products on the bf16 matrix pipe (error of an fp32 fma "
+                              "chain, tests/test_gpu_conv.py); UAPS_CONV_MODE=0 runs everything on the fp32 matrix instruction")
+               if os.environ.get("UAPS_CONV_MODE", "1") not in ("0", "exact", "f32") else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32) everywhere",
                "config": {"workload": f"UAPS K={args.aux} decoders, NEU-Seg-shaped {H}x{W} {C}-class, batch {b}+{b} per GPU (BASELINE.json configs[1])",
                           "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5),
                           "launch_mode": mode},
