@@ -142,6 +142,13 @@ def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
 
 _parts_cache: Dict[tuple, int] = {}
 
+# Packed weights are written into FRESH buffers whenever a parameter changed: the packed input-gradient weights `wb` are what
+# the conv Functions save for backward, and a forward -> optimizer.step() -> forward -> backward(first graph) sequence must
+# still see the weights of its own forward (the kernels write through raw pointers, so autograd's version counters cannot
+# flag an in-place re-pack).  A captured hipGraph needs stable addresses instead: trainer graph capture sets this True.
+# The cache is stream-ordered with the stream that packed (the step's main stream).
+REPACK_IN_PLACE = False
+
 
 def stats_parts_per_image(B: int, Cin: int, Cout: int, H: int, W: int, ks: int, cfg: int = 0) -> int:
     key = (B, Cin, Cout, H, W, ks, cfg)
@@ -175,8 +182,8 @@ def pack_all(weights) -> None:
         if ks != ks2 or ks not in (1, 3) or wt.device != dev or wt.dtype != torch.float32:
             raise ValueError("pack_all: fp32 3x3 / 1x1 conv weights on one device expected")
         ent = _packed.get(id(wt))
-        if ent is not None and ent[0]() is wt and ent[3].device == dev and ent[4] is not None:
-            wf, wb = ent[3], ent[4]                  # same parameter, new values: reuse the buffers
+        if REPACK_IN_PLACE and ent is not None and ent[0]() is wt and ent[3].device == dev and ent[4] is not None:
+            wf, wb = ent[3], ent[4]                  # same parameter, new values, same addresses (captured graphs replay them)
         else:
             nf, nb = C.c_size_t(), C.c_size_t()
             _lib.check(L.uaps_conv_pack_floats(Cout, Cin, ks, C.byref(nf), C.byref(nb)), "uaps_conv_pack_floats")

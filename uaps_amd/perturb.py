@@ -313,8 +313,10 @@ class _PerturbFan(torch.autograd.Function):
         outs, offsets, keeps = [f.view_as(f)], [[0] * groups], [None]
         seed = _RngState.seed
         n = len(kinds)
+        # the one-pass kernel carries one set of FeatureDropout thresholds: with two FeatureDropout decoders (n_aux >= 6) the
+        # per-perturbation kernels below run instead (decided before any random number is reserved)
         if _FUSED_FANOUT and n >= 1 and (H * W) % 4 == 0 and groups <= 4 and n <= 8 and f.data_ptr() % 16 == 0 \
-                and all(k in _KIND_MODE for k in kinds):
+                and all(k in _KIND_MODE for k in kinds) and sum(k == "feature_dropout" for k in kinds) <= 1:
             # one pass over f for all the copies (same draws, same order of RNG reservations as the per-kernel path below)
             ys = [torch.empty_like(f) for _ in kinds]
             us = [0.0] * groups
@@ -326,8 +328,6 @@ class _PerturbFan(torch.autograd.Function):
                 elif kind == "dropout":
                     offsets.append([_RngState.reserve(f.numel())[1]] * groups); keeps.append(None)
                 else:
-                    if ws is not None:
-                        raise ValueError("one FeatureDropout per fan-out")      # a second one would need its own thresholds
                     need = C.c_size_t()
                     _lib.check(L.uaps_feat_dropout_workspace_bytes(B, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
                     key = (dev.index, _lib.current_stream(dev))
