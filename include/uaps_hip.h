@@ -107,6 +107,18 @@ int uaps_sup_bwd(const float* const* logits_host, const int64_t* labels, const f
                  float* const* dlogits_host, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Step state for captured steps (hipGraph replay freezes kernel arguments).  A 64-byte device buffer the host refreshes
+ * before every step: words 0-1 a uint64 added to every Philox key (new draws per step), words 2-9 the mixing weights
+ * w[8] as float (UAPS_train.py:251), word 10 / 11 cw1 / cw2 (:279-280), word 12 / 13 Adam's lr / (1 - beta1^t) and
+ * 1 / sqrt(1 - beta2^t).  With a state set, uaps_pairloss_fwd accepts w_host = NULL, uaps_pairloss_* read cw1 / cw2 from it
+ * when passed NaN, uaps_adam_step reads its two scalars from it when step < 1, the perturbation / dropout kernels add the
+ * key increment, and uaps_fanout_perturbed draws a FeatureDropout threshold factor on the device for every u[g] < 0.
+ * Process-wide (not per stream); NULL (the default) restores the by-value behaviour.
+ * ------------------------------------------------------------------------------------------- */
+int uaps_set_step_state(const void* device_ptr);
+const void* uaps_get_step_state(void);
+
+/* ---------------------------------------------------------------------------------------------
  * General strided convolutions and the stem max-pool of the reference's ResNet (utilities/resnet.py:120 conv 7x7 / 2 pad 3,
  * :124 max-pool 3x3 / 2 pad 1, :8-14 + :147 layer2's 3x3 / 2 and 1x1 / 2): odd kernel sizes <= 7, stride 1 or 2, bias-free,
  * fp32 NCHW, on the exact-f32 matrix instruction (csrc/conv_strided.hip).  They replace aten::convolution(_backward) and

@@ -1,0 +1,135 @@
+"""-m gpu: the step-state form of the training step (uaps_amd/graph.py) and its hipGraph capture.
+
+1. state mode == by-value mode once the random draws are taken out (identity perturbations, dropout p = 0): the Dirichlet
+   weights, consistency weights and Adam scalars read from the device step state give the same step as the same numbers
+   passed as kernel arguments.
+2. replaying the captured step == running the same state-mode step eagerly, bit for bit, perturbations included (both
+   draw from Philox key + per-step key increment with the same counters), over warm-up, capture and replays.
+3. the device-drawn FeatureDropout threshold lies in [0.7, 0.9) x max attention and changes from step to step.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(seed, widths=(8, 16, 16, 32, 32)):
+    import uaps_amd
+    torch.manual_seed(seed)
+    return uaps_amd.UNet_UAPS(3, 4, feature_chns=list(widths))
+
+
+def _batches(n, B, H, W, seed=5):
+    import uaps_amd
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        xl = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+        xu = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32)).to(DEV)
+        y = torch.tensor(uaps_amd.data.synthetic_masks(rng, B, 4, H, W)).to(DEV)
+        out.append((xl, y, xu))
+    return out
+
+
+def test_state_mode_equals_by_value_mode_without_random_draws():
+    import uaps_amd
+    m0 = _model(3)
+    for m in m0.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    m1 = copy.deepcopy(m0)
+    ident = [lambda fs: fs] * 3
+    trainers = []
+    for m, kw in ((m0, {}), (m1, {"step_state": True})):
+        m.to(DEV)
+        orig = m.forward_pair
+        m.forward_pair = (lambda a, b, perturbations=None, _o=orig: _o(a, b, perturbations=ident))
+        trainers.append(uaps_amd.UAPSTrainer(m, base_lr=1e-3, seed=11, **kw))
+    assert trainers[1].step_graph is not None and trainers[0].step_graph is None
+    for xl, y, xu in _batches(3, 2, 64, 64):
+        ra = trainers[0].train_step(xl, y, xu)
+        rb = trainers[1].train_step(xl, y, xu)
+        np.testing.assert_allclose(float(rb["loss"]), float(ra["loss"]), rtol=1e-6)
+        np.testing.assert_allclose(rb["w"], ra["w"])
+    for (n, pa), pb in zip(m0.named_parameters(), m1.parameters()):
+        # identical gradients; Adam's lr/bias-correction scalars are rounded to fp32 on the host instead of in the launcher
+        np.testing.assert_allclose(pb.detach().cpu().numpy(), pa.detach().cpu().numpy(), rtol=0, atol=2e-7, err_msg=n)
+    assert trainers[0].epoch_metrics() == trainers[1].epoch_metrics()
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_graph_replay_is_bit_identical_to_the_eager_state_step(streams, monkeypatch):
+    import uaps_amd
+    m0 = _model(4)
+    m1 = copy.deepcopy(m0)
+    m0.to(DEV), m1.to(DEV)
+    from uaps_amd import unet
+    monkeypatch.setattr(unet, "_DECODER_STREAMS", streams)
+    eager = uaps_amd.UAPSTrainer(m0, base_lr=1e-3, seed=7, step_state=True)
+    graph = uaps_amd.UAPSTrainer(m1, base_lr=1e-3, seed=7, use_graph=True)
+    losses_e, losses_g = [], []
+    for i, (xl, y, xu) in enumerate(_batches(6, 2, 64, 64)):
+        uaps_amd.perturb.manual_seed(7, 0)
+        np.random.seed(7)
+        losses_e.append(eager.train_step(xl, y, xu)["loss"].clone())
+        uaps_amd.perturb.manual_seed(7, 0)
+        np.random.seed(7)
+        losses_g.append(graph.train_step(xl, y, xu)["loss"].clone())
+        assert (graph.step_graph.graph is not None) == (i >= 2)          # two eager warm-up steps, then capture + replays
+    torch.cuda.synchronize()
+    assert [float(a) for a in losses_e] == [float(b) for b in losses_g]
+    assert len({float(a) for a in losses_e}) == 6
+    for (n, pa), pb in zip(m0.named_parameters(), m1.parameters()):
+        assert torch.equal(pa, pb), n
+    for (n, ba), bb in zip(m0.named_buffers(), m1.buffers()):
+        assert torch.equal(ba, bb), n
+    sa, sb = eager.optimizer.state_dict()["state"], graph.optimizer.state_dict()["state"]
+    assert all(float(sa[k]["step"]) == float(sb[k]["step"]) == 6.0 for k in sa)
+    assert all(torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"]) for k in sa)
+    assert eager.epoch_metrics() == graph.epoch_metrics()
+    assert eager.iter_num == graph.iter_num == 6
+    # a different batch shape falls back to the eager state-mode step, and the graph keeps working afterwards
+    (xl, y, xu), = _batches(1, 1, 64, 64, seed=9)
+    graph.train_step(xl, y, xu)
+    (xl, y, xu), = _batches(1, 2, 64, 64, seed=10)
+    r = graph.train_step(xl, y, xu)
+    assert np.isfinite(float(r["loss"]))
+
+
+def test_device_drawn_feature_dropout_threshold():
+    """FeatureDropout (UAPS_unet.py:156-169): threshold = max attention x U(0.7, 0.9), pixels whose channel mean reaches it are
+    zeroed.  With the step state active the U is a Philox draw on the device: per image, the attention ratios of the kept and
+    the dropped pixels must be separable by one u in [0.7, 0.9), and that u changes with the step key."""
+    from uaps_amd import perturb
+    from uaps_amd.graph import StepState
+    torch.manual_seed(0)
+    f = torch.rand(4, 16, 32, 32, device=DEV) + 0.1
+    att = f.mean(1)
+    r = att / att.flatten(1).max(1).values.view(-1, 1, 1)
+    st = StepState(torch.device(DEV))
+    brackets = []
+    prev = perturb.DEVICE_THRESHOLDS
+    perturb.DEVICE_THRESHOLDS = True
+    try:
+        for _ in range(2):
+            st.fill([1.0], 0.0, 0.0, 1e-3, 1.0)
+            st.upload()
+            st.activate()
+            perturb._RngState.offset = 0
+            _, out = perturb.perturbed_fan_out(f, ["feature_dropout"], 1)
+            StepState.deactivate()
+            kept = (out != 0).any(1)
+            assert bool(kept.any()) and bool((~kept).any())
+            top_kept = torch.where(kept, r, torch.full_like(r, -1.0)).flatten(1).max(1).values
+            low_drop = torch.where(~kept, r, torch.full_like(r, 9.0)).flatten(1).min(1).values
+            assert bool((top_kept < low_drop).all())                    # a threshold separates them
+            assert bool((low_drop >= 0.7).all()) and bool((top_kept < 0.9).all())
+            brackets.append((top_kept.cpu(), low_drop.cpu()))
+    finally:
+        perturb.DEVICE_THRESHOLDS = prev
+        StepState.deactivate()
+    assert not (torch.equal(brackets[0][0], brackets[1][0]) and torch.equal(brackets[0][1], brackets[1][1]))

@@ -455,17 +455,22 @@ def test_decoder_streams_give_bit_identical_steps():
         assert torch.equal(a, b)
 
 
-def test_grad_buckets_over_rccl_single_rank():
+@pytest.mark.parametrize("streams", [False, True], ids=["single_stream", "decoder_streams"])
+def test_grad_buckets_over_rccl_single_rank(streams):
     """The N > 1 exchange step (uaps_amd.dist.GradBuckets: per-module flat buckets, asynchronous all-reduce launched from
     post-accumulate hooks during backward, gradients re-pointed at the reduced buffers) exercised over the real RCCL
     backend with one rank: with the bucket's divisor forced to 2 every gradient must come out exactly halved.  (The
     multi-rank logic is covered on CPU by tests/test_ddp_gloo.py; this checks the nccl call path, streams and views.)"""
     import torch.distributed as dist
     import uaps_amd
+    import uaps_amd.unet as unet_mod
     from uaps_amd import dist as udist, perturb
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1, device_id=torch.device(DEV))
+    # with decoder streams the bucket hooks fire on the auxiliary decoders' side streams: the all-reduce must order itself
+    # behind the stream that produced the bucket's gradients and the main stream behind the all-reduce
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29653 + int(streams)}", rank=0, world_size=1, device_id=torch.device(DEV))
+    unet_mod._DECODER_STREAMS = streams
     try:
         def grads(with_buckets):
             torch.manual_seed(9); np.random.seed(9); perturb.manual_seed(9)
@@ -499,4 +504,5 @@ def test_grad_buckets_over_rccl_single_rank():
         for a, b in zip(ref, got):
             assert torch.equal(b, a * 0.5)
     finally:
+        unet_mod._DECODER_STREAMS = False
         dist.destroy_process_group()

@@ -22,6 +22,6 @@ from .res_uaps import ResUAPS, ResNet, resnet50
 from .net_factory import net_factory
 from .consistency import (softmax_mse_loss, softmax_kl_loss, kl_loss, entropy_map, entropy_minmization, uncertainty_map)
 from .trainer import UAPSTrainer, BaselineTrainer
-from . import augment, conv, data, dist, inference, optim, sibling
+from . import augment, conv, data, dist, graph, inference, optim, sibling
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -75,6 +75,8 @@ SIGNATURES = {
     "uaps_conv_fwd_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_wrw_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
+    "uaps_set_step_state": (C.c_int, [_PTR]),
+    "uaps_get_step_state": (C.c_void_p, []),
     "uaps_convs_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "uaps_convs_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
     "uaps_convs_out_size": (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <math.h>
 #include "../../include/uaps_hip.h"
+#include "philox.hpp"
 
 namespace {
 constexpr int kThreads = 256;
@@ -17,7 +18,8 @@ struct AdamBatch {
     long n[kAdamBatch];
 };
 __global__ __launch_bounds__(kThreads) void adam_kernel(AdamBatch t, float one_minus_b1, float b2, float one_minus_b2, float step_size,
-                                                        float inv_sqrt_bc2, float eps, float weight_decay) {
+                                                        float inv_sqrt_bc2, float eps, float weight_decay, const uint32_t* __restrict__ st) {
+    step_size = uaps::step_f(st, uaps::kStepAdam, step_size); inv_sqrt_bc2 = uaps::step_f(st, uaps::kStepAdam + 1, inv_sqrt_bc2);
     const int k = blockIdx.y;
     float* __restrict__ p = t.p[k]; const float* __restrict__ g = t.g[k]; float* __restrict__ m = t.m[k]; float* __restrict__ v = t.v[k];
     const long n = t.n[k];
@@ -53,9 +55,11 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(AdamBatch t, float one_m
 extern "C" int uaps_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                               const long* numel, int n, double lr, double beta1, double beta2, double eps, double weight_decay, long step,
                               uaps_stream_t stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || n <= 0 || step < 1) return UAPS_EINVAL;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    const float step_size = (float)(lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    // step < 1 with a step state set (uaps_set_step_state): lr / bias-correction1 and 1 / sqrt(bias-correction2) are read from it
+    const void* st = uaps_get_step_state();
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || n <= 0 || (step < 1 && !st)) return UAPS_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)(step < 1 ? 1 : step)), bc2 = 1.0 - pow(beta2, (double)(step < 1 ? 1 : step));
+    const float step_size = step < 1 ? NAN : (float)(lr / bc1), inv_sqrt_bc2 = step < 1 ? NAN : (float)(1.0 / sqrt(bc2));
     for (int base = 0; base < n; base += kAdamBatch) {
         const int m = n - base < kAdamBatch ? n - base : kAdamBatch;
         AdamBatch t{};
@@ -70,7 +74,7 @@ extern "C" int uaps_adam_step(float* const* params, const float* const* grads, f
         if (bx < 1) bx = 1;
         if (bx > 256) bx = 256;
         hipLaunchKernelGGL(adam_kernel, dim3((unsigned)bx, m), dim3(kThreads), 0, (hipStream_t)stream, t, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps, (float)weight_decay);
+                           (float)(1.0 - beta2), step_size, inv_sqrt_bc2, (float)eps, (float)weight_decay, (const uint32_t*)(step < 1 ? st : nullptr));
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }

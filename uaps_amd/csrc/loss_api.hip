@@ -4,6 +4,16 @@ using namespace uaps;
 
 extern "C" int uaps_abi_version(void) { return 1; }
 
+// Process-wide pointer to the device-resident step state (philox.hpp); every launch wrapper that has per-step scalars or
+// random draws passes it to its kernel.  NULL = by-value arguments only (the default; eager execution needs nothing else).
+static const void* g_step_state = nullptr;
+extern "C" int uaps_set_step_state(const void* device_ptr) {
+    if ((uintptr_t)device_ptr % 8) return UAPS_EINVAL;
+    g_step_state = device_ptr;
+    return UAPS_OK;
+}
+extern "C" const void* uaps_get_step_state(void) { return g_step_state; }
+
 extern "C" const char* uaps_error_string(int code) {
     switch (code) {
         case UAPS_OK: return "ok";
@@ -110,7 +120,8 @@ extern "C" int uaps_pairloss_fwd(const float* const* lab_logits, const float* co
     int rc = check_dims(D, B, C, H, W);
     if (rc) return rc;
     if ((rc = check_heads(lab_logits, D)) || (rc = check_heads(un_logits, D))) return rc;
-    if (!labels || !w || !pseudo || !ws || (!sums_out && (!sup_scalars || !unsup_scalars))) return UAPS_EINVAL;
+    if (!labels || !pseudo || !ws || (!sums_out && (!sup_scalars || !unsup_scalars))) return UAPS_EINVAL;
+    if (!w && !g_step_state) return UAPS_EINVAL;          // NULL weights = the step state's (uaps_set_step_state)
     if (ws_bytes < pairloss_ws_bytes(D, C)) return UAPS_EWORKSPACE;
     PairArgs a{}; a.lab = lab_logits; a.un = un_logits; a.w = w; a.D = D; a.B = B; a.C = C; a.H = H; a.W = W;
     a.ce_coef = 0.5f / D; a.dice_coef = 0.5f / D; a.cw1 = cw1; a.cw2 = cw2; a.eps = eps; a.labels = labels; a.pseudo = pseudo;
@@ -124,7 +135,7 @@ extern "C" int uaps_pairloss_finalize_sums(const double* sums, int D, int C, lon
     if (D < 1 || D > UAPS_MAX_HEADS || C < 2 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
     if (!sums || !sup_scalars || !unsup_scalars || n_pixels <= 0) return UAPS_EINVAL;
     hipLaunchKernelGGL(pair_finalize_sums_kernel, dim3(1), dim3(kFinalizeThreads), 0, (hipStream_t)stream, sums, D, C, n_pixels, 0.5f / D,
-                       0.5f / D, cw1, cw2, eps, sup_scalars, unsup_scalars);
+                       0.5f / D, cw1, cw2, eps, sup_scalars, unsup_scalars, (const uint32_t*)g_step_state);
     return (int)hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "rn_math.hpp"
+#include "philox.hpp"
 
 namespace uaps {
 
@@ -525,7 +526,8 @@ static __global__ __launch_bounds__(kFinalizeThreads) void pair_finalize_kernel(
                                                                          const float* __restrict__ part_u, int nrows_u, int D, int C,
                                                                          long N, float ce_coef, float dice_coef, float cw1, float cw2,
                                                                          float eps, float* __restrict__ sscal, float* __restrict__ uscal,
-                                                                         double* __restrict__ sums_out) {
+                                                                         double* __restrict__ sums_out, const uint32_t* __restrict__ st) {
+    cw1 = step_f(st, kStepCw1, cw1); cw2 = step_f(st, kStepCw2, cw2);
     __shared__ double tot_s[kMaxSums], tot_u[kMaxSums];
     __shared__ double dice_s[UAPS_MAX_HEADS];
     const int ns = sup_nsums(D, C), nu = unsup_nsums(D, C);
@@ -542,7 +544,9 @@ static __global__ __launch_bounds__(kFinalizeThreads) void pair_finalize_kernel(
 }
 static __global__ __launch_bounds__(kFinalizeThreads) void pair_finalize_sums_kernel(const double* __restrict__ sums, int D, int C, long N,
                                                                               float ce_coef, float dice_coef, float cw1, float cw2,
-                                                                              float eps, float* __restrict__ sscal, float* __restrict__ uscal) {
+                                                                              float eps, float* __restrict__ sscal, float* __restrict__ uscal,
+                                                                              const uint32_t* __restrict__ st) {
+    cw1 = step_f(st, kStepCw1, cw1); cw2 = step_f(st, kStepCw2, cw2);
     __shared__ double tot_s[kMaxSums], tot_u[kMaxSums];
     __shared__ double dice_s[UAPS_MAX_HEADS];
     const int ns = sup_nsums(D, C), nu = unsup_nsums(D, C);
@@ -721,7 +725,11 @@ template <int D, int C, int VS, int VU, bool PFS, bool PFU, int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void pair_fwd_kernel(HeadPtrs<D> zl, HeadPtrs<D> zu, HeadWeights<D> w, int HW, long N,
                                                                   const int64_t* __restrict__ labels, int64_t* __restrict__ pseudo,
                                                                   float* __restrict__ var, float* __restrict__ part_s,
-                                                                  float* __restrict__ part_u, int nb_s) {
+                                                                  float* __restrict__ part_u, int nb_s, const uint32_t* __restrict__ st) {
+    if (st != nullptr) {                 // captured step: the mixing weights of THIS step come from the step state (philox.hpp)
+#pragma unroll
+        for (int k = 0; k < D; ++k) w.w[k] = __uint_as_float(st[kStepW + k]);
+    }
 #ifdef UAPS_LOSS_STAGGER
     // two waves per SIMD running the same load -> compute loop from the same start stay in lockstep (both wait for memory,
     // then both compete for the VALU): delay the wave in the odd hardware slot by about half a group's period
@@ -741,7 +749,9 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(HeadPtrs<D> zl, Head
                                                             long N, long Nloss, const int64_t* __restrict__ labels,
                                                             const int64_t* __restrict__ pseudo, const float* __restrict__ sscal,
                                                             const float* __restrict__ uscal, float ce_coef, float dice_coef, float cw1,
-                                                            float cw2, const float* __restrict__ gscale, int nb_s) {
+                                                            float cw2, const float* __restrict__ gscale, int nb_s,
+                                                            const uint32_t* __restrict__ st) {
+    cw1 = step_f(st, kStepCw1, cw1); cw2 = step_f(st, kStepCw2, cw2);
     if ((int)blockIdx.x < nb_s) sup_bwd_body<D, C, VS>(zl, dl, HW, N / VS, Nloss, labels, sscal, ce_coef, dice_coef, gscale, (int)blockIdx.x, nb_s);
     else unsup_bwd_body<D, C, VU>(zu, du, HW, N / VU, Nloss, pseudo, uscal, cw1, cw2, gscale, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
 }

@@ -6,14 +6,14 @@ static void launch_variant(const PairArgs& a, long N, int HW, const HeadPtrs<D>&
                            float* part_s, float* part_u, int& nb_s, int& nb_u) {
     nb_s = pair_grid(N / VS, pair_cap_s(a.cfg)); nb_u = pair_grid(N / VU, pair_cap_u(a.cfg));
     hipLaunchKernelGGL((pair_fwd_kernel<D, C, VS, VU, PFS, PFU, MINW>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
-                       a.pseudo, a.var, part_s, part_u, nb_s);
+                       a.pseudo, a.var, part_s, part_u, nb_s, a.w ? (const uint32_t*)nullptr : (const uint32_t*)uaps_get_step_state());
 }
 template <int D, int C> static int run_pair_fwd(const PairArgs& a) {
     constexpr int VU = unsup_vec<D, C>();
     const long HW = (long)a.H * a.W, N = (long)a.B * HW;
     HeadPtrs<D> zl = in_ptrs<D>(a.lab), zu = in_ptrs<D>(a.un);
     HeadWeights<D> w;
-    for (int k = 0; k < D; ++k) w.w[k] = (float)a.w[k];   // float64 weights act as fp32 scalars (UAPS_train.py:252)
+    for (int k = 0; k < D; ++k) w.w[k] = a.w ? (float)a.w[k] : 0.f;   // float64 weights act as fp32 scalars (UAPS_train.py:252); NULL: step state
     float* part_s = a.partials;
     float* part_u = a.partials + (size_t)kMaxBlocks * sup_nsums(D, C);
     int nb_s, nb_u;
@@ -37,7 +37,7 @@ template <int D, int C> static int run_pair_fwd(const PairArgs& a) {
         launch_variant<D, C, 1, 1, false, false, 2>(a, N, (int)HW, zl, zu, w, part_s, part_u, nb_s, nb_u);
     }
     hipLaunchKernelGGL(pair_finalize_kernel, dim3(1), dim3(kFinalizeThreads), 0, a.stream, part_s, nb_s, part_u, nb_u, D, C, N, a.ce_coef,
-                       a.dice_coef, a.cw1, a.cw2, a.eps, a.sscal, a.uscal, a.sums);
+                       a.dice_coef, a.cw1, a.cw2, a.eps, a.sscal, a.uscal, a.sums, (const uint32_t*)uaps_get_step_state());
     return (int)hipGetLastError();
 }
 int launch_pair_fwd(const PairArgs& a) { UAPS_DISPATCH_DC(run_pair_fwd, a) }

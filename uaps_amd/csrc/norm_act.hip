@@ -146,8 +146,9 @@ __global__ __launch_bounds__(64) void bn_coef_eval(const float* __restrict__ con
 template <bool VEC, bool DROP>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, float* __restrict__ out, int C, long HW,
                                                             const float* __restrict__ mean, const float* __restrict__ coef,
-                                                            float slope, float drop_p, float drop_scale, uint64_t seed,
-                                                            uint64_t offset, int Bg) {
+                                                            float slope, float drop_p, float drop_scale, uint64_t seed_in,
+                                                            uint64_t offset, int Bg, const uint32_t* __restrict__ st) {
+    const uint64_t seed = uaps::step_key(seed_in, st);
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C, g = b / Bg;
     const float* cf = coef + (long)g * 4 * C;
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_sums_kernel(const float* __re
                                                                long HW, int nchunks, const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float slope, float drop_p,
-                                                               float drop_scale, uint64_t seed, uint64_t offset,
-                                                               float2* __restrict__ partials, int Bg) {
+                                                               float drop_scale, uint64_t seed_in, uint64_t offset,
+                                                               float2* __restrict__ partials, int Bg, const uint32_t* __restrict__ st) {
+    const uint64_t seed = uaps::step_key(seed_in, st);
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C, g = b / Bg;
     const float mu = mean[g * C + c], is = invstd[g * C + c], sc = gamma[c] * is, sh = beta[c];
@@ -245,8 +247,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __rest
                                                              const float* __restrict__ beta, const float2* __restrict__ partials,
                                                              int nch_p, int B, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ dconv_bias,
-                                                             float slope, float drop_p, float drop_scale, uint64_t seed,
-                                                             uint64_t offset, int Bg) {
+                                                             float slope, float drop_p, float drop_scale, uint64_t seed_in,
+                                                             uint64_t offset, int Bg, const uint32_t* __restrict__ st) {
+    const uint64_t seed = uaps::step_key(seed_in, st);
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C, g = b / Bg;
     // The reduction's finalize runs here, not as a launch of its own: the first wave sums this channel's per-block
@@ -374,7 +377,7 @@ static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_i
                        given_partials ? given_parts_per_image : nch, (double)HW, conv_bias, gamma, beta, running_mean,
                        running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
     const float dscale = 1.f / (1.f - drop_p);
-#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg)
+#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state())
     if (vec) { if (drop_p > 0.f) UAPS_APPLY(true, true); else UAPS_APPLY(true, false); }
     else { if (drop_p > 0.f) UAPS_APPLY(false, true); else UAPS_APPLY(false, false); }
 #undef UAPS_APPLY
@@ -441,9 +444,9 @@ extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, cons
     hipLaunchKernelGGL(bn_coef_eval, dim3((C + 63) / 64), dim3(64), 0, s, conv_bias, gamma, beta, running_mean, running_var, eps, w.coef, save_mean, C);
     const dim3 grid(nchunks_for(HW), B * C);
     if ((HW % 4 == 0) && al16(y) && al16(out))
-        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B);
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B, (const uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B);
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B, (const uint32_t*)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -463,8 +466,8 @@ static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, co
     const dim3 grid(nch, B * C);
     const bool vec = (HW % 4 == 0) && al16(y) && al16(dout) && al16(dy);
     const float dscale = 1.f / (1.f - drop_p);
-#define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials, Bg)
-#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, (const float2*)w.partials, nch, B, dgamma, dbeta, dconv_bias, slope, drop_p, dscale, seed, offset, Bg)
+#define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials, Bg, (const uint32_t*)uaps_get_step_state())
+#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, (const float2*)w.partials, nch, B, dgamma, dbeta, dconv_bias, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state())
     if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
     else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
     if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }

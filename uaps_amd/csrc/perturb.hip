@@ -324,9 +324,11 @@ struct FanInArgs {
     int n, B, Bg;
     long chw4, hw4;
     int W;
+    const uint32_t* st;             // step state (philox.hpp) or NULL
 };
 __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, float4* __restrict__ out) {
     const long total = (long)a.B * a.chw4;
+    const uint64_t seed = uaps::step_key(a.seed, a.st);
     for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
         const long b = e / a.chw4, ce = e - b * a.chw4;
         const int grp = (int)(b / a.Bg);
@@ -348,13 +350,13 @@ __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, 
                 v = a.g[k][e];
             }
             if (a.mode[k] == 1) {
-                const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, a.seed);
+                const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, seed);
                 const float n0 = (2.f * u01(r.x) - 1.f) * a.range, n1 = (2.f * u01(r.y) - 1.f) * a.range;
                 const float n2 = (2.f * u01(r.z) - 1.f) * a.range, n3 = (2.f * u01(r.w) - 1.f) * a.range;
                 v.x = add_rn(mul_rn(v.x, n0), v.x); v.y = add_rn(mul_rn(v.y, n1), v.y);
                 v.z = add_rn(mul_rn(v.z, n2), v.z); v.w = add_rn(mul_rn(v.w, n3), v.w);
             } else if (a.mode[k] == 2) {
-                const U4 r = philox4x32_10(a.off[k][0] + (uint64_t)e, a.seed);
+                const U4 r = philox4x32_10(a.off[k][0] + (uint64_t)e, seed);
                 v.x = u01(r.x) >= a.p ? v.x * a.scale : 0.f; v.y = u01(r.y) >= a.p ? v.y * a.scale : 0.f;
                 v.z = u01(r.z) >= a.p ? v.z * a.scale : 0.f; v.w = u01(r.w) >= a.p ? v.w * a.scale : 0.f;
             } else if (a.mode[k] == 3) {
@@ -384,9 +386,11 @@ struct FanOutArgs {
     float range, p, scale;
     int n, B, Bg;
     long chw4, hw4;
+    const uint32_t* st;             // step state (philox.hpp) or NULL
 };
 __global__ __launch_bounds__(kThreads) void fanout_perturbed_kernel(const float4* __restrict__ f, FanOutArgs a) {
     const long total = (long)a.B * a.chw4;
+    const uint64_t seed = uaps::step_key(a.seed, a.st);
     for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
         const long b = e / a.chw4, ce = e - b * a.chw4;
         const int grp = (int)(b / a.Bg);
@@ -396,18 +400,21 @@ __global__ __launch_bounds__(kThreads) void fanout_perturbed_kernel(const float4
             if (k >= a.n) break;
             float4 v = x;
             if (a.mode[k] == 1) {
-                const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, a.seed);
+                const U4 r = philox4x32_10(a.off[k][grp] + (uint64_t)ce, seed);
                 const float n0 = (2.f * u01(r.x) - 1.f) * a.range, n1 = (2.f * u01(r.y) - 1.f) * a.range;
                 const float n2 = (2.f * u01(r.z) - 1.f) * a.range, n3 = (2.f * u01(r.w) - 1.f) * a.range;
                 v.x = add_rn(mul_rn(v.x, n0), v.x); v.y = add_rn(mul_rn(v.y, n1), v.y);
                 v.z = add_rn(mul_rn(v.z, n2), v.z); v.w = add_rn(mul_rn(v.w, n3), v.w);
             } else if (a.mode[k] == 2) {
-                const U4 r = philox4x32_10(a.off[k][0] + (uint64_t)e, a.seed);
+                const U4 r = philox4x32_10(a.off[k][0] + (uint64_t)e, seed);
                 v.x = u01(r.x) >= a.p ? v.x * a.scale : 0.f; v.y = u01(r.y) >= a.p ? v.y * a.scale : 0.f;
                 v.z = u01(r.z) >= a.p ? v.z * a.scale : 0.f; v.w = u01(r.w) >= a.p ? v.w * a.scale : 0.f;
             } else if (a.mode[k] == 3) {
                 const long pix = ce % a.hw4;
-                const float thr = mul_rn(fkey_inv(a.maxkey[b]), a.u[grp]);
+                // threshold factor U(0.7, 0.9) (UAPS_unet.py:164): the host's draw, or -- a negative value asks for it -- one
+                // Philox draw per (call, statistics group) on the device (captured steps cannot take a new host number)
+                const float uf = a.u[grp] >= 0.f ? a.u[grp] : 0.7f + 0.2f * u01(philox4x32_10(a.off[k][grp], seed).x);
+                const float thr = mul_rn(fkey_inv(a.maxkey[b]), uf);
                 const float4 t = a.att[b * a.hw4 + pix];
                 const bool k0 = t.x < thr, k1 = t.y < thr, k2 = t.z < thr, k3 = t.w < thr;
                 if (ce < a.hw4) a.keep[k][b * a.hw4 + pix] = make_uchar4(k0, k1, k2, k3);      // channel 0 writes the mask
@@ -572,6 +579,7 @@ extern "C" int uaps_fanout_perturbed(const float* f, float* const* out, const in
         a.att = (const float4*)((const char*)fdrop_ws + (((size_t)B * 4 + 255) / 256) * 256);
     }
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
+    a.st = (const uint32_t*)uaps_get_step_state();
     a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4;
     hipLaunchKernelGGL(fanout_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)f, a);
     return (int)hipGetLastError();
@@ -610,6 +618,7 @@ extern "C" int uaps_fanin_perturbed(const float* const* g, const int* mode, cons
         for (int q = 0; q < groups; ++q) a.off[k][q] = offsets ? offsets[(size_t)k * groups + q] : 0;
     }
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
+    a.st = (const uint32_t*)uaps_get_step_state();
     a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4; a.W = W;
     hipLaunchKernelGGL(fanin_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, a, (float4*)out);
     return (int)hipGetLastError();

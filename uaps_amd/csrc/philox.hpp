@@ -18,6 +18,19 @@ __device__ __forceinline__ U4 philox4x32_10(uint64_t ctr, uint64_t key) {
     }
     return U4{c0, c1, c2, c3};
 }
+// Step state (uaps_set_step_state): a small device buffer the host refreshes before every step so that a CAPTURED step
+// (hipGraph replay: kernel arguments are frozen) still draws new random numbers and sees the current schedule values.
+//   word 0-1  uint64 added to every Philox key          word 2-9   float mixing weights w[8] (UAPS_train.py:251)
+//   word 10   cw1    word 11  cw2  (UAPS_train.py:279-280)          word 12-13 Adam lr / bias-correction1, 1 / sqrt(bias-correction2)
+// A null pointer (the default) means: use the by-value arguments.
+constexpr int kStepW = 2, kStepCw1 = 10, kStepCw2 = 11, kStepAdam = 12, kStepWords = 16;
+__device__ __forceinline__ uint64_t step_key(uint64_t seed, const uint32_t* st) {
+    return st ? seed + (((uint64_t)st[1] << 32) | (uint64_t)st[0]) : seed;
+}
+__device__ __forceinline__ float step_f(const uint32_t* st, int word, float by_value) {      // NaN by value = read the step state
+    return (st && by_value != by_value) ? __uint_as_float(st[word]) : by_value;
+}
 __device__ __forceinline__ float u01(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }   // [0,1)
 __device__ __forceinline__ uint32_t pick(const U4& r, int i) { return i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w; }
 }  // namespace uaps
+extern "C" const void* uaps_get_step_state(void);

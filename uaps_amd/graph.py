@@ -1,0 +1,177 @@
+"""Captured training step: the whole UAPS step (forward_pair, loss block, backward, Adam, confusion matrix) recorded once as a
+hipGraph (torch.cuda.CUDAGraph) and replayed with ONE launch per step.
+
+Why: a step is ~450 kernel launches driven by ~9 ms of Python (autograd Functions + ctypes); at 16 + 16 images the GPU work
+(17-18 ms) hides that, at small batches it is the whole step.  A replay also lets the four decoder chains overlap on the GPU
+(the capture records the per-decoder streams of UNet_UAPS as parallel branches) without any host involvement.
+
+What changes per step can no longer travel in kernel arguments (a graph freezes them), so it lives in the device-resident
+*step state* (include/uaps_hip.h, uaps_set_step_state): the Philox key increment, the Dirichlet mixing weights, the two
+consistency weights and Adam's two step scalars.  The host refreshes a pinned mirror before every step; the upload is the first
+node of the graph.  `UAPSTrainer(step_state=True)` runs the same code path eagerly (bit-identical to the replay, which is
+how tests/test_gpu_graph.py pins the capture); `use_graph=True` adds the capture.  Single-process only (world size 1).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, conv, losses, metrics, perturb
+
+_KEY_STEP = 0x9E3779B97F4A7C15
+NAN = float("nan")
+
+
+class StepState:
+    """Pinned host mirror + device buffer of the 16-word step state."""
+
+    def __init__(self, device: torch.device):
+        self.host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.dev = torch.zeros(16, dtype=torch.int32, device=device)
+        self._u32 = self.host.numpy().view(np.uint32)
+        self._f32 = self.host.numpy().view(np.float32)
+        self.key = 0
+
+    def fill(self, w, cw1: float, cw2: float, adam_step_size: float, adam_inv_sqrt_bc2: float) -> None:
+        self.key = (self.key + _KEY_STEP) & 0xFFFFFFFFFFFFFFFF
+        self._u32[0], self._u32[1] = self.key & 0xFFFFFFFF, self.key >> 32
+        self._f32[2:10] = 0.0
+        self._f32[2:2 + len(w)] = np.asarray(w, dtype=np.float64).astype(np.float32)
+        self._f32[10], self._f32[11] = cw1, cw2
+        self._f32[12], self._f32[13] = adam_step_size, adam_inv_sqrt_bc2
+
+    def upload(self) -> None:
+        self.dev.copy_(self.host, non_blocking=True)
+
+    def activate(self) -> None:
+        _lib.check(_lib.lib().uaps_set_step_state(self.dev.data_ptr()), "uaps_set_step_state")
+
+    @staticmethod
+    def deactivate() -> None:
+        _lib.check(_lib.lib().uaps_set_step_state(None), "uaps_set_step_state")
+
+
+class StepGraph:
+    """State-mode step of a UAPSTrainer, eager or captured.  Owned by the trainer (trainer.train_step dispatches here)."""
+
+    def __init__(self, trainer, capture: bool, warmup: int = 2):
+        if trainer.world != 1:
+            raise ValueError("the captured step is single-process (world size 1)")
+        if not trainer.pair_forward:
+            raise ValueError("the captured step needs the forward_pair path (a GPU model)")
+        self.tr = trainer
+        self.state = StepState(trainer.device)
+        self.want_capture, self.warmup = capture, max(1, warmup)     # Adam's lazily created moments must exist before a capture
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.calls = 0
+        self.static = None
+        self._side = torch.cuda.Stream(device=trainer.device) if capture else None
+        self._adam_t = None
+        trainer.optimizer.from_step_state = True
+
+    # ---- host side of one step: what the reference's loop computes on the host (UAPS_train.py:251, 279-280, 292) ----
+    def _refresh(self):
+        tr = self.tr
+        opt = tr.optimizer
+        if self._adam_t is None:
+            st = [opt.state[p].get("step") for g in opt.param_groups for p in g["params"] if p in opt.state]
+            self._adam_t = int(st[0]) if st else 0
+        self._adam_t += 1
+        ss, isb = opt.step_scalars(self._adam_t)
+        w = tr.mix_rng.dirichlet(np.ones(tr.n_heads), size=1)[0]
+        cw1, cw2 = tr.consistency_weights()
+        self.state.fill(w, cw1, cw2, ss, isb)
+        return w, cw1, cw2
+
+    def _body(self, x_l, y_l, x_u):
+        """The device work of one step; every per-step scalar comes from the step state (w = None, cw = NaN)."""
+        tr = self.tr
+        perturb._RngState.offset = 0                 # the key changes every step: the counters may restart (and must, for replays)
+        both = tr.model.forward_pair(x_l, x_u)
+        out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
+        tr.optimizer.zero_grad(set_to_none=True)
+        out.loss.backward()
+        tr.optimizer.step()
+        cm = metrics.seg_confusion(both[0][: x_l.shape[0]], y_l) if tr.track_metrics else None
+        return out, cm
+
+    def _after_replay(self):
+        """Host bookkeeping of a replayed optimizer.step(): Adam's host-resident step counters, and the packed-weight cache
+        (the replay re-packed into the graph's own buffers; eager code -- validate() -- must pack the new weights itself)."""
+        opt = self.tr.optimizer
+        steps = [opt.state[p]["step"] for g in opt.param_groups for p in g["params"] if p in opt.state]
+        torch._foreach_add_(steps, 1)
+        conv.invalidate_packed_weights()
+
+    def step(self, x_l, y_l, x_u) -> Dict[str, torch.Tensor]:
+        tr = self.tr
+        if not tr.model.training:
+            tr.model.train()
+        prev = (conv.REPACK_IN_PLACE, perturb.DEVICE_THRESHOLDS)
+        conv.REPACK_IN_PLACE, perturb.DEVICE_THRESHOLDS = True, True
+        self.state.activate()
+        try:
+            w, cw1, cw2 = self._refresh()
+            if self.graph is not None and self._matches(x_l, y_l, x_u):
+                self._copy_in(x_l, y_l, x_u)
+                self.graph.replay()
+                self._after_replay()
+                out, cm = self.static["out"], self.static["cm"]
+            elif self.want_capture and self.calls >= self.warmup and self.graph is None:
+                out, cm = self._capture(x_l, y_l, x_u)
+            else:
+                if self._side is not None:             # warm-up steps of a capture run on a side stream (torch's capture recipe)
+                    self._side.wait_stream(torch.cuda.current_stream(tr.device))
+                    with torch.cuda.stream(self._side):
+                        self.state.upload()
+                        out, cm = self._body(x_l, y_l, x_u)
+                    torch.cuda.current_stream(tr.device).wait_stream(self._side)
+                else:
+                    self.state.upload()
+                    out, cm = self._body(x_l, y_l, x_u)
+        finally:
+            conv.REPACK_IN_PLACE, perturb.DEVICE_THRESHOLDS = prev
+            StepState.deactivate()
+        self.calls += 1
+        if cm is not None:
+            tr._cms.append(cm.clone() if self.graph is not None else cm)
+        tr.iter_num += 1
+        tr.last = {"loss": out.loss.detach(), "sup": out.sup.detach(), "unsup": out.unsup.detach(), "cw1": cw1, "cw2": cw2, "w": w}
+        return tr.last
+
+    # ---- capture / replay ----
+    def _matches(self, x_l, y_l, x_u) -> bool:
+        s = self.static
+        return s is not None and x_l.shape == s["x_l"].shape and y_l.shape == s["y_l"].shape and x_u.shape == s["x_u"].shape
+
+    def _copy_in(self, x_l, y_l, x_u) -> None:
+        s = self.static
+        for name, t in (("x_l", x_l), ("y_l", y_l), ("x_u", x_u)):
+            if t.data_ptr() != s[name].data_ptr():
+                s[name].copy_(t, non_blocking=True)
+
+    def _capture(self, x_l, y_l, x_u):
+        tr = self.tr
+        dev = tr.device
+        self.static = {"x_l": x_l.clone(), "y_l": y_l.clone(), "x_u": x_u.clone()}
+        conv.invalidate_packed_weights()             # the weight packing must be part of the captured step
+        tr.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.state.upload()
+            out, cm = self._body(self.static["x_l"], self.static["y_l"], self.static["x_u"])
+        self.graph = g
+        self.static["out"], self.static["cm"] = out, cm
+        # the graph writes the packed weights through raw pointers: hold the buffers, whatever the cache does later
+        self.static["packed"] = [(e[3], e[4]) for e in conv._packed.values()]
+        # the capture executed nothing (and its host-side Adam counter bump belongs to no step): undo that, then run the step
+        opt = tr.optimizer
+        steps = [opt.state[p]["step"] for gr in opt.param_groups for p in gr["params"] if p in opt.state]
+        torch._foreach_add_(steps, -1)
+        g.replay()
+        self._after_replay()
+        return out, cm

@@ -301,7 +301,7 @@ class _PairLoss(torch.autograd.Function):
             ns = C.c_int()
             _lib.check(L.uaps_pairloss_num_sums(D, Cc, C.byref(ns)), "uaps_pairloss_num_sums")
             sums = torch.empty(ns.value, dtype=torch.float64, device=dev)
-        w64 = (C.c_double * D)(*[float(x) for x in w])
+        w64 = (C.c_double * D)(*[float(x) for x in w]) if w is not None else None      # None: the device step state's weights
         st = _lib.current_stream(dev)
         n_loss = B * H * W
         with _lib.device_guard(dev):
@@ -365,9 +365,10 @@ def uaps_pair_loss(pair_logits, labels, w, cw1, cw2, eps=1e-7, return_var=False,
     """uaps_step_loss for the output of UNet_UAPS.forward_pair: D tensors [2B,C,H,W] whose rows [:B] are the labelled
     batch (supervised branch, UAPS_train.py:194-218) and rows [B:] the unlabelled one (:186-189, 223-282).
     `exchange`: see _PairLoss (gathered-batch loss statistics across ranks)."""
-    if len(w) != len(pair_logits):
+    if w is not None and len(w) != len(pair_logits):
         raise ValueError("one mixing weight per head")
-    out = _PairLoss.apply(labels, tuple(float(x) for x in w), cw1, cw2, eps, bool(return_var), exchange, True, *pair_logits)
+    out = _PairLoss.apply(labels, tuple(float(x) for x in w) if w is not None else None, cw1, cw2, eps, bool(return_var), exchange, True,
+                          *pair_logits)
     return StepLoss(out[0], out[1], out[2], out[3], out[6] if return_var else None, out[4], out[5])
 
 

@@ -19,6 +19,15 @@ class Adam(torch.optim.Adam):
             raise ValueError("uaps_amd.optim.Adam: amsgrad / maximize / capturable / differentiable are not supported")
         kw.pop("fused", None); kw.pop("foreach", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False, fused=False, **kw)
+        # True: the kernel reads lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) from the step state (uaps_set_step_state) instead
+        # of taking them by value, so that a captured step can be replayed (trainer.StepGraph keeps the state current)
+        self.from_step_state = False
+
+    def step_scalars(self, t: int):
+        """(lr / bias_correction1, 1 / sqrt(bias_correction2)) of step t for the first parameter group, as uaps_adam_step computes them."""
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        return float(g["lr"]) / (1.0 - b1 ** t), 1.0 / (1.0 - b2 ** t) ** 0.5
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -48,6 +57,8 @@ class Adam(torch.optim.Adam):
             step = int(steps[0])
             if int(steps[-1]) != step:
                 raise RuntimeError("uaps_amd.optim.Adam: parameters of one group must share the step count")
+            if self.from_step_state:                              # lr / bias corrections come from the device step state
+                step = 0
             n = len(ps)
             arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
             sizes = (C.c_long * n)(*[p.numel() for p in ps])

@@ -21,6 +21,11 @@ import torch.nn as nn
 from . import _lib
 
 
+# Captured steps (trainer graph mode) cannot take a fresh host number per replay: with DEVICE_THRESHOLDS the FeatureDropout
+# threshold factors U(0.7, 0.9) (UAPS_unet.py:164) are drawn by the fan-out kernel itself from its own Philox counter.
+DEVICE_THRESHOLDS = False
+
+
 class _RngState:
     """(seed, running Philox counter offset).  One per process; ranks use different seeds."""
     seed = 0x5EED_0A95
@@ -334,9 +339,13 @@ class _PerturbFan(torch.autograd.Function):
                     ws = _fd_ws.get(key)
                     if ws is None or ws.numel() < need.value:
                         ws = _fd_ws[key] = torch.empty(need.value, dtype=torch.uint8, device=dev)
-                    us = [float(np.random.uniform(0.7, 0.9)) for _ in range(groups)]
                     kp[i] = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
-                    offsets.append([0] * groups); keeps.append(kp[i])
+                    if DEVICE_THRESHOLDS:
+                        us = [-1.0] * groups
+                        offsets.append([_RngState.reserve(4)[1] for _ in range(groups)]); keeps.append(kp[i])
+                    else:
+                        us = [float(np.random.uniform(0.7, 0.9)) for _ in range(groups)]
+                        offsets.append([0] * groups); keeps.append(kp[i])
             with _lib.device_guard(dev):
                 st = _lib.current_stream(dev)
                 if ws is not None:

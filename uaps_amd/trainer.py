@@ -23,7 +23,8 @@ class UAPSTrainer:
     def __init__(self, model: torch.nn.Module, base_lr: float = 1e-3, consistency1: float = 0.1,
                  consistency2: float = 0.1, consistency_rampup: float = 200, ramp_divisor: int = 80,
                  seed: int = 1337, loss_fn: Optional[Callable] = None, overlap_comm: bool = True,
-                 track_metrics: bool = True, pair_forward: bool = True, gathered_loss: bool = False):
+                 track_metrics: bool = True, pair_forward: bool = True, gathered_loss: bool = False, step_state: bool = False,
+                 use_graph: bool = False):
         self.model = model
         params = list(model.parameters())
         self.device = params[0].device
@@ -54,6 +55,12 @@ class UAPSTrainer:
         self.buckets = udist.GradBuckets(model, overlap=overlap_comm, average=not self.gathered_loss) if self.world > 1 else None
         self._cms = []                                        # one on-device C x C confusion matrix per training step
         self.last: Dict[str, torch.Tensor] = {}
+        # step_state: per-step scalars and the RNG key travel through the device-resident step state instead of kernel
+        # arguments (uaps_amd.graph); use_graph: that step is captured as a hipGraph after two warm-up steps and replayed
+        self.step_graph = None
+        if (step_state or use_graph) and on_gpu:
+            from .graph import StepGraph
+            self.step_graph = StepGraph(self, capture=bool(use_graph))
 
     # -- schedule (UAPS_train.py:279-280) --
     def consistency_weights(self):
@@ -62,6 +69,8 @@ class UAPSTrainer:
 
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u: torch.Tensor, w=None) -> Dict[str, torch.Tensor]:
         """Returns device scalars (loss, sup, unsup); nothing here synchronises with the host."""
+        if self.step_graph is not None and w is None and x_l.shape == x_u.shape:
+            return self.step_graph.step(x_l, y_l, x_u)
         if not self.model.training:                      # model.train() walks ~2600 modules: only when the mode changes
             self.model.train()
         cw1, cw2 = self.consistency_weights()

@@ -271,7 +271,8 @@ class UNet_UAPS(nn.Module):
                 side.wait_event(ready)
                 with torch.cuda.stream(side):
                     outs[d] = decoders[d](per_dec[d])
-                outs[d].record_stream(main)              # consumed by the loss on the main stream
+                if not torch.cuda.is_current_stream_capturing():
+                    outs[d].record_stream(main)          # consumed by the loss on the main stream
             outs[0] = decoders[0](per_dec[0])
             for side in self._streams:
                 main.wait_stream(side)
