@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="time the headline steps with all launches on one HIP stream (default: one stream per auxiliary decoder, "
                          "bit-identical results, launches of different decoders overlap)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N=1 only: run the timed steps eagerly instead of replaying the captured hipGraph of the step (uaps_amd/graph.py)")
     ap.add_argument("--analysis-steps", type=int, default=6, help="single-stream steps after the timed region for the per-kernel figures")
     args = ap.parse_args()
 
@@ -162,7 +164,10 @@ def main():
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
-    trainer = uaps_amd.UAPSTrainer(model, seed=1337)
+    # one process: the step is captured as a hipGraph after two eager steps (needs --warmup >= 3 to stay out of the timed region)
+    # and replayed, bit-identical to the eager step; N > 1 steps eagerly (the RCCL bucket exchange is not captured)
+    use_graph = world == 1 and not args.no_graph and args.net == "unet_uaps"
+    trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
     data = uaps_amd.data.SyntheticBatches(b, 3, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
 
     from uaps_amd import conv
@@ -207,6 +212,7 @@ def main():
     discover, ev, cev, single_ms = None, {}, {}, None
     if args.analysis_steps > 0:                              # every rank steps (the gradient exchange is collective); rank 0's events are reported
         _unet._DECODER_STREAMS = False
+        trainer.step_graph, trainer.optimizer.from_step_state = None, False     # eager launches: events can bracket each kernel
         trainer.train_step(*data.next())                   # re-warm in the new mode
         torch.cuda.synchronize()
         conv.KERNEL_EVENTS, conv.EVENT_FILTER, losses.KERNEL_EVENTS = {}, None, {}
@@ -301,6 +307,8 @@ def main():
                          "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
         mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (bit-identical to single-stream)"
+        if use_graph:
+            mode = "captured hipGraph of the whole step, replayed once per step (bit-identical to the eager step); " + mode
         res = {"metric": "training images/sec (labeled+unlabeled) NEU-Seg 256x256 K=3", "value": round(2 * b * world * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

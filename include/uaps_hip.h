@@ -295,11 +295,22 @@ int uaps_up_cat_fwd(const float* skip, const float* low, float* out, int B, int 
 int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs, int Cl, int h, int w,
                     uaps_stream_t stream);
 
+/* out[i] = max_c(|gamma_i[c]| + |beta_i[c]|) for n BatchNorm layers (host arrays of n device pointers / channel counts), one
+ * launch: times sqrt(elements per channel and statistics group) this bounds every output of the train-mode
+ * BatchNorm (+ LeakyReLU) of utilities/UAPS_unet.py:38-39 (|x_hat| <= sqrt(n - 1) for batch statistics), the operand bound
+ * of the convolutions behind it (uaps_next_call_hints). */
+int uaps_bn_param_bounds(const float* const* gamma_host, const float* const* beta_host, const int* C_host, int n, float* out,
+                         uaps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Convolutions of the U-Net: every nn.Conv2d of utilities/UAPS_unet.py (ConvBlock 3x3 :36-44,
  * UpBlock.conv1x1 :73, Decoder.out_conv :138-139; stride 1, padding ks/2, ks in {1,3}), fp32 NCHW,
- * computed as an implicit GEMM on the matrix cores in one of two arithmetic modes (uaps_conv_set_mode):
- *   1 (default)  exact three-way bf16 split of both fp32 operands, six partial products per multiply on
+ * computed as an implicit GEMM on the matrix cores in one of three arithmetic modes (uaps_conv_set_mode):
+ *   2 (default)  as 1, and where the caller supplies magnitude bounds of the tensor operands (uaps_next_call_hints):
+ *                both fp32 operands scaled by a power of two and split into two fp16 pieces (22 significant bits),
+ *                three partial products per multiply on v_mfma_f32_*_f16 with fp32 accumulation -- an error below that of
+ *                the fp32 matrix instruction's accumulation chain (tests/test_gpu_conv.py) at twice the rate of mode 1,
+ *   1            exact three-way bf16 split of both fp32 operands, six partial products per multiply on
  *                v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the error of an fp32 fma chain at 2.67x the
  *                fp32 matrix rate (csrc/conv_split.hpp); used for 16-byte-aligned rows without dilation,
  *   0            the exact-f32 matrix instruction v_mfma_f32_16x16x4_f32 for everything (also: UAPS_CONV_MODE=0,
@@ -316,9 +327,26 @@ int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs,
  * Bits 24-27 of `cfg` are functional: the dilation of a 3x3 kernel, 0/1 (none), 2 or 4, with padding = dilation
  * (the dilated stages of utilities/resnet.py:8-10, 201-203); pass the same value to all three directions.
  * ------------------------------------------------------------------------------------------- */
-int uaps_conv_set_mode(int mode);      /* 0 / 1 as above; process-wide, not stream-ordered: set it between steps */
+int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above; process-wide, not stream-ordered: set it between steps */
+
+/* One-shot side arguments for the NEXT kernel entry point called on this thread; that call consumes and clears them
+ * (every convolution entry point, uaps_bn_act_bwd*, uaps_pairloss_bwd and uaps_upsample2x do; NULL clears).
+ *   bound[i], mul[i]  device scalar b and host factor m > 0 with |operand i| <= b[0] * m for every element; NULL = unknown.
+ *                     Operands: conv forward: 0 = x (for the *_bn entry points: the activation after the fused
+ *                     BatchNorm + LeakyReLU), 1 = x2 of *_cat;  conv bwd_data: 0 = dy;  conv bwd_weight: 0 = dy, 1 = x, 2 = x2.
+ *                     In mode 2 a 3x3 convolution whose tensor operands all carry a bound runs in the two-piece fp16 form;
+ *                     without bounds it runs as in mode 1.  A bound that is too small makes the result wrong (fp16
+ *                     overflow), one that is too large by up to 2^10 costs no accuracy.
+ *   out_amax          device scalar (zero-initialised by the caller) that the producing kernel raises atomically to the
+ *                     maximum |element| of its output tensor: the bound of a later convolution's operand. */
+typedef struct uaps_call_hints {
+    const float* bound[3];
+    float mul[3];
+    float* out_amax;
+} uaps_call_hints;
+int uaps_next_call_hints(const uaps_call_hints* hints);
 int uaps_conv_get_mode(void);
-/* both packed buffers hold the fp32 layout followed by the bf16-split layout; they must be 16-byte aligned */
+/* both packed buffers hold the fp32 layout followed by the bf16-split and the fp16-split layouts; they must be 16-byte aligned */
 int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);
 int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* wf, float* wb, uaps_stream_t stream);
 /* n convolutions packed by one launch (host arrays with n entries; wf[i] or wb[i] may be NULL). */

@@ -40,10 +40,11 @@ def test_pack_sizes_and_workspace_queries(L):
     nf, nb = C.c_size_t(), C.c_size_t()
     assert L.uaps_conv_pack_floats(16, 3, 3, C.byref(nf), C.byref(nb)) == OK
     # exact layout: K padded to 4 (Cin <= 4) / 16, N padded to 16; then the three-piece bf16 layout: 3 pieces x taps x
-    # channel groups (8 channels each, padded to a multiple of 4 groups) x N x 16 bytes
-    assert nf.value == 9 * 4 * 16 + 3 * 9 * 4 * 16 * 4 and nb.value == 9 * 16 * 16 + 3 * 9 * 4 * 16 * 4
+    # channel groups (8 channels each, padded to a multiple of 4 groups) x N x 16 bytes; then a 32-float header (partial maxima of |w|, scale,
+    # 1 / scale) and the two-piece fp16 layout of the same shape
+    assert nf.value == 9 * 4 * 16 + 5 * 9 * 4 * 16 * 4 + 32 and nb.value == 9 * 16 * 16 + 5 * 9 * 4 * 16 * 4 + 32
     assert L.uaps_conv_pack_floats(64, 128, 1, C.byref(nf), C.byref(nb)) == OK
-    assert nf.value == 128 * 64 + 3 * 16 * 64 * 4 and nb.value == 64 * 128 + 3 * 8 * 128 * 4
+    assert nf.value == 128 * 64 + 5 * 16 * 64 * 4 + 32 and nb.value == 64 * 128 + 5 * 8 * 128 * 4 + 32
     assert L.uaps_conv_pack_floats(0, 3, 3, C.byref(nf), C.byref(nb)) == EINVAL
     assert L.uaps_conv_pack_floats(16, 3, 5, C.byref(nf), C.byref(nb)) == EINVAL          # only 1x1 and 3x3 exist
     n = C.c_size_t()
@@ -58,9 +59,10 @@ def test_kernel_plan_names_and_statistics_tiles(L):
     assert L.uaps_conv_set_mode(0) == OK and L.uaps_conv_get_mode() == 0
     assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
     assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # exact mode: the fp32 matrix instruction
+    assert L.uaps_conv_set_mode(2) == OK and L.uaps_conv_get_mode() == 2                 # default: fp16 pieces where operands carry bounds
     assert L.uaps_conv_set_mode(1) == OK and L.uaps_conv_get_mode() == 1
     assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
-    assert buf.value.decode() == "conv_s32_kernel<32>"                                   # split mode (default): 32x32x16 bf16 form
+    assert buf.value.decode() == "conv_s32_kernel<32>"                                   # split modes: the 32x32x16 form (bf16 / fp16 pieces)
     assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 1 << 28, buf, 96) == OK
     assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # cfg bit 28: exact kernels for this call
     assert L.uaps_conv_set_mode(7) == EINVAL
@@ -75,9 +77,25 @@ def test_kernel_plan_names_and_statistics_tiles(L):
     assert buf.value.decode() == "conv_swrw_kernel<4, 2, 2>"                             # split mode: 32 x 32 channel blocks, 4-row tiles
     assert L.uaps_conv_wrw_variant(32, 64, 64, 64, 64, 3, 1 << 28, buf, 96) == OK
     assert buf.value.decode() == "conv_wrw_kernel<3, 4, 32, 2, 2, 4, 1>"                 # cfg bit 28: the fp32 matrix instruction
+    assert L.uaps_conv_set_mode(2) == OK
     parts = C.c_int()
     assert L.uaps_conv_fwd_stats_parts(32, 16, 16, 256, 256, 3, 0, C.byref(parts)) == OK and parts.value == 32 * 8
     assert L.uaps_conv_fwd_stats_parts(4, 128, 128, 16, 16, 3, 0, C.byref(parts)) == OK and parts.value == 1
+
+
+def test_call_hints_are_validated_and_one_shot(L):
+    h = _lib.CallHints()
+    assert L.uaps_next_call_hints(C.byref(h)) == OK
+    h.bound[0], h.mul[0] = 1 << 20, 0.0                                                  # a bound needs a positive finite factor
+    assert L.uaps_next_call_hints(C.byref(h)) == EINVAL
+    h.mul[0] = float("inf")
+    assert L.uaps_next_call_hints(C.byref(h)) == EINVAL
+    h.mul[0] = 2.0
+    assert L.uaps_next_call_hints(C.byref(h)) == OK
+    assert L.uaps_conv_fwd(None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL   # consumes the pending hints
+    assert L.uaps_next_call_hints(None) == OK
+    out = (C.c_float * 1)()
+    assert L.uaps_bn_param_bounds(None, None, None, 1, out, None) == EINVAL
 
 
 def test_tensors_of_two_gib_or_more_are_refused_before_any_launch(L):

@@ -10,15 +10,22 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["split", "exact"])
+@pytest.fixture(autouse=True, params=["h16", "split", "exact"])
 def conv_mode(request):
-    """Every test of this file runs in both arithmetic modes of the convolution kernels: the three-way bf16 split on the
-    bf16 matrix pipe (the default) and the fp32 matrix instruction."""
+    """Every test of this file runs in the three arithmetic modes of the convolution kernels: two fp16 pieces per scaled operand
+    (the default; needs the operands' magnitude bounds, which _b() attaches), the three-way bf16 split, and the fp32 matrix
+    instruction."""
     from uaps_amd import conv
     prev = conv.get_mode()
     conv.set_mode(request.param)
     yield request.param
     conv.set_mode(prev)
+
+
+def _b(t, slack=1.0):
+    """Attach the tensor's magnitude bound (uaps_amd/bounds.py) the way the producing kernels do: a device scalar >= max|t|."""
+    from uaps_amd import bounds
+    return bounds.put(t, t.detach().abs().max().reshape(1) * slack, 1.0)
 
 # (B, Cin, Cout, H, W, ks)
 SHAPES = [
@@ -54,8 +61,8 @@ def test_conv_forward_backward_vs_torch_cpu(B, Cin, Cout, H, W, ks):
     yr.backward(dy)
     dev = torch.device("cuda:0")
     xg, wg, bg = (t.to(dev).requires_grad_(True) for t in (x, w, b))
-    y = conv2d(xg, wg, bg)
-    y.backward(dy.to(dev))
+    y = conv2d(_b(xg), wg, bg)
+    y.backward(_b(dy.to(dev)))
 
     def close(a, ref, what):
         scale = float(ref.abs().max()) + 1e-12
@@ -128,7 +135,7 @@ def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
     from uaps_amd import fused
     from uaps_amd.conv import conv2d, conv2d_with_stats
     dev = torch.device("cuda:0")
-    x = _mk((B, Cin, H, W), 11).to(dev)
+    x = _b(_mk((B, Cin, H, W), 11).to(dev))
     w = (_mk((Cout, Cin, 3, 3), 12) / np.sqrt(9 * Cin)).to(dev)
     y, st = conv2d_with_stats(x, w)
     assert torch.equal(y, conv2d(x, w))
@@ -157,12 +164,12 @@ def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
     x1, x2 = _mk((B, C1, H, W), 21).to(dev).requires_grad_(True), _mk((B, C2, H, W), 22).to(dev).requires_grad_(True)
     w = (_mk((Cout, C1 + C2, ks, ks), 23) / np.sqrt((C1 + C2) * ks * ks)).to(dev).requires_grad_(True)
     b = _mk((Cout,), 24).to(dev).requires_grad_(True)
-    dy = _mk((B, Cout, H, W), 25).to(dev)
-    y, st = conv2d_cat(x1, x2, w, b, with_stats=True)
+    dy = _b(_mk((B, Cout, H, W), 25).to(dev))
+    y, st = conv2d_cat(_b(x1), _b(x2), w, b, with_stats=True)
     y.backward(dy)
     g = (x1.grad.clone(), x2.grad.clone(), w.grad.clone(), b.grad.clone())
     x1.grad = x2.grad = w.grad = b.grad = None
-    xc = torch.cat([x1, x2], dim=1).detach().requires_grad_(True)
+    xc = _b(torch.cat([x1, x2], dim=1).detach().requires_grad_(True))
     yr = conv2d(xc, w, b)
     yr.backward(dy)
     assert torch.equal(y, yr)
@@ -212,15 +219,67 @@ def test_split_mode_is_as_accurate_as_the_fp32_matrix_instruction(B, Cin, Cout, 
     mag_dx = torch.nn.grad.conv2d_input(x.shape, wr.abs(), dy.double().abs(), padding=ks // 2)
     dev = torch.device("cuda:0")
     errs = {}
-    for mode in ("split", "exact"):
+    for mode in ("h16", "split", "exact"):
         conv.set_mode(mode)
         xg, wg = x.to(dev).requires_grad_(True), w.to(dev)
-        y = conv.conv2d(xg, wg)
-        y.backward(dy.to(dev))
+        y = conv.conv2d(_b(xg), wg)
+        y.backward(_b(dy.to(dev)))
         errs[mode] = (float(((y.detach().cpu().double() - yr.detach()).abs() / mag_y).max()),
                       float(((xg.grad.cpu().double() - xr.grad).abs() / mag_dx).max()))
     conv.set_mode("split")
     print(errs)
     for i, what in enumerate(("y", "dx")):
-        assert errs["split"][i] < 1.5 * errs["exact"][i] + 1e-7, (what, errs)
-        assert errs["split"][i] < 5e-6, (what, errs)                       # both are a few fp32 roundings of sum |a*b| (K up to 2304)
+        for mode in ("h16", "split"):
+            assert errs[mode][i] < 1.5 * errs["exact"][i] + 1e-7, (mode, what, errs)
+            assert errs[mode][i] < 5e-6, (mode, what, errs)                # all are a few fp32 roundings of sum |a*b| (K up to 2304)
+
+
+@pytest.mark.parametrize("xs,ws,dys", [(1e-30, 1.0, 1e30), (1e30, 1e-6, 1e-30), (1.0, 1e-30, 1.0), (3e4, 50.0, 1e-9)])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(32, 64, 32, 32), (16, 16, 64, 64)])
+def test_fp16_pieces_hold_any_fp32_range(xs, ws, dys, Cin, Cout, H, W, conv_mode):
+    """The two-piece fp16 form scales every operand by a power of two taken from its bound: tensors of any fp32 magnitude
+    (1e-30 ... 1e30, far outside fp16's 6e-8 ... 65504), a bound that is 1000x too large, and an all-zero operand give the
+    accuracy of the fp32 kernels -- relative to sum |a b|, against float64."""
+    if conv_mode != "h16":
+        pytest.skip("h16 only")
+    from uaps_amd import conv
+    g = torch.Generator().manual_seed(Cin + H)
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, Cin, H, W, generator=g) * torch.exp(torch.randn(2, Cin, H, W, generator=g)) * xs
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin) * ws
+    dy = torch.randn(2, Cout, H, W, generator=g) * torch.exp(torch.randn(2, Cout, H, W, generator=g)) * dys
+    for slack in (1.0, 1000.0):
+        conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, None
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        y = conv.conv2d(_b(xg, slack), wg)
+        y.backward(_b(dy.to(dev), slack))
+        names, conv.KERNEL_EVENTS = set(conv.KERNEL_EVENTS), None
+        assert any(n.startswith("conv_h32") or n.startswith("conv_hfwd") for n in names) and any(n.startswith("conv_hwrw") for n in names), names
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        yr = F.conv2d(xr, wr, None, padding=1)
+        yr.backward(dy.double())
+        mag_y = F.conv2d(x.double().abs(), w.double().abs(), None, padding=1)
+        mag_dx = torch.nn.grad.conv2d_input(x.shape, w.double().abs(), dy.double().abs(), padding=1)
+        mag_dw = torch.nn.grad.conv2d_weight(x.double().abs(), w.shape, dy.double().abs(), padding=1)
+        for got, ref, mag, what in ((y.detach(), yr.detach(), mag_y, "y"), (xg.grad, xr.grad, mag_dx, "dx"), (wg.grad, wr.grad, mag_dw, "dw")):
+            assert torch.isfinite(got).all(), what
+            err = float(((got.cpu().double() - ref).abs() / mag).max())
+            assert err < 5e-6, (what, slack, err)
+    # an all-zero operand (bound 0: no scaling) and a zero gradient
+    xg, wg = torch.zeros(2, Cin, H, W, device=dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = conv.conv2d(_b(xg), wg)
+    y.backward(_b(torch.zeros_like(y)))
+    assert float(y.abs().max()) == 0.0 and float(xg.grad.abs().max()) == 0.0 and float(wg.grad.abs().max()) == 0.0
+
+
+def test_conv_without_bounds_runs_the_bf16_form_in_h16_mode(conv_mode):
+    if conv_mode != "h16":
+        pytest.skip("h16 only")
+    from uaps_amd import conv
+    dev = torch.device("cuda:0")
+    x, w = _mk((2, 32, 32, 32), 5).to(dev).requires_grad_(True), (_mk((32, 32, 3, 3), 6) / 17).to(dev).requires_grad_(True)
+    conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, None
+    y = conv.conv2d(x, w)
+    y.backward(torch.ones_like(y))
+    names, conv.KERNEL_EVENTS = set(conv.KERNEL_EVENTS), None
+    assert names and all(n.startswith("conv_s") for n in names), names

@@ -76,6 +76,8 @@ SIGNATURES = {
     "uaps_conv_wrw_variant": (C.c_int, [C.c_int] * 7 + [C.c_char_p, C.c_size_t]),
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
     "uaps_set_step_state": (C.c_int, [_PTR]),
+    "uaps_next_call_hints": (C.c_int, [_PTR]),
+    "uaps_bn_param_bounds": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, _PTR]),
     "uaps_get_step_state": (C.c_void_p, []),
     "uaps_convs_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "uaps_convs_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
@@ -141,6 +143,22 @@ def lib() -> C.CDLL:
                 fn.restype, fn.argtypes = res, args
             _lib = l
     return _lib
+
+
+class CallHints(C.Structure):
+    """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
+    _fields_ = [("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p)]
+
+
+def hints(bounds=(), out_amax=None) -> None:
+    """bounds: up to three (1-element device tensor, host factor) pairs or None; out_amax: a zeroed 1-element device tensor."""
+    h = CallHints()
+    for i, b in enumerate(bounds):
+        if b is not None:
+            h.bound[i], h.mul[i] = b[0].data_ptr(), float(b[1])
+    if out_amax is not None:
+        h.out_amax = out_amax.data_ptr()
+    check(lib().uaps_next_call_hints(C.byref(h)), "uaps_next_call_hints")
 
 
 def check(rc: int, what: str) -> None:

@@ -1,0 +1,101 @@
+"""Magnitude bounds of the tensors that feed the convolutions.
+
+The fastest convolution kernels (conv mode 2, csrc/conv_split.hpp) compute an fp32 convolution from two fp16 pieces per
+operand; fp16's narrow exponent needs every tensor operand scaled by a power of two into range, and the scale comes from an
+upper bound of the tensor's magnitude held in DEVICE memory (the host never reads it).  A bound travels with a tensor as the
+Python attribute `_uaps_bound = (scalar, factor)`: |t| <= scalar[0] * factor.  Three sources:
+
+  * train-mode BatchNorm outputs: |gamma * x_hat + beta| <= sqrt(n) * max_c(|gamma_c| + |beta_c|) (uaps_bn_param_bounds, one
+    launch per optimizer step for all layers of a model; `refresh`), passed through LeakyReLU, dropout (x 1 / (1 - p)), max-pool,
+    the feature perturbations (x 1.3, x 2, x 1) and bilinear up-sampling unchanged or with their static factor;
+  * kernels that produce gradients (BatchNorm backward, the loss backward) and the decoder's up-sampling raise a zeroed
+    device scalar to max|output| (uaps_call_hints::out_amax);
+  * anything else has no bound, and the convolution runs in the exact three-piece bf16 form instead -- correctness never
+    depends on a bound being present, only on a present bound being true.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+ATTR = "_uaps_bound"
+Bound = Tuple[torch.Tensor, float]
+
+_pool = {}          # device index -> [chunk tensor, next free slot]
+_CHUNK = 256
+
+
+def get(t: Optional[torch.Tensor]) -> Optional[Bound]:
+    return getattr(t, ATTR, None) if t is not None else None
+
+
+def put(t: torch.Tensor, scalar: Optional[torch.Tensor], factor: float = 1.0) -> torch.Tensor:
+    if scalar is not None:
+        setattr(t, ATTR, (scalar, float(factor)))
+    return t
+
+
+def carry(src: torch.Tensor, dst: torch.Tensor, factor: float = 1.0) -> torch.Tensor:
+    """dst is an elementwise contraction of src times at most `factor` (a mask, a max-pool, an interpolation ...)."""
+    b = get(src)
+    if b is not None:
+        setattr(dst, ATTR, (b[0], b[1] * float(factor)))
+    return dst
+
+
+def new_amax(dev: torch.device) -> torch.Tensor:
+    """A zeroed device scalar for uaps_call_hints::out_amax: a view into a chunk of zeros (one fill launch per 256 scalars)."""
+    ent = _pool.get(dev.index)
+    if ent is None or ent[1] >= _CHUNK:
+        ent = _pool[dev.index] = [torch.zeros(_CHUNK, dtype=torch.float32, device=dev), 0]
+    s = ent[0][ent[1]:ent[1] + 1]
+    ent[1] += 1
+    return s
+
+
+def reset_pool() -> None:
+    """Forget the current chunks: the next scalar comes from a fresh one (a graph capture calls this first, so that the zero
+    fill of every scalar it hands to the captured kernels is part of the graph)."""
+    _pool.clear()
+
+
+def enabled() -> bool:
+    from . import conv
+    return conv.get_mode() == "h16"
+
+
+# ---- BatchNorm parameter bounds, refreshed once per optimizer step -------------------------------------------------------------
+
+def refresh(bns: List[torch.nn.BatchNorm2d]) -> None:
+    """max_c(|gamma_c| + |beta_c|) of every layer in `bns` by one launch; each layer keeps a view of its scalar."""
+    from . import conv
+    if not bns or not enabled():
+        return
+    gen = conv._generation
+    if getattr(bns[0], "_uaps_G_gen", None) == gen and getattr(bns[0], "_uaps_G", None) is not None \
+            and bns[0]._uaps_G.device == bns[0].weight.device:
+        return
+    dev = bns[0].weight.device
+    n = len(bns)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+    with _lib.device_guard(dev):
+        rc = _lib.lib().uaps_bn_param_bounds(arr([m.weight for m in bns]), arr([m.bias for m in bns]),
+                                             (C.c_int * n)(*[m.num_features for m in bns]), n, out.data_ptr(), _lib.current_stream(dev))
+    _lib.check(rc, "uaps_bn_param_bounds")
+    for i, m in enumerate(bns):
+        m._uaps_G, m._uaps_G_gen = out[i:i + 1], gen
+
+
+def bn_output_bound(bn: torch.nn.BatchNorm2d, n_per_channel: int, factor: float = 1.0) -> Optional[Bound]:
+    """Bound of leaky_relu(batch_norm_train(.)) (x factor) of this layer, if its scalar is current."""
+    from . import conv
+    g = getattr(bn, "_uaps_G", None)
+    if g is None or getattr(bn, "_uaps_G_gen", None) != conv._generation:
+        return None
+    return (g, math.sqrt(max(1, n_per_channel)) * float(factor))

@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
-from . import _graddest, _lib
+from . import _graddest, _lib, bounds
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 # packed weights per parameter: id(weight) -> (weakref, version, generation, wf, wb)
@@ -67,10 +67,12 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
 
 
 class _timed:
-    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg):
+    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False):
         self.on = False
         if KERNEL_EVENTS is not None:
             self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg)
+            if h16:                   # every tensor operand carried a bound: the fp16 two-piece instantiation of the same plan ran
+                self.name = self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
             self.on = EVENT_FILTER is None or self.name in EVENT_FILTER
             self.flops = 2.0 * B * H * W * Cin * Cout * ks * ks
 
@@ -88,16 +90,18 @@ class _timed:
 
 
 def set_mode(mode) -> None:
-    """Arithmetic of the convolution kernels: 'split' / 1 (default) = exact three-way bf16 split of both fp32 operands on the
-    bf16 matrix pipe (csrc/conv_split.hpp, fp32-chain accuracy at 2.67x the fp32 matrix rate), 'exact' / 0 = the fp32 matrix
-    instruction everywhere.  Process-wide; also UAPS_CONV_MODE=0/1 in the environment."""
-    m = {"split": 1, "exact": 0, "f32": 0}.get(mode, mode)
+    """Arithmetic of the convolution kernels: 'h16' / 2 (default) = two fp16 pieces per power-of-two-scaled operand where the
+    operands' magnitude bounds are known (uaps_amd/bounds.py; 22 significant bits, fp32 accumulation), else as 'split';
+    'split' / 1 = exact three-way bf16 split of both fp32 operands on the bf16 matrix pipe (csrc/conv_split.hpp, fp32-chain
+    accuracy at 2.67x the fp32 matrix rate); 'exact' / 0 = the fp32 matrix instruction everywhere.  Process-wide; also
+    UAPS_CONV_MODE=0/1/2 in the environment."""
+    m = {"h16": 2, "split": 1, "bf16": 1, "exact": 0, "f32": 0}.get(mode, mode)
     _lib.check(_lib.lib().uaps_conv_set_mode(int(m)), "uaps_conv_set_mode")
     _variant_cache.clear()
 
 
 def get_mode() -> str:
-    return "split" if _lib.lib().uaps_conv_get_mode() == 1 else "exact"
+    return {2: "h16", 1: "split"}.get(_lib.lib().uaps_conv_get_mode(), "exact")
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
@@ -202,8 +206,12 @@ def pack_all(weights) -> None:
         _packed[id(wt)] = (weakref.ref(wt), wt._version, _generation, wf, wb)
 
 
+def _h16(*bs) -> bool:
+    return all(b is not None for b in bs) and get_mode() == "h16"
+
+
 def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ks: int, cfg: int = 0,
-                 want_stats: bool = False):
+                 want_stats: bool = False, xb=None):
     """y = conv(x); with want_stats also the per-tile (sum, sum of squares) of y as float2 [Cout][B][parts_per_image]
     (the first pass of the BatchNorm that follows), returned as (y, stats, parts_per_image)."""
     B, Cin, H, W = x.shape
@@ -213,7 +221,9 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     if want_stats:
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
-    with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg):
+    with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb)):
+        if xb is not None:
+            _lib.hints((xb,))
         if want_stats:
             rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
                                        _lib.current_stream(x.device))
@@ -224,17 +234,20 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     return (y, stats, ppi) if want_stats else y
 
 
-def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0):
+def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0, dyb=None):
     B, Cout, H, W = dy.shape
     dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
-    with _lib.device_guard(dy.device), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg):
+    with _lib.device_guard(dy.device), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, _h16(dyb)):
+        if dyb is not None:
+            _lib.hints((dyb,))
         rc = _lib.lib().uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
                                            _lib.current_stream(dy.device))
     _lib.check(rc, "uaps_conv_bwd_data")
     return dx
 
 
-def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None):
+def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None,
+                        dyb=None, xb=None):
     """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest)."""
     B, Cout, H, W = dy.shape
     Cin = x.shape[1]
@@ -247,7 +260,9 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
     with _lib.device_guard(dev):
         st = _lib.current_stream(dev)
-        with _timed("wrw", B, Cin, Cout, H, W, ks, cfg):
+        with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, _h16(dyb, xb)):
+            if dyb is not None and xb is not None:
+                _lib.hints((dyb, xb))
             rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
                                                 ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "uaps_conv_bwd_weight_partial")
@@ -280,11 +295,12 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, wb)
         ctx.meta = (Cin, Cout, ks, bias is not None, cfg)
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
+        ctx.xb = xb = bounds.get(x)
         if want_stats:
-            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True)
+            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True, xb=xb)
             ctx.mark_non_differentiable(stats)
             return y, stats
-        return conv_fwd_raw(x, wf, bias, Cout, ks, cfg)
+        return conv_fwd_raw(x, wf, bias, Cout, ks, cfg, xb=xb)
 
     @staticmethod
     def backward(ctx, dy, *_unused):
@@ -292,11 +308,12 @@ class _Conv2d(torch.autograd.Function):
             return None, None, None, None, None
         x, wb = ctx.saved_tensors
         Cin, Cout, ks, has_bias, cfg = ctx.meta
+        dyb = bounds.get(dy)
         dy = dy.contiguous()
-        dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg) if ctx.needs_input_grad[0] else None
+        dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys)
+            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb)
         return dx, dw, db, None, None
 
 
@@ -334,7 +351,11 @@ class _Conv2dCat(torch.autograd.Function):
         stats = None
         if want_stats:
             stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
-        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0):
+        b1, b2 = bounds.get(x1), bounds.get(x2)
+        ctx.xb = (b1, b2)
+        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0, _h16(b1, b2)):
+            if b1 is not None and b2 is not None:
+                _lib.hints((b1, b2))
             rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
                                               bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                               stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, 0, _lib.current_stream(dev))
@@ -353,6 +374,8 @@ class _Conv2dCat(torch.autograd.Function):
             return None, None, None, None, None
         x1, x2, wb = ctx.saved_tensors
         C1, C2, Cout, ks, has_bias = ctx.meta
+        dyb = bounds.get(dy)
+        b1, b2 = ctx.xb
         dy = dy.contiguous()
         B, _, H, W = dy.shape
         dev = dy.device
@@ -363,7 +386,9 @@ class _Conv2dCat(torch.autograd.Function):
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx1 = torch.empty_like(x1)
                 dx2 = torch.empty_like(x2)
-                with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, 0):
+                with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, 0, _h16(dyb)):
+                    if dyb is not None:
+                        _lib.hints((dyb,))
                     rc = L.uaps_conv_bwd_data_cat(dy.data_ptr(), wb.data_ptr(), dx1.data_ptr(), C1, dx2.data_ptr(), C2, B, Cout, H, W,
                                                   ks, 0, st)
                 _lib.check(rc, "uaps_conv_bwd_data_cat")
@@ -374,7 +399,9 @@ class _Conv2dCat(torch.autograd.Function):
                 ws = _workspace(dev, n.value)
                 dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
                 db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
-                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0):
+                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0, _h16(dyb, b1, b2)):
+                    if dyb is not None and b1 is not None and b2 is not None:
+                        _lib.hints((dyb, b1, b2))
                     rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
                                                             H, W, ks, 0, ws.data_ptr(), ws.numel(), st)
                 _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")

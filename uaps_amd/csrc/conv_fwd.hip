@@ -5,20 +5,22 @@
 #include <stdlib.h>
 #include "conv_kernels.hpp"
 #include "conv_split.hpp"
+#include "hints.hpp"
 using namespace uaps;
 
-// 0 = exact fp32 matrix instructions (v_mfma_f32_16x16x4_f32), 1 = exact 3-way bf16 split on the bf16 matrix pipe
-// (conv_split.hpp; the default).  Initialised from UAPS_CONV_MODE, switchable with uaps_conv_set_mode.
+// 0 = exact fp32 matrix instructions (v_mfma_f32_16x16x4_f32), 1 = exact 3-way bf16 split on the bf16 matrix pipe,
+// 2 (default) = 1, and the two-piece fp16 split for operands with a known magnitude bound (conv_split.hpp).
+// Initialised from UAPS_CONV_MODE, switchable with uaps_conv_set_mode.
 static int g_conv_mode = -1;
 static int conv_mode() {
     if (g_conv_mode < 0) {
         const char* e = getenv("UAPS_CONV_MODE");
-        g_conv_mode = (e && (e[0] == '0' || e[0] == 'e' || e[0] == 'f')) ? 0 : 1;      // "0" / "exact" / "f32"
-    }
+        g_conv_mode = !e ? 2 : ((e[0] == '0' || e[0] == 'e' || e[0] == 'f') ? 0 : ((e[0] == '1' || e[0] == 'b' || e[0] == 's') ? 1 : 2));
+    }                                                                // "0" / "exact" / "f32";  "1" / "bf16" / "split";  "2" / "h16"
     return g_conv_mode;
 }
 extern "C" int uaps_conv_set_mode(int mode) {
-    if (mode != 0 && mode != 1) return UAPS_EINVAL;
+    if (mode != 0 && mode != 1 && mode != 2) return UAPS_EINVAL;
     g_conv_mode = mode;
     return UAPS_OK;
 }
@@ -78,6 +80,11 @@ int launch_sfwd(ConvFwdArgs a, hipStream_t s) {
     a.nblk = a.CoutP / BN;
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.wscale) {                                   // the fp16 two-piece form (plan: h16)
+        if (a.xf) hipLaunchKernelGGL((conv_hfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else hipLaunchKernelGGL((conv_hfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (a.xf) hipLaunchKernelGGL((conv_sfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     else hipLaunchKernelGGL((conv_sfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
@@ -99,6 +106,11 @@ int launch_s32(ConvFwdArgs a, hipStream_t s) {
     a.nblk = a.CoutP / BN;
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.wscale) {                                   // the fp16 two-piece form (plan: h16)
+        if (a.xf) hipLaunchKernelGGL((conv_h32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else hipLaunchKernelGGL((conv_h32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (a.xf) hipLaunchKernelGGL((conv_s32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     else hipLaunchKernelGGL((conv_s32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
@@ -132,7 +144,7 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // measured (tools/bench_modes.py, B = 32): the split forms win 1.2-1.7x on every 3x3 layer with more than 8 contraction
     // channels and lose on 1x1 convolutions (HBM-bound, the split only adds staging work) and on the <= 8-channel layers
     // (a chunk of 8 channels fills 9 of 12 k-groups); cfg bits 29-30 != 0 force a split form regardless
-    p->split = conv_mode() == 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || ((cfg >> 29) & 3));
+    p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || ((cfg >> 29) & 3));
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
     p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);
     p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 512) ? 32 : 16;
@@ -153,6 +165,7 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
 int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
                  int cfg, hipStream_t s, float2* stats = nullptr, const float* x2 = nullptr, int Csplit = -1,
                  float* y2 = nullptr, int Osplit = -1, const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
+    const uaps_call_hints hints = take_hints();
     if (!x || !wp || !y) return UAPS_EINVAL;
     if (xf && (x2 || groups < 1 || B % groups || (uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (xf && !(xf_slope >= 0.f && xf_slope <= 1.f)) return UAPS_ERANGE;      // leaky_relu is evaluated as max(z, slope * z)
@@ -174,6 +187,14 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
         a.wp = wp + (size_t)ks * ks * p.CinP * p.CoutP;
         a.CinP = split_cgroups(Cin);
+        // mode 2 and every tensor operand bounded: the two-piece fp16 form; its weights follow the bf16 pieces behind a header
+        if (conv_mode() == 2 && hints.bound[0] && (!x2 || Csplit >= Cin || hints.bound[1])) {
+            const size_t piece = (size_t)ks * ks * a.CinP * p.CoutP * 4;
+            a.wscale = a.wp + 3 * piece + 16;         // {s, 1 / s, max|w|} behind the 16 partial maxima
+            a.wp = a.wp + 3 * piece + kH16Header;
+            a.in_bound = hints.bound[0]; a.in_mul = hints.mul[0];
+            if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[1]; a.in2_mul = hints.mul[1]; }
+        }
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
         return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);
@@ -195,12 +216,15 @@ static PackDesc make_pack_desc(const float* w, float* wf, float* wb, int Cout, i
 }
 
 // Sizes (in floats) of the two packed buffers of a convolution: each holds the exact fp32 layout followed by the
-// three-piece bf16 layout of conv_split.hpp (3 * taps * groups * channels * 16 bytes).
+// three-piece bf16 layout of conv_split.hpp (3 * taps * groups * channels * 16 bytes), a 16-byte header and the
+// two-piece fp16 layout (2 * taps * groups * channels * 16 bytes).
 extern "C" int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats, size_t* bwd_floats) {
     if (Cout <= 0 || Cin <= 0 || (ks != 1 && ks != 3)) return UAPS_EINVAL;
     const size_t taps = (size_t)ks * ks;
-    if (fwd_floats) *fwd_floats = taps * kdim_pad(Cin, ks) * ndim_pad(Cout) + 3 * taps * split_cgroups(Cin) * ndim_pad(Cout) * 4;
-    if (bwd_floats) *bwd_floats = taps * kdim_pad(Cout, ks) * ndim_pad(Cin) + 3 * taps * split_cgroups(Cout) * ndim_pad(Cin) * 4;
+    const PackDesc q = make_pack_desc(nullptr, nullptr, nullptr, Cout, Cin, ks);
+    (void)taps;
+    if (fwd_floats) *fwd_floats = (size_t)pack_fwd_floats(q);
+    if (bwd_floats) *bwd_floats = (size_t)pack_bwd_floats(q);
     return UAPS_OK;
 }
 
@@ -210,6 +234,7 @@ extern "C" int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks,
     const PackDesc q = make_pack_desc(w, wf, wb, Cout, Cin, ks);
     const long n = conv_pack_elems(q);
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(conv_weight_scale_kernel, dim3(kH16Parts), dim3(256), 0, (hipStream_t)stream, q);
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q);
     return (int)hipGetLastError();
 }
@@ -231,6 +256,7 @@ extern "C" int uaps_conv_pack_weights_batch(const float* const* w, float* const*
             if (e > most) most = e;
         }
         const int bx = (int)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);
+        hipLaunchKernelGGL(conv_weight_scale_batch_kernel, dim3(kH16Parts, m), dim3(256), 0, (hipStream_t)stream, pb);
         hipLaunchKernelGGL(conv_pack_weights_batch_kernel, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, pb);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;

@@ -138,6 +138,10 @@ struct ConvFwdArgs {
     const float2* xf;
     float xf_slope;
     int xf_Bg;
+    // fp16-split kernels only (conv_split.hpp): device scalars with an upper bound of |in| (after the XF transform) and of |in2|,
+    // each times a host factor, and the packed weights' header {scale, 1 / scale}
+    const float* in_bound; const float* in2_bound; const float* wscale;
+    float in_mul, in2_mul;
 };
 
 template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL, bool XF>
@@ -383,6 +387,10 @@ struct ConvWrwArgs {
     int B, Cin, Cout, H, W;
     int CoutS, CinS;
     int tiles_x, tiles_y, ncob, ncib, nsplit;
+    // fp16-split kernels only: bounds of |dout| and |in| (|in2|) as in ConvFwdArgs
+    const float* dy_bound; const float* in_bound; const float* in2_bound;
+    float dy_mul, in_mul, in2_mul;
+    int col_major;      // split kernels: consecutive tiles of a workgroup run down a 32-pixel column strip (halo rows re-read from L2)
     // conv_wrw_bn_kernel only: `in` is the raw conv output y in front of BatchNorm(train) + LeakyReLU; the activation
     // is recomputed while staging (see ConvFwdArgs::xf)
     const float2* xf;

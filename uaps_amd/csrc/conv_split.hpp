@@ -35,6 +35,30 @@ __device__ __forceinline__ void conv_split3(float a, float b, unsigned& p0, unsi
     p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{sa, sb}, bf16x2));
 }
 
+// fp16 form: (a, b) -> two dwords of packed fp16 pairs with a = a0 + a1 up to 2^-23 |a| (11 + 11 significant bits).  The caller
+// scales the operands into fp16's range first.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void conv_split2h(float a, float b, unsigned& p0, unsigned& p1) {
+    const f16x2 h0 = __builtin_convertvector(f32x2{a, b}, f16x2);
+    const float ra = a - (float)h0[0], rb = b - (float)h0[1];
+    const f16x2 h1 = __builtin_convertvector(f32x2{ra, rb}, f16x2);
+    p0 = __builtin_bit_cast(unsigned, h0); p1 = __builtin_bit_cast(unsigned, h1);
+}
+
+// Power-of-two scale s (and 1 / s) that maps |x| <= bound to |s x| < 2^15, the upper end of fp16's range (max 65504): the
+// two-piece split then keeps 22 significant bits of every element down to 2^-18 of the bound and an absolute error of
+// 2^-40 bound below that.  bound = 0, subnormal or not finite: no scaling.  The scale exponent is clamped to +-100 so that
+// s, 1 / s and the product of two inverse scales stay normal numbers.
+__device__ __forceinline__ f32x2 h16_scale(float bound) {
+    const int e = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu);      // 2^(e - 127) <= bound < 2^(e - 126)
+    if (e == 0 || e == 255) return f32x2{1.f, 1.f};
+    int se = 127 + 14 - (e - 127);
+    se = se < 27 ? 27 : (se > 227 ? 227 : se);
+    return f32x2{__builtin_bit_cast(float, (unsigned)se << 23), __builtin_bit_cast(float, (unsigned)(254 - se) << 23)};
+}
+__device__ __forceinline__ float bound_of(const float* p, float mul) { return p ? p[0] * mul : 0.f; }
+
 // number of 8-channel groups of the packed split weights for C contraction channels: padded to a multiple of 4 groups so
 // that any channel chunk (8, 16 or 32 channels) stays inside one tap's rows and reads zeros past the last channel
 __host__ __device__ constexpr int split_cgroups(int C) { return ((C + 7) / 8 + 3) / 4 * 4; }
@@ -59,20 +83,21 @@ template <int KS, int TH, int TW> struct SplitGeom {
 };
 
 // CK = channels per chunk (8, 16, 32); BN = output channels per workgroup (16, 32); XF as in conv_fwd_body
-template <int KS, int TH, int TW, int BN, int CK, bool XF>
+template <int KS, int TH, int TW, int BN, int CK, bool XF, bool H16 = false>
 __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
     using G = SplitGeom<KS, TH, TW>;
+    constexpr int NP = H16 ? 2 : 3;                   // pieces per operand: three bf16 (six products) or two fp16 (three products)
     constexpr int TAPS = KS * KS, NCG = CK / 8, NQ = TAPS * NCG, NSTEP = (NQ + 3) / 4, NQP = NSTEP * 4;
     constexpr int IW = G::IW, PLANE = G::PLANE, XS = G::XOFF - G::PAD;
     constexpr int MT = TH * TW / 16, MW = MT / 4, NW = BN / 16, XB = TW / 16;
     constexpr int NUNITS = NCG * G::NUNITS_PER_CG;
-    constexpr int NWU = 3 * NQP * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
+    constexpr int NWU = NP * NQP * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
     static_assert(NUNITS <= kConvThreads, "one staging unit (4 pixels x 8 channels) per thread");
     static_assert(MT % 4 == 0 && BN % 16 == 0, "tile shape");
-    static_assert(3 * NCG * PLANE * 16 >= 16 * BN * 2 * 4, "the statistics epilogue reuses sIn");
+    static_assert(NP * NCG * PLANE * 16 >= 16 * BN * 2 * 4, "the statistics epilogue reuses sIn");
 
-    __shared__ __attribute__((aligned(16))) u32x4 sIn[3 * NCG * PLANE];
-    __shared__ __attribute__((aligned(16))) u32x4 sW[3 * NQP * BN];
+    __shared__ __attribute__((aligned(16))) u32x4 sIn[NP * NCG * PLANE];
+    __shared__ __attribute__((aligned(16))) u32x4 sW[NP * NQP * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -87,6 +112,12 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
     const int y0 = ty * TH, x0 = tx * TW, co0 = nb * BN;
     const int HW = a.H * a.W;
     const uint32_t HW4 = (uint32_t)HW * 4u;
+
+    float in_scale = 1.f, out_scale_a = 1.f, out_scale_w = 1.f;
+    if constexpr (H16) {
+        const f32x2 sc = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
+        in_scale = sc.x; out_scale_a = sc.y; out_scale_w = a.wscale[1];
+    }
 
     // ---- staging plan: this thread's unit = 4 consecutive pixels x the 8 channels of one channel group ----
     const bool has_unit = tid < NUNITS;
@@ -109,7 +140,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
     }
     const float* in_b = a.in + (size_t)b * a.Csplit * HW;
     const float* in2_b = a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW;
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(3 * TAPS) * CGP * a.CoutP * 16u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(NP * TAPS) * CGP * a.CoutP * 16u);
     const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u)
                                             : make_rsrc(a.wp, 0);
 
@@ -137,7 +168,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
     };
     // split of the fetched unit into packed pieces pk[piece][pixel] (16 bytes = 8 channels each); one call handles the channel
     // pair c2 of pixel p.  XF: leaky_relu(fma(y, scale, shift)) first; leaky_relu(z) = max(z, slope * z)
-    u32x4 pk[3][4];
+    u32x4 pk[NP][4];
     auto split_pair = [&](int idx) {
         const int p = idx / 4, c2 = idx % 4;
         float v0 = rin[2 * c2][p], v1 = rin[2 * c2 + 1][p];
@@ -145,17 +176,22 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
             const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
             v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
         }
-        unsigned q0, q1, q2;
-        conv_split3(v0, v1, q0, q1, q2);
-        pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+        if constexpr (H16) {
+            unsigned q0, q1;
+            conv_split2h(v0 * in_scale, v1 * in_scale, q0, q1);
+            pk[0][p][c2] = q0; pk[1][p][c2] = q1;
+        } else {
+            unsigned q0, q1, q2;
+            conv_split3(v0, v1, q0, q1, q2);
+            pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+        }
     };
     auto store_chunk = [&]() {
         if (has_unit) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                sIn[uloff + p] = pk[0][p];
-                sIn[NCG * PLANE + uloff + p] = pk[1][p];
-                sIn[2 * NCG * PLANE + uloff + p] = pk[2][p];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) sIn[q * NCG * PLANE + uloff + p] = pk[q][p];
             }
         }
 #pragma unroll
@@ -199,17 +235,17 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) load_chunk((ch + 1) * CK);
-        bf16x8 af[2][3], bfr[2][NW][3];
-        auto read_a = [&](int u, bf16x8 (&dst)[3]) {
+        bf16x8 af[2][NP], bfr[2][NW][NP];
+        auto read_a = [&](int u, bf16x8 (&dst)[NP]) {
             const int s = u / MW, m = u % MW;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * NCG * PLANE + abase[m] + astep[s]]);
+            for (int p = 0; p < NP; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * NCG * PLANE + abase[m] + astep[s]]);
         };
-        auto read_b = [&](int s, bf16x8 (&dst)[NW][3]) {
+        auto read_b = [&](int s, bf16x8 (&dst)[NW][NP]) {
 #pragma unroll
             for (int n = 0; n < NW; ++n)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 4 * s) * BN + boff + n * 16]);
+                for (int p = 0; p < NP; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 4 * s) * BN + boff + n * 16]);
         };
         read_b(0, bfr[0]);
         read_a(0, af[0]);
@@ -222,17 +258,24 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
 #pragma unroll
             for (int n = 0; n < NW; ++n) {           // smallest partial products first
                 f32x4 c = acc[m][n];
+                if constexpr (H16) {
+                    const auto H = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][1]), H(bfr[s & 1][n][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s & 1][n][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s & 1][n][0]), c, 0, 0, 0);
+                } else {
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], bfr[s & 1][n][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], bfr[s & 1][n][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], bfr[s & 1][n][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], bfr[s & 1][n][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], bfr[s & 1][n][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], bfr[s & 1][n][0], c, 0, 0, 0);
+                }
                 acc[m][n] = c;
             }
-            if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * NW, 0);                            // next unit's DS reads first ...
-            else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NW, 0);                                          // ... then this unit's MFMAs
+            if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, NP + NP * NW, 0);                          // next unit's DS reads first ...
+            else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (H16 ? 3 : 6) * NW, 0);                              // ... then this unit's MFMAs
             if constexpr (SPLIT_IN_LOOP) {           // unconditional (stale registers when no chunk follows): straight-line code
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -264,6 +307,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
             const int mt = wave * MW + m;
             const int gy = y0 + mt / XB, gx = x0 + (mt % XB) * 16 + kq * 4;
             f32x4 v = acc[m][n];
+            if constexpr (H16) { v *= out_scale_a; v *= out_scale_w; }      // exact: powers of two
             v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             const bool ok = co_ok && gy < a.H && gx < a.W;      // W % 4 == 0: the 4 pixels are all inside or all outside
             if (ok) {
@@ -299,6 +343,14 @@ template <int KS, int TH, int TW, int BN, int CK>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_sfwd_bn_kernel(ConvFwdArgs a) {
     conv_sfwd_body<KS, TH, TW, BN, CK, true>(a);
 }
+template <int KS, int TH, int TW, int BN, int CK>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_hfwd_kernel(ConvFwdArgs a) {
+    conv_sfwd_body<KS, TH, TW, BN, CK, false, true>(a);
+}
+template <int KS, int TH, int TW, int BN, int CK>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_hfwd_bn_kernel(ConvFwdArgs a) {
+    conv_sfwd_body<KS, TH, TW, BN, CK, true, true>(a);
+}
 
 // -------------------------------------------------------------------------------------------------
 // 3x3 forward / input gradient for >= 32 output channels on v_mfma_f32_32x32x16_bf16 (same split arithmetic).
@@ -313,17 +365,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_sfwd_bn_kernel(ConvFwdAr
 // -------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BN, bool XF>
+template <int BN, bool XF, bool H16 = false>
 __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
+    constexpr int NP = H16 ? 2 : 3;                   // pieces per operand: three bf16 (six products) or two fp16 (three products)
     constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 8, PLANE = IH * IW, XS = 3;     // rows start 4 floats left of the tile
     constexpr int NQ = 9, NKS = 5, NQP = 2 * NKS;
     constexpr int NT = BN / 32;                       // 32-channel N tiles per wave (every wave covers all BN channels)
     constexpr int NHU = IH * (IW / 2);                // staging half-units: 2 consecutive pixels x 8 channels
-    constexpr int NWU = 3 * NQ * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
+    constexpr int NWU = NP * NQ * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
     static_assert(NHU <= kConvThreads, "one half-unit per thread");
 
-    __shared__ __attribute__((aligned(16))) u32x4 sIn[3 * PLANE];
-    __shared__ __attribute__((aligned(16))) u32x4 sW[3 * NQP * BN];
+    __shared__ __attribute__((aligned(16))) u32x4 sIn[NP * PLANE];
+    __shared__ __attribute__((aligned(16))) u32x4 sW[NP * NQP * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -338,6 +391,12 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     const int y0 = ty * TH, x0 = tx * TW, co0 = nb * BN;
     const int HW = a.H * a.W;
     const uint32_t HW4 = (uint32_t)HW * 4u;
+
+    float in_scale = 1.f, out_scale_a = 1.f, out_scale_w = 1.f;
+    if constexpr (H16) {
+        const f32x2 sc = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
+        in_scale = sc.x; out_scale_a = sc.y; out_scale_w = a.wscale[1];
+    }
 
     // ---- staging plan ----
     const bool has_unit = tid < NHU;
@@ -357,18 +416,18 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         wloff[n] = e < NWU ? (piece * NQP + q) * BN + col : -1;
     }
     // the padded k-group (slot 9 of every piece) meets zero weights: written once
-    for (int e = tid; e < 3 * BN; e += kConvThreads) sW[((e / BN) * NQP + NQ) * BN + e % BN] = u32x4{0u, 0u, 0u, 0u};
+    for (int e = tid; e < NP * BN; e += kConvThreads) sW[((e / BN) * NQP + NQ) * BN + e % BN] = u32x4{0u, 0u, 0u, 0u};
 
     const float* in_b = a.in + (size_t)b * a.Csplit * HW;
     const float* in2_b = a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW;
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(3 * NQ) * CGP * a.CoutP * 16u);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(NP * NQ) * CGP * a.CoutP * 16u);
     const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u)
                                             : make_rsrc(a.wp, 0);
 
     f32x2 rin[8];
     u32x4 rw[NWT];
     f32x2 rxf[XF ? 8 : 1];
-    u32x4 pk[3][2];
+    u32x4 pk[NP][2];
 
     auto load_chunk = [&](int ci0) {
         const bool second = ci0 >= a.Csplit;        // the chunk lies in one source (Csplit % 8 == 0)
@@ -396,17 +455,22 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
             v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
         }
-        unsigned q0, q1, q2;
-        conv_split3(v0, v1, q0, q1, q2);
-        pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+        if constexpr (H16) {
+            unsigned q0, q1;
+            conv_split2h(v0 * in_scale, v1 * in_scale, q0, q1);
+            pk[0][p][c2] = q0; pk[1][p][c2] = q1;
+        } else {
+            unsigned q0, q1, q2;
+            conv_split3(v0, v1, q0, q1, q2);
+            pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+        }
     };
     auto store_chunk = [&]() {
         if (has_unit) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                sIn[uloff + p] = pk[0][p];
-                sIn[PLANE + uloff + p] = pk[1][p];
-                sIn[2 * PLANE + uloff + p] = pk[2][p];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) sIn[q * PLANE + uloff + p] = pk[q][p];
             }
         }
 #pragma unroll
@@ -444,16 +508,16 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
         if (more) load_chunk((ch + 1) * 8);
-        bf16x8 af[2][3], bfr[2][NT][3];
-        auto read_a = [&](int u, bf16x8 (&dst)[3]) {
+        bf16x8 af[2][NP], bfr[2][NT][NP];
+        auto read_a = [&](int u, bf16x8 (&dst)[NP]) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * PLANE + abase[u % 2] + kstep[u / 2]]);
+            for (int p = 0; p < NP; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * PLANE + abase[u % 2] + kstep[u / 2]]);
         };
-        auto read_b = [&](int ks, bf16x8 (&dst)[NT][3]) {
+        auto read_b = [&](int ks, bf16x8 (&dst)[NT][NP]) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 2 * ks) * BN + boff + n * 32]);
+                for (int p = 0; p < NP; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 2 * ks) * BN + boff + n * 32]);
         };
         read_b(0, bfr[0]);
         read_a(0, af[0]);
@@ -466,17 +530,24 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {           // smallest partial products first
                 f32x16 c = acc[m][n];
+                if constexpr (H16) {
+                    const auto H = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(H(af[u & 1][1]), H(bfr[ks & 1][n][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(H(af[u & 1][0]), H(bfr[ks & 1][n][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(H(af[u & 1][0]), H(bfr[ks & 1][n][0]), c, 0, 0, 0);
+                } else {
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][2], bfr[ks & 1][n][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][0], bfr[ks & 1][n][2], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][1], bfr[ks & 1][n][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][1], bfr[ks & 1][n][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][0], bfr[ks & 1][n][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u & 1][0], bfr[ks & 1][n][0], c, 0, 0, 0);
+                }
                 acc[m][n] = c;
             }
-            if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * NT, 0);
-            else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+            if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, NP + NP * NT, 0);
+            else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, (H16 ? 3 : 6) * NT, 0);
             if (u >= 2) split_pair(u - 2);            // the next chunk's 8 channel pairs, one per unit behind the first k-step
         }
         __syncthreads();
@@ -501,7 +572,9 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int gx = x0 + 8 * g + 4 * h;
-                f32x4 v = f32x4{acc[m][n][4 * g] + bv, acc[m][n][4 * g + 1] + bv, acc[m][n][4 * g + 2] + bv, acc[m][n][4 * g + 3] + bv};
+                f32x4 v = f32x4{acc[m][n][4 * g], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]};
+                if constexpr (H16) { v *= out_scale_a; v *= out_scale_w; }      // exact: powers of two
+                v += bv;
                 if (co_ok && gy < a.H && gx < a.W) {
                     *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
                     st_s[n] += (v.x + v.y) + (v.z + v.w);
@@ -532,14 +605,23 @@ template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_s32_kernel(ConvFwdArgs a) { conv_s32_body<BN, false>(a); }
 template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_s32_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true>(a); }
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_h32_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, true>(a); }
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_h32_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true, true>(a); }
 
 // -------------------------------------------------------------------------------------------------
 // Split weight packing: w [Cout][Cin][KS][KS] fp32 ->
 //   sf [piece][tap][CGP(Cin)][CoutP][8]     sf[p][t][g][co][j] = piece p of w[co][8g+j][t]            (forward)
 //   sb [piece][tap][CGP(Cout)][CinPn][8]    sb[p][T-1-t][g][ci][j] = piece p of w[8g+j][ci][t]       (input gradient)
-// zero padded; 16-byte units of 8 bf16.  One thread per (unit, pair of channels).
+// zero padded; 16-byte units of 8 bf16 (three pieces) and, behind a header of kH16Header floats (16 partial maxima of |w| written
+// by conv_weight_scale_kernel before the pack kernel runs, then {s, 1 / s, max|w|} with s = h16_scale(max|w|)), the same
+// layouts with two fp16 pieces of s * w.
+// One thread per (unit, pair of channels).
 // -------------------------------------------------------------------------------------------------
+constexpr int kH16Header = 32, kH16Parts = 16;      // floats in front of the fp16 pieces; [0, 16) partial maxima, [16] s, [17] 1 / s, [18] max|w|
 struct SplitPackDesc { const float* w; unsigned* sf; unsigned* sb; int Cout, Cin, taps, CGf, CoutP, CGb, CinPn; };
+template <bool H16>
 __device__ __forceinline__ void conv_pack_split_elem(const SplitPackDesc& q, long e) {
     // dword index space: forward part [tap][CGf][CoutP][4 dwords], then backward part [tap][CGb][CinPn][4]
     const long nf = (long)q.taps * q.CGf * q.CoutP * 4, nbk = (long)q.taps * q.CGb * q.CinPn * 4;
@@ -568,21 +650,46 @@ __device__ __forceinline__ void conv_pack_split_elem(const SplitPackDesc& q, lon
     } else {
         return;
     }
-    unsigned p0, p1, p2;
-    conv_split3(v0, v1, p0, p1, p2);
-    dst[idx] = p0; dst[piece_stride + idx] = p1; dst[2 * piece_stride + idx] = p2;
+    if constexpr (H16) {                          // dst points behind the header
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < kH16Parts; ++i) m = __builtin_fmaxf(m, __builtin_bit_cast(float, dst[i - kH16Header]));
+        const f32x2 s2 = h16_scale(m);
+        const float sc = s2[0], inv = s2[1];
+        if (e == 0 || e == nf) {                  // one thread per direction completes the header for the convolution kernels
+            float* hdr = reinterpret_cast<float*>(dst) - kH16Header;
+            hdr[16] = sc; hdr[17] = inv; hdr[18] = m;
+        }
+        unsigned p0, p1;
+        conv_split2h(v0 * sc, v1 * sc, p0, p1);
+        dst[idx] = p0; dst[piece_stride + idx] = p1;
+    } else {
+        unsigned p0, p1, p2;
+        conv_split3(v0, v1, p0, p1, p2);
+        dst[idx] = p0; dst[piece_stride + idx] = p1; dst[2 * piece_stride + idx] = p2;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
 // Weight packing, all layouts of one convolution by one kernel: w [Cout][Cin][KS][KS] (nn.Conv2d.weight) ->
 //   wf [tap][CinP][CoutP]            wf[t][ci][co] = w[co][ci][t]            (exact forward)
 //   wb [tap][CoutPk][CinPn]          wb[T-1-t][co][ci] = w[co][ci][t]        (exact input gradient)
-//   sf / sb                          the split layouts above; they FOLLOW wf / wb in the same buffers
+//   sf / sb, header + hf / hb        the split layouts above; they FOLLOW wf / wb in the same buffers
 // zero padded; wf / wb may be null (then nothing of that direction is written).
 // -------------------------------------------------------------------------------------------------
 struct PackDesc { const float* w; float* wf; float* wb; int Cout, Cin, taps, CinP, CoutP, CoutPk, CinPn, CGf, CGb; };
+// offsets (in floats / dwords) of the parts of the two buffers
+__host__ __device__ inline long pack_nf(const PackDesc& q) { return (long)q.taps * q.CinP * q.CoutP; }
+__host__ __device__ inline long pack_nbk(const PackDesc& q) { return (long)q.taps * q.CoutPk * q.CinPn; }
+__host__ __device__ inline long pack_nsf(const PackDesc& q) { return (long)q.taps * q.CGf * q.CoutP * 4; }      // dwords of ONE piece
+__host__ __device__ inline long pack_nsb(const PackDesc& q) { return (long)q.taps * q.CGb * q.CinPn * 4; }
+__host__ __device__ inline long pack_fwd_floats(const PackDesc& q) { return pack_nf(q) + 3 * pack_nsf(q) + kH16Header + 2 * pack_nsf(q); }
+__host__ __device__ inline long pack_bwd_floats(const PackDesc& q) { return pack_nbk(q) + 3 * pack_nsb(q) + kH16Header + 2 * pack_nsb(q); }
+__host__ __device__ inline long pack_h16_fwd_off(const PackDesc& q) { return pack_nf(q) + 3 * pack_nsf(q); }      // the header; the pieces follow it
+__host__ __device__ inline long pack_h16_bwd_off(const PackDesc& q) { return pack_nbk(q) + 3 * pack_nsb(q); }
+
 __device__ __forceinline__ void conv_pack_elem(const PackDesc& q, long e) {
-    const long nf = (long)q.taps * q.CinP * q.CoutP, nbk = (long)q.taps * q.CoutPk * q.CinPn;
+    const long nf = pack_nf(q), nbk = pack_nbk(q), ns = pack_nsf(q) + pack_nsb(q);
     if (e < nf) {
         if (!q.wf) return;
         const int co = (int)(e % q.CoutP); const long r = e / q.CoutP;
@@ -594,15 +701,39 @@ __device__ __forceinline__ void conv_pack_elem(const PackDesc& q, long e) {
         const int ci = (int)(f % q.CinPn); const long r = f / q.CinPn;
         const int co = (int)(r % q.CoutPk), t = (int)(r / q.CoutPk);
         q.wb[f] = (co < q.Cout && ci < q.Cin) ? q.w[((long)co * q.Cin + ci) * q.taps + (q.taps - 1 - t)] : 0.f;
-    } else {
+    } else if (e < nf + nbk + ns) {
         SplitPackDesc sp{q.w, q.wf ? reinterpret_cast<unsigned*>(q.wf + nf) : nullptr, q.wb ? reinterpret_cast<unsigned*>(q.wb + nbk) : nullptr,
                          q.Cout, q.Cin, q.taps, q.CGf, q.CoutP, q.CGb, q.CinPn};
-        conv_pack_split_elem(sp, e - nf - nbk);
+        conv_pack_split_elem<false>(sp, e - nf - nbk);
+    } else {
+        SplitPackDesc sp{q.w, q.wf ? reinterpret_cast<unsigned*>(q.wf + pack_h16_fwd_off(q) + kH16Header) : nullptr,
+                         q.wb ? reinterpret_cast<unsigned*>(q.wb + pack_h16_bwd_off(q) + kH16Header) : nullptr,
+                         q.Cout, q.Cin, q.taps, q.CGf, q.CoutP, q.CGb, q.CinPn};
+        conv_pack_split_elem<true>(sp, e - nf - nbk - ns);
     }
 }
 __host__ __device__ inline long conv_pack_elems(const PackDesc& q) {
-    return (long)q.taps * ((long)q.CinP * q.CoutP + (long)q.CoutPk * q.CinPn + 4L * q.CGf * q.CoutP + 4L * q.CGb * q.CinPn);
+    return pack_nf(q) + pack_nbk(q) + 2 * (pack_nsf(q) + pack_nsb(q));
 }
+// partial maxima of |w| -> header slots [0, kH16Parts) of both buffers' fp16 parts: kH16Parts workgroups per convolution, fixed order
+__device__ __forceinline__ void conv_weight_scale_block(const PackDesc& q, int part) {
+    __shared__ float red[256];
+    const long n = (long)q.Cout * q.Cin * q.taps;
+    float m = 0.f;
+    for (long i = (long)part * blockDim.x + threadIdx.x; i < n; i += (long)kH16Parts * blockDim.x)
+        m = __builtin_fmaxf(m, __builtin_fabsf(q.w[i]));                 // NaN weights: fmaxf drops them, the products stay NaN
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = __builtin_fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (q.wf) q.wf[pack_h16_fwd_off(q) + part] = red[0];
+        if (q.wb) q.wb[pack_h16_bwd_off(q) + part] = red[0];
+    }
+}
+static __global__ __launch_bounds__(256) void conv_weight_scale_kernel(PackDesc q) { conv_weight_scale_block(q, (int)blockIdx.x); }
 static __global__ void conv_pack_weights_kernel(PackDesc q) {
     const long n = conv_pack_elems(q);
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) conv_pack_elem(q, e);
@@ -611,6 +742,7 @@ static __global__ void conv_pack_weights_kernel(PackDesc q) {
 // One launch for up to kPackBatch convolutions (the whole U-Net has 62): blockIdx.y selects the descriptor.
 constexpr int kPackBatch = 48;
 struct PackBatch { PackDesc d[kPackBatch]; };
+static __global__ __launch_bounds__(256) void conv_weight_scale_batch_kernel(PackBatch pb) { conv_weight_scale_block(pb.d[blockIdx.y], (int)blockIdx.x); }
 static __global__ void conv_pack_weights_batch_kernel(PackBatch pb) {
     const PackDesc& q = pb.d[blockIdx.y];
     const long n = conv_pack_elems(q);

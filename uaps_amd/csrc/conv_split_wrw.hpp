@@ -41,21 +41,41 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& p0, u32x4& p1
     }
 }
 
-template <int TH, int WCO, int WCI, bool XF>
+// 8 consecutive floats (already scaled) -> two 16-byte rows of packed fp16 pieces
+__device__ __forceinline__ void split8h(const float (&v)[8], float sc, u32x4& p0, u32x4& p1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned a, b;
+        conv_split2h(v[2 * i] * sc, v[2 * i + 1] * sc, a, b);
+        p0[i] = a; p1[i] = b;
+    }
+}
+
+// H16: the two-piece fp16 form (three partial products); dy and the input are scaled by powers of two derived from the
+// callers' bounds (ConvWrwArgs::dy_bound / in_bound / in2_bound), the slabs receive the unscaled partial sums
+template <int TH, int WCO, int WCI, bool XF, bool H16 = false>
 __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     using Cfg = SWrwCfg<TH, WCO, WCI>;
+    constexpr int NP = H16 ? 2 : 3;
     constexpr int TW = 32, WR = Cfg::WR, RPW = Cfg::RPW, BCO = Cfg::BCO, BCI = Cfg::BCI;
     constexpr int DPLU = Cfg::DPLU, XPLU = Cfg::XPLU, EPL = Cfg::EPL, ND = Cfg::ND, NX = Cfg::NX;
     constexpr int RED_FLOATS = WR > 1 ? (WR / 2) * WCO * WCI * 10 * 256 : 0;
-    constexpr int STAGE_UNITS = 3 * BCO * DPLU + 3 * BCI * XPLU;
+    constexpr int STAGE_UNITS = NP * BCO * DPLU + NP * BCI * XPLU;
     constexpr int LDS_UNITS = STAGE_UNITS > RED_FLOATS / 4 ? STAGE_UNITS : RED_FLOATS / 4;
 
     __shared__ __attribute__((aligned(16))) u32x4 smem[LDS_UNITS];
-    __shared__ unsigned sE[3 * BCI * EPL];
+    __shared__ unsigned sE[NP * BCI * EPL];
     __shared__ f32x2 sXf[XF ? kWrwMaxGroups * BCI + 1 : 1];
     u32x4* sD = smem;                        // [piece][co][row][4 groups] (+ 2 pad units per plane)
-    u32x4* sX = smem + 3 * BCO * DPLU;       // [piece][ci][row][4 groups] (+ 2 pad units per plane)
+    u32x4* sX = smem + NP * BCO * DPLU;      // [piece][ci][row][4 groups] (+ 2 pad units per plane)
     constexpr int XF_ZERO = kWrwMaxGroups * BCI;
+
+    float sc_d = 1.f, sc_x = 1.f, inv_d = 1.f, inv_x = 1.f;
+    if constexpr (H16) {
+        const f32x2 sd = h16_scale(bound_of(a.dy_bound, a.dy_mul));
+        const f32x2 sx = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
+        sc_d = sd.x; inv_d = sd.y; sc_x = sx.x; inv_x = sx.y;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -103,7 +123,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 
     auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
-        const int y0 = (tt / a.tiles_x) * TH, x0 = (tt % a.tiles_x) * TW;
+        const int y0 = (a.col_major ? tt % a.tiles_y : tt / a.tiles_x) * TH, x0 = (a.col_major ? tt / a.tiles_y : tt % a.tiles_x) * TW;
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
             const int c = co0 + dC[n], gy = y0 + dR[n], gx = x0 + dG[n] * 8;
@@ -133,14 +153,20 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     };
     auto store_tile = [&](int t) {
         const int tt = t % tiles_per_img;
-        const int x0 = (tt % a.tiles_x) * TW;
+        const int x0 = (a.col_major ? tt / a.tiles_y : tt % a.tiles_x) * TW;
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
             if (dC[n] < 0) continue;
-            u32x4 p0, p1, p2;
-            split8(rd[n], p0, p1, p2);
             const int u = dC[n] * DPLU + dR[n] * 4 + dG[n];
-            sD[u] = p0; sD[BCO * DPLU + u] = p1; sD[2 * BCO * DPLU + u] = p2;
+            if constexpr (H16) {
+                u32x4 p0, p1;
+                split8h(rd[n], sc_d, p0, p1);
+                sD[u] = p0; sD[BCO * DPLU + u] = p1;
+            } else {
+                u32x4 p0, p1, p2;
+                split8(rd[n], p0, p1, p2);
+                sD[u] = p0; sD[BCO * DPLU + u] = p1; sD[2 * BCO * DPLU + u] = p2;
+            }
         }
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
@@ -155,17 +181,26 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                     rx[n][k] = (col >= 0 && col < a.W) ? __builtin_fmaxf(z, z * a.xf_slope) : 0.f;
                 }
             }
-            u32x4 p0, p1, p2;
             float v8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v8[k] = rx[n][k];
-            split8(v8, p0, p1, p2);
             const int u = xC[n] * XPLU + xR[n] * 4 + xG[n];
-            sX[u] = p0; sX[BCI * XPLU + u] = p1; sX[2 * BCI * XPLU + u] = p2;
-            unsigned e0, e1, e2;                 // (right neighbour, left neighbour) -> low / high half of the edge dword
-            conv_split3(rx[n][9], rx[n][8], e0, e1, e2);
             const int eu = xC[n] * EPL + xR[n] * 4 + xG[n];
-            sE[eu] = e0; sE[BCI * EPL + eu] = e1; sE[2 * BCI * EPL + eu] = e2;
+            if constexpr (H16) {
+                u32x4 p0, p1;
+                split8h(v8, sc_x, p0, p1);
+                sX[u] = p0; sX[BCI * XPLU + u] = p1;
+                unsigned e0, e1;                 // (right neighbour, left neighbour) -> low / high half of the edge dword
+                conv_split2h(rx[n][9] * sc_x, rx[n][8] * sc_x, e0, e1);
+                sE[eu] = e0; sE[BCI * EPL + eu] = e1;
+            } else {
+                u32x4 p0, p1, p2;
+                split8(v8, p0, p1, p2);
+                sX[u] = p0; sX[BCI * XPLU + u] = p1; sX[2 * BCI * XPLU + u] = p2;
+                unsigned e0, e1, e2;             // (right neighbour, left neighbour) -> low / high half of the edge dword
+                conv_split3(rx[n][9], rx[n][8], e0, e1, e2);
+                sE[eu] = e0; sE[BCI * EPL + eu] = e1; sE[2 * BCI * EPL + eu] = e2;
+            }
         }
     };
 
@@ -173,7 +208,8 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const u32x4 ones_u = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};      // eight bf16 1.0
+    constexpr unsigned kOnes = H16 ? 0x3C003C00u : 0x3F803F80u;                          // two fp16 / bf16 1.0
+    const u32x4 ones_u = u32x4{kOnes, kOnes, kOnes, kOnes};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     const int aoff = (wco * 16 + j) * DPLU + kq;         // + row * 4 (+ piece plane)
@@ -191,9 +227,9 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int rr = 0; rr < RPW + 2; ++rr) {
             const int r = wr * RPW + rr;
-            bf16x8 bf[3][3];                              // [shift kx][piece]
+            bf16x8 bf[3][NP];                             // [shift kx][piece]
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const u32x4 c = sX[p * BCI * XPLU + boff + r * 4];
                 const unsigned e = sE[p * BCI * EPL + eoff + r * 4];
                 const unsigned t01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), t12 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
@@ -207,24 +243,36 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             for (int ky = 0; ky < 3; ++ky) {
                 const int yy = rr - ky;                   // dy row (relative to this wave's first) that meets input row r at row tap ky
                 if (yy < 0 || yy >= RPW) continue;
-                bf16x8 af[3];
+                bf16x8 af[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(bf16x8, sD[p * BCO * DPLU + aoff + (wr * RPW + yy) * 4]);
+                for (int p = 0; p < NP; ++p) af[p] = __builtin_bit_cast(bf16x8, sD[p * BCO * DPLU + aoff + (wr * RPW + yy) * 4]);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     f32x4 c = acc[ky * 3 + kx];
+                    if constexpr (H16) {
+                        const auto H = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[1]), H(bf[kx][0]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[0]), H(bf[kx][1]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[0]), H(bf[kx][0]), c, 0, 0, 0);
+                    } else {
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[kx][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[kx][2], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[kx][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[kx][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[kx][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[kx][0], c, 0, 0, 0);
+                    }
                     acc[ky * 3 + kx] = c;
                 }
                 if (ky == 0 && want_bias && wci == 0) {   // every dy row exactly once
-                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], ones, accb, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], ones, accb, 0, 0, 0);
-                    accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, accb, 0, 0, 0);
+                    if constexpr (H16) {
+                        accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[1]), __builtin_bit_cast(f16x8, ones), accb, 0, 0, 0);
+                        accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, ones), accb, 0, 0, 0);
+                    } else {
+                        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], ones, accb, 0, 0, 0);
+                        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], ones, accb, 0, 0, 0);
+                        accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], ones, accb, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -268,11 +316,11 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + wco * 16 + kq * 4 + r, ci = ci0 + wci * 16 + j;
-            slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = acc[t][r];
+            slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = H16 ? (acc[t][r] * inv_d) * inv_x : acc[t][r];      // exact: powers of two
         }
     if (want_bias && wci == 0 && j == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = accb[r];
+        for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = H16 ? accb[r] * inv_d : accb[r];
     }
 }
 
@@ -280,5 +328,9 @@ template <int TH, int WCO, int WCI>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_swrw_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, false>(a); }
 template <int TH, int WCO, int WCI>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_swrw_bn_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, true>(a); }
+template <int TH, int WCO, int WCI>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_hwrw_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, false, true>(a); }
+template <int TH, int WCO, int WCI>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_hwrw_bn_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, true, true>(a); }
 
 }  // namespace uaps

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include "conv_kernels.hpp"
 #include "conv_split_wrw.hpp"
+#include "hints.hpp"
 using namespace uaps;
 
 extern "C" int uaps_conv_get_mode(void);
@@ -18,7 +19,7 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     p.dil = ((cfg >> 24) & 0xf) ? ((cfg >> 24) & 0xf) : 1;       // bits 24-27: dilation; bit 28: exact kernels; bit 29: split kernels; low bits: pixel splits override
     const bool force_exact = (cfg >> 28) & 1, force_split = (cfg >> 29) & 1;
     cfg &= 0xffffff;
-    p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() == 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
+    p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() >= 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
     if (p.split) {
         p.wco = Cout > 16 ? 2 : 1; p.wci = Cin > 16 ? 2 : 1;
         p.TH = 4; p.TW = 32;
@@ -59,6 +60,11 @@ template <int TH, int WCO, int WCI>
 int launch_swrw(const ConvWrwArgs& a, hipStream_t s) {
     const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.dy_bound) {                                 // the fp16 two-piece form
+        if (a.xf) hipLaunchKernelGGL((conv_hwrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else hipLaunchKernelGGL((conv_hwrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (a.xf) hipLaunchKernelGGL((conv_swrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     else hipLaunchKernelGGL((conv_swrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
@@ -115,6 +121,7 @@ extern "C" int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, in
 static int wrw_partial_impl(const float* dy, const float* x, const float* x2, int Csplit, int want_bias, int B, int Cin, int Cout,
                             int H, int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream,
                             const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
+    const uaps_call_hints hints = uaps::take_hints();
     if (!dy || !x || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (xf && (x2 || groups < 1 || groups > kWrwMaxGroups || B % groups || (uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (xf && !(xf_slope >= 0.f && xf_slope <= 1.f)) return UAPS_ERANGE;      // leaky_relu is evaluated as max(z, slope * z)
@@ -131,12 +138,21 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     ConvWrwArgs a{};
     a.dout = dy; a.in = x; a.in2 = x2; a.Csplit = Csplit; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
+    { static const char* e = getenv("UAPS_SWRW_COLMAJOR"); a.col_major = e ? atoi(e) : 1; }      // measured: 2.3x -> 1.07x of the algorithmic bytes at 32 -> 16 @ 256^2
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
     a.bslab = want_bias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
-    if (p.split) return dispatch_swrw(a, p, s);
+    if (p.split) {
+        // mode 2 and every tensor operand bounded (uaps_next_call_hints: 0 = dy, 1 = x, 2 = x2): the two-piece fp16 form
+        if (uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1] && (!x2 || Csplit >= Cin || hints.bound[2])) {
+            a.dy_bound = hints.bound[0]; a.dy_mul = hints.mul[0];
+            a.in_bound = hints.bound[1]; a.in_mul = hints.mul[1];
+            if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
+        }
+        return dispatch_swrw(a, p, s);
+    }
     return ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
 }
 

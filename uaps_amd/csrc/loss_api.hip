@@ -143,6 +143,7 @@ extern "C" int uaps_pairloss_bwd(const float* const* lab_logits, const float* co
                                  const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1, float cw2,
                                  const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss, float* const* dlab,
                                  float* const* dun, int cfg, uaps_stream_t stream) {
+    float* amax_out = uaps::take_hints().out_amax;
     int rc = check_dims(D, B, C, H, W);
     if (rc) return rc;
     if ((rc = check_heads(lab_logits, D)) || (rc = check_heads(un_logits, D))) return rc;
@@ -152,5 +153,6 @@ extern "C" int uaps_pairloss_bwd(const float* const* lab_logits, const float* co
     a.ce_coef = 0.5f / D; a.dice_coef = 0.5f / D; a.cw1 = cw1; a.cw2 = cw2; a.labels = labels; a.cpseudo = pseudo;
     a.sscal = const_cast<float*>(sup_scalars); a.uscal = const_cast<float*>(unsup_scalars);
     a.Nloss = n_pixels_loss > 0 ? n_pixels_loss : (long)B * H * W; a.gscale = gscale; a.cfg = cfg; a.stream = (hipStream_t)stream;
+    a.amax_out = amax_out;
     return launch_pair_bwd(a);
 }

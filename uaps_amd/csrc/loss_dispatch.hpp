@@ -83,6 +83,7 @@ struct PairArgs {
     int D, B, C, H, W; float ce_coef, dice_coef, cw1, cw2, eps;
     const int64_t* labels; int64_t* pseudo; const int64_t* cpseudo; float* var; float* sscal; float* uscal; double* sums;
     long Nloss; const float* gscale; float* partials; int cfg; hipStream_t stream;
+    float* amax_out;      // backward: device scalar raised to max|gradient element| (uaps_call_hints::out_amax), or nullptr
 };
 // 16-byte access to every plane of both branches?
 inline bool pair_vec_ok(const PairArgs& a, int vec, bool outs) {

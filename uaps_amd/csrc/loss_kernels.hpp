@@ -11,6 +11,7 @@
 //
 // Reference lines restated: UAPS_train.py:186-189, 194-218, 223-277, 282; pytorch_losses.py:81-89.
 #pragma once
+#include "hints.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -567,7 +568,7 @@ template <int D, int C, int VEC>
 __device__ __forceinline__ void unsup_bwd_body(const HeadPtrs<D>& z, const HeadOutPtrs<D>& dz, int HW, long ngroups, long N,
                                                const int64_t* __restrict__ pseudo,
                                                const float* __restrict__ sc, float cw1, float cw2,
-                                               const float* __restrict__ gscale, int bid, int nblk) {
+                                               const float* __restrict__ gscale, int bid, int nblk, float& am) {
     const float gs = gscale ? gscale[0] : 1.f;
     const float invN = 1.f / (float)N;
     // per-head constants: coefficient of exp(-v_k) in g_k, and of the (CE + Dice) term
@@ -643,6 +644,7 @@ __device__ __forceinline__ void unsup_bwd_body(const HeadPtrs<D>& z, const HeadO
                                    - gk[j] * (m[c] - p[j][c])
                                    + p[j][c] * (h[c] - ph);
                     zv[j][c][v] = gr;
+                    am = fmaxf(am, fabsf(gr));
                 }
             }
         }
@@ -657,7 +659,8 @@ __global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, Head
                                                              const int64_t* __restrict__ pseudo,
                                                              const float* __restrict__ sc, float cw1, float cw2,
                                                              const float* __restrict__ gscale) {
-    unsup_bwd_body<D, C, VEC>(z, dz, HW, ngroups, N, pseudo, sc, cw1, cw2, gscale, (int)blockIdx.x, (int)gridDim.x);
+    float am = 0.f;
+    unsup_bwd_body<D, C, VEC>(z, dz, HW, ngroups, N, pseudo, sc, cw1, cw2, gscale, (int)blockIdx.x, (int)gridDim.x, am);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -667,7 +670,7 @@ template <int D, int C, int VEC>
 __device__ __forceinline__ void sup_bwd_body(const HeadPtrs<D>& z, const HeadOutPtrs<D>& dz, int HW, long ngroups, long N,
                                              const int64_t* __restrict__ labels,
                                              const float* __restrict__ sc, float ce_coef,
-                                             float dice_coef, const float* __restrict__ gscale, int bid, int nblk) {
+                                             float dice_coef, const float* __restrict__ gscale, int bid, int nblk, float& am) {
     const float gs0 = gscale ? gscale[0] : 1.f;
     const float gce = gs0 * ce_coef / (float)N, gdc = gs0 * dice_coef;
     const float* __restrict__ A1 = sc + UAPS_S_A1(D, C);
@@ -700,6 +703,7 @@ __device__ __forceinline__ void sup_bwd_body(const HeadPtrs<D>& z, const HeadOut
                 for (int c = 0; c < C; ++c) {
                     const float oh = (y == c) ? 1.f : 0.f;
                     zv[c][v] = gce * (p[c] - oh) + gdc * p[c] * (a[c] - pa);
+                    am = fmaxf(am, fabsf(zv[c][v]));
                 }
             }
 #pragma unroll
@@ -712,7 +716,8 @@ __global__ __launch_bounds__(kThreads) void sup_bwd_kernel(HeadPtrs<D> z, HeadOu
                                                            const int64_t* __restrict__ labels,
                                                            const float* __restrict__ sc, float ce_coef,
                                                            float dice_coef, const float* __restrict__ gscale) {
-    sup_bwd_body<D, C, VEC>(z, dz, HW, ngroups, N, labels, sc, ce_coef, dice_coef, gscale, (int)blockIdx.x, (int)gridDim.x);
+    float am = 0.f;
+    sup_bwd_body<D, C, VEC>(z, dz, HW, ngroups, N, labels, sc, ce_coef, dice_coef, gscale, (int)blockIdx.x, (int)gridDim.x, am);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -750,10 +755,15 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(HeadPtrs<D> zl, Head
                                                             const int64_t* __restrict__ pseudo, const float* __restrict__ sscal,
                                                             const float* __restrict__ uscal, float ce_coef, float dice_coef, float cw1,
                                                             float cw2, const float* __restrict__ gscale, int nb_s,
-                                                            const uint32_t* __restrict__ st) {
+                                                            const uint32_t* __restrict__ st, float* __restrict__ amax_out) {
     cw1 = step_f(st, kStepCw1, cw1); cw2 = step_f(st, kStepCw2, cw2);
-    if ((int)blockIdx.x < nb_s) sup_bwd_body<D, C, VS>(zl, dl, HW, N / VS, Nloss, labels, sscal, ce_coef, dice_coef, gscale, (int)blockIdx.x, nb_s);
-    else unsup_bwd_body<D, C, VU>(zu, du, HW, N / VU, Nloss, pseudo, uscal, cw1, cw2, gscale, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s);
+    float am = 0.f;                              // max|gradient element| written by this thread (uaps_call_hints::out_amax)
+    if ((int)blockIdx.x < nb_s) sup_bwd_body<D, C, VS>(zl, dl, HW, N / VS, Nloss, labels, sscal, ce_coef, dice_coef, gscale, (int)blockIdx.x, nb_s, am);
+    else unsup_bwd_body<D, C, VU>(zu, du, HW, N / VU, Nloss, pseudo, uscal, cw1, cw2, gscale, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s, am);
+    if (amax_out) {                              // uniform branch
+        __shared__ float sm[16];
+        block_amax_to(amax_out, am, sm);
+    }
 }
 
 }  // namespace uaps

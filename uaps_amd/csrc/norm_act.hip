@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include "../../include/uaps_hip.h"
 #include "philox.hpp"
+#include "hints.hpp"
 
 namespace {
 using uaps::philox4x32_10; using uaps::u01; using uaps::U4; using uaps::pick;
@@ -248,10 +249,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __rest
                                                              int nch_p, int B, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ dconv_bias,
                                                              float slope, float drop_p, float drop_scale, uint64_t seed_in,
-                                                             uint64_t offset, int Bg, const uint32_t* __restrict__ st) {
+                                                             uint64_t offset, int Bg, const uint32_t* __restrict__ st,
+                                                             float* __restrict__ amax_out) {
     const uint64_t seed = uaps::step_key(seed_in, st);
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C, g = b / Bg;
+    float amax = 0.f;                            // max|dy| of this thread's elements (uaps_call_hints::out_amax)
     // The reduction's finalize runs here, not as a launch of its own: the first wave sums this channel's per-block
     // partials of the block's statistics group (a few hundred float2, L2-resident) in a fixed order -- every block of
     // the group computes the same two means bit for bit -- and the block of image 0, chunk 0 also adds up all groups
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __rest
                 o[k] = sc * (d - k2 - ((yy[k] - mu) * is) * k3);
             }
             *reinterpret_cast<float4*>(dy + pbase + i) = make_float4(o[0], o[1], o[2], o[3]);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
         }
     } else {
         for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
@@ -310,8 +314,14 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __rest
                 g = u01(pick(r, (int)(e & 3))) >= drop_p ? g * drop_scale : 0.f;
             }
             const float d = dpre(g, yv, mu, sc, sh, slope);
-            dy[pbase + i] = sc * (d - k2 - ((yv - mu) * is) * k3);
+            const float o = sc * (d - k2 - ((yv - mu) * is) * k3);
+            dy[pbase + i] = o;
+            amax = fmaxf(amax, fabsf(o));
         }
+    }
+    if (amax_out) {                              // uniform branch
+        __shared__ float sm[16];
+        uaps::block_amax_to(amax_out, amax, sm);
     }
 }
 
@@ -454,6 +464,7 @@ static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, co
                                        const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
                                        uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
                                        float* dbeta, float* dconv_bias, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    float* amax_out = uaps::take_hints().out_amax;
     int rc = check(dout, dy, B, C, H, W);
     if (rc) return rc;
     if (!y || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
@@ -467,7 +478,7 @@ static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, co
     const bool vec = (HW % 4 == 0) && al16(y) && al16(dout) && al16(dy);
     const float dscale = 1.f / (1.f - drop_p);
 #define UAPS_SUMS(V, D) hipLaunchKernelGGL((bn_bwd_sums_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, drop_p, dscale, seed, offset, w.partials, Bg, (const uint32_t*)uaps_get_step_state())
-#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, (const float2*)w.partials, nch, B, dgamma, dbeta, dconv_bias, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state())
+#define UAPS_DX(V, D) hipLaunchKernelGGL((bn_bwd_dx_kernel<V, D>), grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, save_mean, save_invstd, gamma, beta, (const float2*)w.partials, nch, B, dgamma, dbeta, dconv_bias, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state(), amax_out)
     if (vec) { if (drop_p > 0.f) UAPS_SUMS(true, true); else UAPS_SUMS(true, false); }
     else { if (drop_p > 0.f) UAPS_SUMS(false, true); else UAPS_SUMS(false, false); }
     if (vec) { if (drop_p > 0.f) UAPS_DX(true, true); else UAPS_DX(true, false); }
@@ -523,4 +534,42 @@ extern "C" int uaps_bn_act_bwd_eval(const float* dout, const float* y, const flo
     else
         hipLaunchKernelGGL(bn_bwd_eval_kernel<false>, grid, dim3(kThreads), 0, s, dout, y, dy, C, HW, mean_eff, w.coef, slope);
     return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Magnitude bounds of train-mode BatchNorm outputs from the parameters alone: with batch statistics every normalised
+// value obeys |x_hat| <= sqrt(n - 1) (Samuelson's inequality, n = elements per channel and statistics group), hence
+//   |gamma * x_hat + beta| <= sqrt(n) * max_c(|gamma_c| + |beta_c|)        (n >= 1),
+// and LeakyReLU (slope <= 1) only shrinks it.  out[i] = max_c(|gamma_c| + |beta_c|) of layer i; the caller multiplies by
+// sqrt(n) (and 1 / (1 - p) of a following dropout) when it passes the bound on (uaps_next_call_hints).  One launch for all
+// layers of a model, once per optimizer step.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kBoundBatch = 64;
+struct BoundBatch { const float* gamma[kBoundBatch]; const float* beta[kBoundBatch]; int C[kBoundBatch]; };
+__global__ __launch_bounds__(64) void bn_param_bounds_kernel(BoundBatch bb, float* __restrict__ out) {
+    const int i = blockIdx.x, C = bb.C[i];
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 64) m = fmaxf(m, fabsf(bb.gamma[i][c]) + fabsf(bb.beta[i][c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) out[i] = m;
+}
+}  // namespace
+
+extern "C" int uaps_bn_param_bounds(const float* const* gamma, const float* const* beta, const int* C, int n, float* out,
+                                    uaps_stream_t stream) {
+    if (!gamma || !beta || !C || !out || n <= 0) return UAPS_EINVAL;
+    for (int base = 0; base < n; base += kBoundBatch) {
+        const int m = n - base < kBoundBatch ? n - base : kBoundBatch;
+        BoundBatch bb{};
+        for (int i = 0; i < m; ++i) {
+            if (!gamma[base + i] || !beta[base + i] || C[base + i] <= 0) return UAPS_EINVAL;
+            bb.gamma[i] = gamma[base + i]; bb.beta[i] = beta[base + i]; bb.C[i] = C[base + i];
+        }
+        hipLaunchKernelGGL(bn_param_bounds_kernel, dim3(m), dim3(64), 0, (hipStream_t)stream, bb, out + base);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return UAPS_OK;
 }

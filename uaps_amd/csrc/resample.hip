@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/uaps_hip.h"
+#include "hints.hpp"
 #include "rn_math.hpp"
 
 namespace {
@@ -24,11 +25,15 @@ inline int grid_for(long work, int cap = 4096) {
 }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// a0 v0 + a1 v1 with the contraction spelled out (a rounded product, then one fma), so that every kernel that interpolates
+// produces the same bits whatever the compiler would have fused
+__device__ __forceinline__ float lerp2(float a0, float v0, float a1, float v1) { return __builtin_fmaf(a1, v1, mul_rn(a0, v0)); }
+
 __device__ __forceinline__ float bilerp(const float* __restrict__ p, int w, int h0, int h1, float lh0, float lh1, int w0, int w1,
                                         float lw0, float lw1) {
-    const float top = lw0 * p[(long)h0 * w + w0] + lw1 * p[(long)h0 * w + w1];
-    const float bot = lw0 * p[(long)h1 * w + w0] + lw1 * p[(long)h1 * w + w1];
-    return lh0 * top + lh1 * bot;
+    const float top = lerp2(lw0, p[(long)h0 * w + w0], lw1, p[(long)h0 * w + w1]);
+    const float bot = lerp2(lw0, p[(long)h1 * w + w0], lw1, p[(long)h1 * w + w1]);
+    return lerp2(lh0, top, lh1, bot);
 }
 
 // out[b, 0:Cs]      = skip[b]                      (copy)
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void up_cat_fwd_kernel(const float* __res
 // the gather kernel above is load-instruction-bound at 2.3 TB/s).  Arithmetic and association are bilerp()'s.
 template <int TC>
 __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __restrict__ low, float* __restrict__ out, int h, int w,
-                                                              float rh, float rw, int tiles_x, int tiles_y) {
+                                                              float rh, float rw, int tiles_x, int tiles_y, float* __restrict__ amax_out) {
     constexpr int TR = 1024 / TC, LR = TR / 2 + 2, LC = TC / 2 + 2, LCP = LC + 1;
     __shared__ float sL[LR * LCP];
     const int H = 2 * h, W = 2 * w;
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __res
     __syncthreads();
     const int xg = threadIdx.x % (TC / 4), row = threadIdx.x / (TC / 4);
     const int oy = oy0 + row, ox = ox0 + xg * 4;
-    if (oy >= H || ox >= W) return;
+    float am = 0.f;                              // max|output| of this thread (uaps_call_hints::out_amax)
+    if (oy < H && ox < W) {
     const float sy = mul_rn(rh, (float)oy);
     const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
     const float lh1 = sy - h0, lh0 = 1.f - lh1;
@@ -110,11 +116,17 @@ __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __res
         const float sx = mul_rn(rw, (float)(ox + k));
         const int w0 = (int)sx, w1 = w0 + (w0 < w - 1 ? 1 : 0);
         const float lw1 = sx - w0, lw0 = 1.f - lw1;
-        const float top = lw0 * r0[w0] + lw1 * r0[w1];
-        const float bot = lw0 * r1[w0] + lw1 * r1[w1];
-        v[k] = lh0 * top + lh1 * bot;
+        const float top = lerp2(lw0, r0[w0], lw1, r0[w1]);
+        const float bot = lerp2(lw0, r1[w0], lw1, r1[w1]);
+        v[k] = lerp2(lh0, top, lh1, bot);
     }
     *reinterpret_cast<float4*>(out + (plane * H + oy) * W + ox) = make_float4(v[0], v[1], v[2], v[3]);
+    am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (amax_out) {                              // uniform branch
+        __shared__ float sm[16];
+        uaps::block_amax_to(amax_out, am, sm);
+    }
 }
 
 // d_skip = dout[:, :Cs] (copy) ;  d_low = transpose of the interpolation applied to dout[:, Cs:].
@@ -225,19 +237,21 @@ __global__ __launch_bounds__(kThreads) void slice_channels_kernel(const float* _
 
 extern "C" int uaps_up_cat_fwd(const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w,
                                uaps_stream_t stream) {
+    float* amax_out = uaps::take_hints().out_amax;
     if (!skip || !low || !out || B <= 0 || Cs < 0 || Cl <= 0 || h <= 0 || w <= 0) return UAPS_EINVAL;
     const int H = 2 * h, W = 2 * w;
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * (Cs + Cl) * H * W;
+    if (amax_out && !(Cs == 0 && W % 4 == 0 && al16(out))) return UAPS_ERANGE;      // only the plain up-sampling form tracks max|out|
     if (Cs == 0 && W % 4 == 0 && al16(out)) {            // plain up-sampling: the LDS-tiled kernel
         const bool wide = W >= 64;
         const int TC = wide ? 64 : 32, TR = 1024 / TC;
         const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
         const long nblk = (long)B * Cl * tiles_x * tiles_y;
         if (nblk > 0x7fffffffL) return UAPS_ERANGE;
-        if (wide) hipLaunchKernelGGL(up2x_tiled_kernel<64>, dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y);
-        else hipLaunchKernelGGL(up2x_tiled_kernel<32>, dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y);
+        if (wide) hipLaunchKernelGGL(up2x_tiled_kernel<64>, dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
+        else hipLaunchKernelGGL(up2x_tiled_kernel<32>, dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
         return (int)hipGetLastError();
     }
     if (W % 4 == 0 && al16(skip) && al16(out))

@@ -9,7 +9,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import _graddest, _lib
+from . import _graddest, _lib, bounds
 from .perturb import _RngState
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -99,12 +99,16 @@ class _BnActTrain(torch.autograd.Function):
         # over a channel) is exactly zero -- written by the same finalize kernel instead of a fill launch
         dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys]
         ws = _bn_ws(dev, B, Cc, H, W)
+        am = bounds.new_amax(dev) if bounds.enabled() else None      # max|dy|: the operand bound of the convolution's backward
         with _lib.device_guard(dev):
+            if am is not None:
+                _lib.hints((), am)
             rc = _lib.lib().uaps_bn_act_bwd_grouped_bias(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                          stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B,
                                                          Cc, H, W, groups, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                                                          dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
         _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
+        bounds.put(dy, am)
         return dy, (dgb[2] if has_bias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -154,8 +158,13 @@ def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2
         p = float(drop_p) if training else 0.0
         seed, off = _RngState.reserve(y.numel()) if p > 0 else (0, 0)
         mom = 0.1 if bn.momentum is None else bn.momentum
-        return _BnActTrain.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                 mom, bn.eps, slope, p, seed, off, STAT_GROUPS, stats)
+        out = _BnActTrain.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                mom, bn.eps, slope, p, seed, off, STAT_GROUPS, stats)
+        if y.is_cuda and slope <= 1.0:             # |gamma x_hat + beta| <= sqrt(n) max(|gamma| + |beta|), dropout scales by 1 / (1 - p)
+            b = bounds.bn_output_bound(bn, y.shape[0] // STAT_GROUPS * y.shape[2] * y.shape[3], 1.0 / (1.0 - p))
+            if b is not None:
+                bounds.put(out, *b)
+        return out
     return _BnActEval.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, slope)
 
 
@@ -167,7 +176,7 @@ class _BnActConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, stats_partials, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, groups,
-                weight, bias, want_stats):
+                weight, bias, want_stats, xb=None):
         from . import conv as _conv
         _lib.require_device(y, "bn_act_conv")
         ctx.set_materialize_grads(False)
@@ -198,7 +207,9 @@ class _BnActConv(torch.autograd.Function):
                                           nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), B, Cc, H, W,
                                           groups, stats[0].data_ptr(), stats[1].data_ptr(), xf.data_ptr(), st)
             _lib.check(rc, "uaps_bn_finalize_train")
-            with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, 0):
+            with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, 0, _conv._h16(xb)):
+                if xb is not None:
+                    _lib.hints((xb,))
                 rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, z.data_ptr(),
                                         zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, 0, st)
@@ -206,6 +217,7 @@ class _BnActConv(torch.autograd.Function):
         ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
+        ctx.xb = xb
         if want_stats:
             ctx.mark_non_differentiable(zstats)
             return z, zstats
@@ -215,14 +227,15 @@ class _BnActConv(torch.autograd.Function):
     def backward(ctx, dz, *_unused):
         from . import conv as _conv
         if dz is None:
-            return (None,) * 15
+            return (None,) * 16
         y, gamma, beta, stats, xf, wb = ctx.saved_tensors
         slope, groups, has_cbias, has_bias, Cout, ks = ctx.meta
+        dzb, xb = bounds.get(dz), ctx.xb
         dz = dz.contiguous()
         B, Cc, H, W = y.shape
         dev = y.device
         L = _lib.lib()
-        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks)
+        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, dyb=dzb)
         n = C.c_size_t()
         _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
         cws = _conv._workspace(dev, n.value)
@@ -234,18 +247,24 @@ class _BnActConv(torch.autograd.Function):
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
-            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, 0):
+            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, 0, _conv._h16(dzb, xb)):
+                if dzb is not None and xb is not None:
+                    _lib.hints((dzb, xb))
                 rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
                                                        Cout, H, W, ks, 0, cws.data_ptr(), cws.numel(), st)
             _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
             rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
                                                ks, 0, st)
             _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+            am = bounds.new_amax(dev) if bounds.enabled() else None
+            if am is not None:
+                _lib.hints((), am)
             rc = L.uaps_bn_act_bwd_grouped_bias(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
                                                 stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), st)
             _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
-        return dy, None, (dgb[2] if has_cbias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None
+        bounds.put(dy, am)
+        return dy, None, (dgb[2] if has_cbias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None, None
 
 
 def can_fuse_bn_into_conv(y: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -258,8 +277,9 @@ def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.
     """conv2d(leaky_relu(bn_train(y + conv_bias)), weight, bias) (+ the epilogue statistics of the result) where `y`,
     `stats` come from conv2d_with_stats: train-mode only, no dropout between the two (decoder ConvBlocks)."""
     mom = 0.1 if bn.momentum is None else bn.momentum
+    xb = bounds.bn_output_bound(bn, y.shape[0] // STAT_GROUPS * y.shape[2] * y.shape[3]) if slope <= 1.0 else None
     return _BnActConv.apply(y, stats, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                            mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats)
+                            mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats, xb)
 
 
 class _UpCat(torch.autograd.Function):
@@ -329,7 +349,10 @@ class _FanOut(torch.autograd.Function):
 def fan_out(x: torch.Tensor, n: int):
     """n handles on the same tensor whose gradients are summed by one kernel (GPU tensors only)."""
     _lib.require_device(x, "fan_out")
-    return _FanOut.apply(x, n)
+    return tuple(bounds.carry(x, h) for h in _FanOut.apply(x, n))
+
+
+_last_up2x_amax = None
 
 
 class _Up2x(torch.autograd.Function):
@@ -342,11 +365,17 @@ class _Up2x(torch.autograd.Function):
         low = low.contiguous()
         B, Cl, h, w = low.shape
         out = torch.empty((B, Cl, 2 * h, 2 * w), dtype=torch.float32, device=low.device)
+        # max|out| for the convolution that reads the up-sampled tensor (the LDS-tiled kernel of 16-byte rows tracks it)
+        am = bounds.new_amax(low.device) if bounds.enabled() and (2 * w) % 4 == 0 and out.data_ptr() % 16 == 0 else None
         with _lib.device_guard(low.device):
+            if am is not None:
+                _lib.hints((), am)
             rc = _lib.lib().uaps_up_cat_fwd(low.data_ptr(), low.data_ptr(), out.data_ptr(), B, 0, Cl, h, w,
                                             _lib.current_stream(low.device))
         _lib.check(rc, "uaps_up_cat_fwd")
         ctx.meta = (B, Cl, h, w)
+        global _last_up2x_amax
+        _last_up2x_amax = am
         return out
 
     @staticmethod
@@ -361,4 +390,7 @@ class _Up2x(torch.autograd.Function):
 
 
 def upsample2x(low: torch.Tensor) -> torch.Tensor:
-    return _Up2x.apply(low)
+    global _last_up2x_amax
+    out = _Up2x.apply(low)
+    am, _last_up2x_amax = _last_up2x_amax, None
+    return bounds.put(out, am)

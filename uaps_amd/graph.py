@@ -19,7 +19,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib, conv, losses, metrics, perturb
+from . import _lib, bounds, conv, losses, metrics, perturb
 
 _KEY_STEP = 0x9E3779B97F4A7C15
 NAN = float("nan")
@@ -158,6 +158,7 @@ class StepGraph:
         dev = tr.device
         self.static = {"x_l": x_l.clone(), "y_l": y_l.clone(), "x_u": x_u.clone()}
         conv.invalidate_packed_weights()             # the weight packing must be part of the captured step
+        bounds.reset_pool()                          # ... and so must the zero fill of every max|.| scalar the kernels raise
         tr.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
@@ -165,6 +166,7 @@ class StepGraph:
             self.state.upload()
             out, cm = self._body(self.static["x_l"], self.static["y_l"], self.static["x_u"])
         self.graph = g
+        bounds.reset_pool()                          # eager code must not be handed scalars the replays re-zero
         self.static["out"], self.static["cm"] = out, cm
         # the graph writes the packed weights through raw pointers: hold the buffers, whatever the cache does later
         self.static["packed"] = [(e[3], e[4]) for e in conv._packed.values()]

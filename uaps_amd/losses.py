@@ -344,10 +344,16 @@ class _PairLoss(torch.autograd.Function):
             un_p = (C.c_void_p * D)(*[z.data_ptr() for z in zs[D:]])
             dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz[:D]])
             dun_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz[D:]])
+        from . import bounds
+        am = bounds.new_amax(dev) if bounds.enabled() else None      # max|d logits|: operand bound of out_conv's weight gradient
         with _lib.device_guard(dev), _timed("uaps_pair_bwd"):
+            if am is not None:
+                _lib.hints((), am)
             rc = L.uaps_pairloss_bwd(lab_p, un_p, y.data_ptr(), pseudo.data_ptr(), sscal.data_ptr(), uscal.data_ptr(), cw1, cw2,
                                      g.data_ptr(), D, B, Cc, H, W, n_loss, dlab_p, dun_p, PAIR_CFG, st)
         _lib.check(rc, "uaps_pairloss_bwd")
+        for t in dz:
+            bounds.put(t, am)
         return (None, None, None, None, None, None, None, None) + tuple(dz)
 
 

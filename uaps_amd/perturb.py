@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, bounds
 
 
 # Captured steps (trainer graph mode) cannot take a fresh host number per replay: with DEVICE_THRESHOLDS the FeatureDropout
@@ -466,4 +466,10 @@ def perturbed_fan_out(f: torch.Tensor, kinds, groups: int = 1, noise_range: floa
     with_pool appends MaxPool2d(2)(f), whose gradient returns through the same fused backward kernel."""
     if with_pool and (f.shape[2] % 2 or f.shape[3] % 8):
         raise ValueError("with_pool needs an even height and a width that is a multiple of 8")
-    return _PerturbFan.apply(f, tuple(kinds), int(groups), noise_range, drop_p, bool(with_pool))
+    outs = _PerturbFan.apply(f, tuple(kinds), int(groups), noise_range, drop_p, bool(with_pool))
+    if bounds.get(f) is not None:            # |f (1 + U(-r, r))| <= (1 + r) |f|, dropout scales by 1 / (1 - p), masks and max-pool contract
+        factor = {"noise": 1.0 + abs(float(noise_range)), "dropout": 1.0 / (1.0 - float(drop_p)), "feature_dropout": 1.0}
+        fs = [1.0] + [factor[k] for k in kinds] + ([1.0] if with_pool else [])
+        for o, m in zip(outs, fs):
+            bounds.carry(f, o, m)
+    return outs

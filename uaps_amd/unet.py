@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import conv, fused, perturb
+from . import bounds, conv, fused, perturb
 
 FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
 ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
@@ -182,8 +182,13 @@ class UNet(nn.Module):
         super().__init__()
         self.encoder = Encoder(in_chns, feature_chns)
         self.decoder = Decoder(class_num, feature_chns)
+        self._bns = None
 
     def forward(self, x):
+        if x.is_cuda and self.training:          # bounds of the train-mode BatchNorm outputs (conv mode 'h16')
+            if self._bns is None:
+                self._bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            bounds.refresh(self._bns)
         return self.decoder(self.encoder(x))
 
 
@@ -209,6 +214,7 @@ class UNet_UAPS(nn.Module):
             setattr(self, f"aux_decoder{i}", Decoder(class_num, feature_chns))
         self._noise = perturb.FeatureNoise()
         self._conv_weights = None
+        self._bns = None
         self._streams = None
 
     def aux_decoders(self) -> List[Decoder]:
@@ -240,6 +246,10 @@ class UNet_UAPS(nn.Module):
             if self._conv_weights is None:
                 self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
             conv.pack_all(self._conv_weights)
+            if self.training:                        # bounds of the train-mode BatchNorm outputs (conv mode 'h16')
+                if self._bns is None:
+                    self._bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+                bounds.refresh(self._bns)
         if x.is_cuda and perturbations is None and self.n_aux > 0 and _FUSED_FAN:
             # per feature map: the clean handle + one perturbed copy per auxiliary decoder (+ the 2x2 max-pool that feeds
             # the next encoder level); all their gradients come back through ONE kernel that re-applies the perturbations,
