@@ -295,8 +295,8 @@ int uaps_up_cat_fwd(const float* skip, const float* low, float* out, int B, int 
 int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int B, int Cs, int Cl, int h, int w,
                     uaps_stream_t stream);
 
-/* out[i] = max_c(|gamma_i[c]| + |beta_i[c]|) for n BatchNorm layers (host arrays of n device pointers / channel counts), one
- * launch: times sqrt(elements per channel and statistics group) this bounds every output of the train-mode
+/* Bound i (out + i * UAPS_BOUND_FLOATS, see uaps_next_call_hints) = max_c(|gamma_i[c]| + |beta_i[c]|) for n BatchNorm layers
+ * (host arrays of n device pointers / channel counts; out holds n * UAPS_BOUND_FLOATS floats), one launch: times sqrt(elements per channel and statistics group) this bounds every output of the train-mode
  * BatchNorm (+ LeakyReLU) of utilities/UAPS_unet.py:38-39 (|x_hat| <= sqrt(n - 1) for batch statistics), the operand bound
  * of the convolutions behind it (uaps_next_call_hints). */
 int uaps_bn_param_bounds(const float* const* gamma_host, const float* const* beta_host, const int* C_host, int n, float* out,
@@ -331,14 +331,21 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above; process-wide, not 
 
 /* One-shot side arguments for the NEXT kernel entry point called on this thread; that call consumes and clears them
  * (every convolution entry point, uaps_bn_act_bwd*, uaps_pairloss_bwd and uaps_upsample2x do; NULL clears).
- *   bound[i], mul[i]  device scalar b and host factor m > 0 with |operand i| <= b[0] * m for every element; NULL = unknown.
+ *   bound[i], mul[i]  device bound b and host factor m > 0 with |operand i| <= value(b) * m for every element; NULL = unknown.
+ *                     A bound is UAPS_BOUND_FLOATS floats (16-byte aligned): value(b) = max over the UAPS_BOUND_SLOTS
+ *                     floats b[k * UAPS_BOUND_STRIDE], the rest is padding -- the producing kernels raise the slots with
+ *                     atomics, and thousands of workgroups on ONE address would serialise at the memory side.
  *                     Operands: conv forward: 0 = x (for the *_bn entry points: the activation after the fused
  *                     BatchNorm + LeakyReLU), 1 = x2 of *_cat;  conv bwd_data: 0 = dy;  conv bwd_weight: 0 = dy, 1 = x, 2 = x2.
  *                     In mode 2 a 3x3 convolution whose tensor operands all carry a bound runs in the two-piece fp16 form;
  *                     without bounds it runs as in mode 1.  A bound that is too small makes the result wrong (fp16
  *                     overflow), one that is too large by up to 2^10 costs no accuracy.
- *   out_amax          device scalar (zero-initialised by the caller) that the producing kernel raises atomically to the
- *                     maximum |element| of its output tensor: the bound of a later convolution's operand. */
+ *   out_amax          a bound (UAPS_BOUND_FLOATS floats, zero-initialised by the caller) whose slots the producing kernel raises
+ *                     atomically so that value(out_amax) = maximum |element| of its output tensor: the bound of a later
+ *                     convolution's operand. */
+#define UAPS_BOUND_SLOTS 16
+#define UAPS_BOUND_STRIDE 64
+#define UAPS_BOUND_FLOATS (UAPS_BOUND_SLOTS * UAPS_BOUND_STRIDE)
 typedef struct uaps_call_hints {
     const float* bound[3];
     float mul[3];

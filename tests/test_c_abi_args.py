@@ -94,7 +94,7 @@ def test_call_hints_are_validated_and_one_shot(L):
     assert L.uaps_next_call_hints(C.byref(h)) == OK
     assert L.uaps_conv_fwd(None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL   # consumes the pending hints
     assert L.uaps_next_call_hints(None) == OK
-    out = (C.c_float * 1)()
+    out = (C.c_float * 1024)()
     assert L.uaps_bn_param_bounds(None, None, None, 1, out, None) == EINVAL
 
 

@@ -25,7 +25,7 @@ def conv_mode(request):
 def _b(t, slack=1.0):
     """Attach the tensor's magnitude bound (uaps_amd/bounds.py) the way the producing kernels do: a device scalar >= max|t|."""
     from uaps_amd import bounds
-    return bounds.put(t, t.detach().abs().max().reshape(1) * slack, 1.0)
+    return bounds.put(t, bounds.from_value(t.detach().abs().max() * slack), 1.0)
 
 # (B, Cin, Cout, H, W, ks)
 SHAPES = [

@@ -3,7 +3,8 @@
 The fastest convolution kernels (conv mode 2, csrc/conv_split.hpp) compute an fp32 convolution from two fp16 pieces per
 operand; fp16's narrow exponent needs every tensor operand scaled by a power of two into range, and the scale comes from an
 upper bound of the tensor's magnitude held in DEVICE memory (the host never reads it).  A bound travels with a tensor as the
-Python attribute `_uaps_bound = (scalar, factor)`: |t| <= scalar[0] * factor.  Three sources:
+Python attribute `_uaps_bound = (bound, factor)`: |t| <= value(bound) * factor, a bound being 16 strided floats whose maximum
+counts (the kernels that raise one atomically spread over the slots).  Three sources:
 
   * train-mode BatchNorm outputs: |gamma * x_hat + beta| <= sqrt(n) * max_c(|gamma_c| + |beta_c|) (uaps_bn_param_bounds, one
     launch per optimizer step for all layers of a model; `refresh`), passed through LeakyReLU, dropout (x 1 / (1 - p)), max-pool,
@@ -26,8 +27,12 @@ from . import _lib
 ATTR = "_uaps_bound"
 Bound = Tuple[torch.Tensor, float]
 
-_pool = {}          # device index -> [chunk tensor, next free slot]
-_CHUNK = 256
+_pool = {}          # device index -> [chunk tensor, next free bound]
+_CHUNK = 64
+# a bound is FLOATS floats: SLOTS values STRIDE apart whose maximum counts (include/uaps_hip.h: UAPS_BOUND_*); the kernels that
+# raise it atomically spread their workgroups over the slots
+SLOTS, STRIDE = 16, 64
+FLOATS = SLOTS * STRIDE
 
 
 def get(t: Optional[torch.Tensor]) -> Optional[Bound]:
@@ -49,13 +54,24 @@ def carry(src: torch.Tensor, dst: torch.Tensor, factor: float = 1.0) -> torch.Te
 
 
 def new_amax(dev: torch.device) -> torch.Tensor:
-    """A zeroed device scalar for uaps_call_hints::out_amax: a view into a chunk of zeros (one fill launch per 256 scalars)."""
+    """A zeroed device bound for uaps_call_hints::out_amax: a view into a chunk of zeros (one fill launch per 64 bounds)."""
     ent = _pool.get(dev.index)
     if ent is None or ent[1] >= _CHUNK:
-        ent = _pool[dev.index] = [torch.zeros(_CHUNK, dtype=torch.float32, device=dev), 0]
-    s = ent[0][ent[1]:ent[1] + 1]
+        ent = _pool[dev.index] = [torch.zeros(_CHUNK * FLOATS, dtype=torch.float32, device=dev), 0]
+    s = ent[0][ent[1] * FLOATS:(ent[1] + 1) * FLOATS]
     ent[1] += 1
     return s
+
+
+def from_value(v: torch.Tensor) -> torch.Tensor:
+    """A bound holding the 1-element device tensor `v` (tests, and callers that computed a maximum themselves)."""
+    b = torch.zeros(FLOATS, dtype=torch.float32, device=v.device)
+    b[0:1] = v.reshape(1)
+    return b
+
+
+def value(b: torch.Tensor) -> torch.Tensor:
+    return b[::STRIDE][:SLOTS].max()
 
 
 def reset_pool() -> None:
@@ -82,14 +98,14 @@ def refresh(bns: List[torch.nn.BatchNorm2d]) -> None:
         return
     dev = bns[0].weight.device
     n = len(bns)
-    out = torch.empty(n, dtype=torch.float32, device=dev)
+    out = torch.empty(n * FLOATS, dtype=torch.float32, device=dev)
     arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
     with _lib.device_guard(dev):
         rc = _lib.lib().uaps_bn_param_bounds(arr([m.weight for m in bns]), arr([m.bias for m in bns]),
                                              (C.c_int * n)(*[m.num_features for m in bns]), n, out.data_ptr(), _lib.current_stream(dev))
     _lib.check(rc, "uaps_bn_param_bounds")
     for i, m in enumerate(bns):
-        m._uaps_G, m._uaps_G_gen = out[i:i + 1], gen
+        m._uaps_G, m._uaps_G_gen = out[i * FLOATS:(i + 1) * FLOATS], gen
 
 
 def bn_output_bound(bn: torch.nn.BatchNorm2d, n_per_channel: int, factor: float = 1.0) -> Optional[Bound]:

@@ -18,6 +18,7 @@
 //     channels and all taps.
 #pragma once
 #include "conv_kernels.hpp"
+#include "hints.hpp"
 
 namespace uaps {
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ f32x2 h16_scale(float bound) {
     se = se < 27 ? 27 : (se > 227 ? 227 : se);
     return f32x2{__builtin_bit_cast(float, (unsigned)se << 23), __builtin_bit_cast(float, (unsigned)(254 - se) << 23)};
 }
-__device__ __forceinline__ float bound_of(const float* p, float mul) { return p ? p[0] * mul : 0.f; }
+__device__ __forceinline__ float bound_of(const float* p, float mul) { return p ? bound_max(p) * mul : 0.f; }
 
 // number of 8-channel groups of the packed split weights for C contraction channels: padded to a multiple of 4 groups so
 // that any channel chunk (8, 16 or 32 channels) stays inside one tap's rows and reads zeros past the last channel

@@ -8,8 +8,19 @@ namespace uaps {
 // first, so that a hint never outlives the call it was meant for
 uaps_call_hints take_hints();
 
-// block-wide max|v| of the calling threads' values -> atomic max on a device scalar (non-negative floats order like their
-// bit patterns); every thread of the block must call it
+// A magnitude bound lives in UAPS_BOUND_SLOTS floats spaced UAPS_BOUND_STRIDE floats apart (include/uaps_hip.h); its value
+// is the maximum over the slots.  Thousands of workgroups raising ONE address serialise at the memory side (measured: ~2.4 ns
+// per atomic, +20 us on a 30 us kernel of 8192 blocks); spread over 16 lines they do not.
+__device__ __forceinline__ float bound_max(const float* p) {
+    float m = p[0];
+#pragma unroll
+    for (int i = 1; i < UAPS_BOUND_SLOTS; ++i) m = __builtin_fmaxf(m, p[i * UAPS_BOUND_STRIDE]);
+    return m;
+}
+
+// block-wide max|v| of the calling threads' values -> atomic max on one slot of a bound (non-negative floats order like their
+// bit patterns).  Only blocks that would change the slot issue the atomic (a stale, smaller value read here merely costs a
+// redundant atomic).  Every thread of the block must call it; smem_16: 16 floats of LDS.
 __device__ __forceinline__ void block_amax_to(float* dst, float v, float* smem_16) {
     v = __builtin_fabsf(v);
 #pragma unroll
@@ -20,9 +31,8 @@ __device__ __forceinline__ void block_amax_to(float* dst, float v, float* smem_1
     if (threadIdx.x == 0) {
         float m = smem_16[0];
         for (int i = 1; i < nw; ++i) m = __builtin_fmaxf(m, smem_16[i]);
-        // thousands of blocks raise one scalar: only those that would change it issue the atomic (a stale, smaller value read
-        // here merely costs a redundant atomic; same-address atomics serialise at the memory side)
-        if (m == m && m > __builtin_bit_cast(float, __atomic_load_n(reinterpret_cast<unsigned*>(dst), __ATOMIC_RELAXED))) atomicMax(reinterpret_cast<unsigned*>(dst), __builtin_bit_cast(unsigned, m));
+        unsigned* slot = reinterpret_cast<unsigned*>(dst) + ((blockIdx.x + blockIdx.y * 5u) % UAPS_BOUND_SLOTS) * UAPS_BOUND_STRIDE;
+        if (m == m && m > __builtin_bit_cast(float, __atomic_load_n(slot, __ATOMIC_RELAXED))) atomicMax(slot, __builtin_bit_cast(unsigned, m));
     }
 }
 }  // namespace uaps

@@ -540,7 +540,7 @@ extern "C" int uaps_bn_act_bwd_eval(const float* dout, const float* y, const flo
 // Magnitude bounds of train-mode BatchNorm outputs from the parameters alone: with batch statistics every normalised
 // value obeys |x_hat| <= sqrt(n - 1) (Samuelson's inequality, n = elements per channel and statistics group), hence
 //   |gamma * x_hat + beta| <= sqrt(n) * max_c(|gamma_c| + |beta_c|)        (n >= 1),
-// and LeakyReLU (slope <= 1) only shrinks it.  out[i] = max_c(|gamma_c| + |beta_c|) of layer i; the caller multiplies by
+// and LeakyReLU (slope <= 1) only shrinks it.  Bound i (out + i * UAPS_BOUND_FLOATS) = max_c(|gamma_c| + |beta_c|) of layer i; the caller multiplies by
 // sqrt(n) (and 1 / (1 - p) of a following dropout) when it passes the bound on (uaps_next_call_hints).  One launch for all
 // layers of a model, once per optimizer step.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -553,7 +553,8 @@ __global__ __launch_bounds__(64) void bn_param_bounds_kernel(BoundBatch bb, floa
     for (int c = threadIdx.x; c < C; c += 64) m = fmaxf(m, fabsf(bb.gamma[i][c]) + fabsf(bb.beta[i][c]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if (threadIdx.x == 0) out[i] = m;
+    // a bound is UAPS_BOUND_SLOTS strided floats whose maximum counts (include/uaps_hip.h): slot 0 = m, the others 0
+    if (threadIdx.x < UAPS_BOUND_SLOTS) out[(long)i * UAPS_BOUND_FLOATS + threadIdx.x * UAPS_BOUND_STRIDE] = threadIdx.x == 0 ? m : 0.f;
 }
 }  // namespace
 
@@ -567,7 +568,7 @@ extern "C" int uaps_bn_param_bounds(const float* const* gamma, const float* cons
             if (!gamma[base + i] || !beta[base + i] || C[base + i] <= 0) return UAPS_EINVAL;
             bb.gamma[i] = gamma[base + i]; bb.beta[i] = beta[base + i]; bb.C[i] = C[base + i];
         }
-        hipLaunchKernelGGL(bn_param_bounds_kernel, dim3(m), dim3(64), 0, (hipStream_t)stream, bb, out + base);
+        hipLaunchKernelGGL(bn_param_bounds_kernel, dim3(m), dim3(64), 0, (hipStream_t)stream, bb, out + (size_t)base * UAPS_BOUND_FLOATS);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
