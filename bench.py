@@ -24,8 +24,11 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak (same guide); the split ker
 
 
 def mfma_peak_for(kernel_name):
-    """Peak in ALGORITHMIC (fp32) TFLOP/s of the matrix pipe a conv kernel runs on: the bf16-split kernels (conv_s*) evaluate
-    every fp32 multiply as six bf16 partial products, so their ceiling is the dense bf16 peak / 6."""
+    """Peak in ALGORITHMIC (fp32) TFLOP/s of the matrix pipe a conv kernel runs on: the fp16-split kernels (conv_h*) evaluate every
+    fp32 multiply as three fp16 partial products, the bf16-split kernels (conv_s*) as six bf16 ones: their ceilings are the
+    dense 16-bit matrix peak / 3 and / 6."""
+    if kernel_name.startswith("conv_h"):
+        return MFMA_BF16_PEAK_TF / 3.0
     return MFMA_BF16_PEAK_TF / 6.0 if kernel_name.startswith("conv_s") else MFMA_F32_PEAK_TF
 
 
@@ -278,8 +281,9 @@ def main():
                             "algorithmic flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time on "
                             "the launch stream; traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); "
                             "peak: fp32 flops per second the kernel's matrix instruction allows at the nominal 2.4 GHz -- 157.3 for the "
-                            "fp32 MFMA kernels, 2500 / 6 = 416.7 for the bf16-split kernels (conv_s*: six bf16 partial products per "
-                            "fp32 multiply, fp32 accumulation; under bf16 MFMA load the chip holds ~1.66 GHz, DESIGN.md section 5)"}
+                            "fp32 MFMA kernels, 2500 / 3 = 833.3 for the fp16-split kernels (conv_h*: three fp16 partial products per "
+                            "fp32 multiply, fp32 accumulation), 2500 / 6 = 416.7 for the bf16-split kernels (conv_s*, six partial "
+                            "products; operands without a magnitude bound); DESIGN.md section 5"}
         elif ev:
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -313,10 +317,13 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "arithmetic": ("fp32 tensors and fp32 accumulation throughout; 3x3 convolutions with > 8 channels split both fp32 operands exactly "
-                              "into three bf16 pieces and sum the six leading partial products on the bf16 matrix pipe (error of an fp32 fma "
-                              "chain, tests/test_gpu_conv.py); UAPS_CONV_MODE=0 runs everything on the fp32 matrix instruction")
-               if os.environ.get("UAPS_CONV_MODE", "1") not in ("0", "exact", "f32") else "fp32 matrix instruction (v_mfma_f32_16x16x4_f32) everywhere",
+               "arithmetic": {"h16": "fp32 tensors and fp32 accumulation throughout; 3x3 convolutions with > 8 channels scale both fp32 operands by "
+                                     "powers of two (from device-resident magnitude bounds) and split them into two fp16 pieces (22 significant bits), "
+                                     "three partial products per multiply on the fp16 matrix pipe; measured error vs float64 at or below the fp32 "
+                                     "matrix instruction's (tests/test_gpu_conv.py); UAPS_CONV_MODE=1: exact three-piece bf16 split, =0: fp32 MFMA",
+                              "split": "fp32 tensors and fp32 accumulation throughout; 3x3 convolutions with > 8 channels split both fp32 operands exactly "
+                                       "into three bf16 pieces and sum the six leading partial products on the bf16 matrix pipe",
+                              "exact": "fp32 matrix instruction (v_mfma_f32_16x16x4_f32) everywhere"}[conv.get_mode()],
                "config": {"workload": f"UAPS K={args.aux} decoders, NEU-Seg-shaped {H}x{W} {C}-class, batch {b}+{b} per GPU (BASELINE.json configs[1])",
                           "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5),
                           "launch_mode": mode},

@@ -254,7 +254,7 @@ def test_fp16_pieces_hold_any_fp32_range(xs, ws, dys, Cin, Cout, H, W, conv_mode
         y = conv.conv2d(_b(xg, slack), wg)
         y.backward(_b(dy.to(dev), slack))
         names, conv.KERNEL_EVENTS = set(conv.KERNEL_EVENTS), None
-        assert any(n.startswith("conv_h32") or n.startswith("conv_hfwd") for n in names) and any(n.startswith("conv_hwrw") for n in names), names
+        assert any(n.startswith(("conv_h32", "conv_hfwd", "conv_hp16")) for n in names) and any(n.startswith("conv_hwrw") for n in names), names
         xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
         yr = F.conv2d(xr, wr, None, padding=1)
         yr.backward(dy.double())

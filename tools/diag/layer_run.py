@@ -14,11 +14,14 @@ x = torch.randn(B, Cin, HW, HW, device=dev)
 w = torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05
 dy = torch.randn(B, Cout, HW, HW, device=dev)
 wf, wb = C.pack_weights(w)
+from uaps_amd import bounds
+xb = (bounds.from_value(x.abs().max()), 1.0) if mode == "h16" else None
+dyb = (bounds.from_value(dy.abs().max()), 1.0) if mode == "h16" else None
 for _ in range(6):
     if d == "fwd":
-        C.conv_fwd_raw(x, wf, None, Cout, ks, cfg)
+        C.conv_fwd_raw(x, wf, None, Cout, ks, cfg, xb=xb)
     elif d == "bwd":
-        C.conv_bwd_data_raw(dy, wb, Cin, ks, cfg)
+        C.conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb)
     else:
-        C.conv_bwd_weight_raw(dy, x, ks, False, cfg)
+        C.conv_bwd_weight_raw(dy, x, ks, False, cfg, dyb=dyb, xb=xb)
 torch.cuda.synchronize()

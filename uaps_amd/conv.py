@@ -72,6 +72,10 @@ class _timed:
         if KERNEL_EVENTS is not None:
             self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg)
             if h16:                   # every tensor operand carried a bound: the fp16 two-piece instantiation of the same plan ran
+                kin = Cout if kind == "bwd_data" else Cin
+                if self.name.startswith("conv_sfwd") and "<3, 8, 32, 16," in self.name and 8 < kin <= 32:
+                    # <= 16 output channels on a wide map: the persistent kernels of csrc/conv_split_n16.hpp
+                    self.name = ("conv_hp16_bn_kernel" if "_bn_" in self.name else "conv_hp16_kernel") + ("<2>" if kin <= 16 else "<4>")
                 self.name = self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
             self.on = EVENT_FILTER is None or self.name in EVENT_FILTER
             self.flops = 2.0 * B * H * W * Cin * Cout * ks * ks

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include "conv_kernels.hpp"
 #include "conv_split.hpp"
+#include "conv_split_n16.hpp"
 #include "hints.hpp"
 using namespace uaps;
 
@@ -97,6 +98,26 @@ int dispatch_sfwd(const ConvFwdArgs& a, int bn, int ck, hipStream_t s) {
     } else {
         return bn == 16 ? launch_sfwd<1, TH, TW, 16, 32>(a, s) : launch_sfwd<1, TH, TW, 32, 32>(a, s);
     }
+}
+
+// persistent 16-output-channel kernels of conv_split_n16.hpp (fp16 form only): each workgroup takes a run of tiles
+int launch_hp16(ConvFwdArgs a, hipStream_t s) {
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 7) / 8;
+    a.nblk = 1;
+    const long ntiles = (long)a.B * a.tiles_x * a.tiles_y;
+    if (ntiles <= 0 || ntiles > 0x7fffffffL) return UAPS_EINVAL;
+    // one resident round: 3 (16 input channels) or 2 (32) workgroups fit a CU (registers), 256 CUs; forcing 4 spills and is slower
+    const long want = a.Cin <= 16 ? 768 : 512;
+    const unsigned grid = (unsigned)(((ntiles < want ? ntiles : want) + 7) / 8 * 8);
+    if (a.Cin <= 16) {
+        if (a.xf) hipLaunchKernelGGL((conv_hp16_bn_kernel<2>), dim3(grid), dim3(kConvThreads), 0, s, a);
+        else hipLaunchKernelGGL((conv_hp16_kernel<2>), dim3(grid), dim3(kConvThreads), 0, s, a);
+    } else {
+        if (a.xf) hipLaunchKernelGGL((conv_hp16_bn_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
+        else hipLaunchKernelGGL((conv_hp16_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
+    }
+    return (int)hipGetLastError();
 }
 
 template <int BN>
@@ -196,6 +217,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[1]; a.in2_mul = hints.mul[1]; }
         }
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
+        if (a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
         return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);
     }
