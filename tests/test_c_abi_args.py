@@ -78,6 +78,10 @@ def test_kernel_plan_names_and_statistics_tiles(L):
     assert L.uaps_conv_wrw_variant(32, 64, 64, 64, 64, 3, 1 << 28, buf, 96) == OK
     assert buf.value.decode() == "conv_wrw_kernel<3, 4, 32, 2, 2, 4, 1>"                 # cfg bit 28: the fp32 matrix instruction
     assert L.uaps_conv_set_mode(2) == OK
+    assert L.uaps_conv_fwd_variant(32, 16, 4, 256, 256, 3, 0, buf, 96) == OK and buf.value.decode() == "conv_small_kernel<8, 4>"      # class dimension
+    assert L.uaps_conv_wrw_variant(32, 16, 4, 256, 256, 3, 0, buf, 96) == OK and buf.value.decode() == "conv_small_wrw_kernel"
+    n = C.c_size_t()
+    assert L.uaps_conv_wrw_workspace_bytes(32, 16, 4, 256, 256, 3, 0, C.byref(n)) == OK and n.value == 512 * (9 * 4 * 16 + 4) * 4
     parts = C.c_int()
     assert L.uaps_conv_fwd_stats_parts(32, 16, 16, 256, 256, 3, 0, C.byref(parts)) == OK and parts.value == 32 * 8
     assert L.uaps_conv_fwd_stats_parts(4, 128, 128, 16, 16, 3, 0, C.byref(parts)) == OK and parts.value == 1

@@ -33,6 +33,9 @@ SHAPES = [
     (2, 16, 16, 64, 64, 3),
     (1, 32, 16, 40, 72, 3),     # concat conv, partial tiles in both directions
     (2, 16, 4, 32, 32, 3),      # out_conv, C=4
+    (2, 16, 4, 64, 128, 3),     # out_conv on a wide map: the exact-N VALU kernels (csrc/conv_small.hpp) in all three directions
+    (1, 16, 2, 40, 72, 3),      # ... C=2, partial tiles
+    (2, 3, 16, 24, 64, 3),      # <= 4 contraction channels on a wide map
     (1, 16, 7, 16, 48, 3),      # out_conv, DAGM C=7
     (1, 16, 2, 24, 20, 3),      # narrow map (16x16 tile path), C=2
     (2, 64, 64, 16, 16, 3),

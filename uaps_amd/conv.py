@@ -61,16 +61,19 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
         name = buf.value.decode()
         if kind.endswith("_bn"):      # the variants that apply BatchNorm + LeakyReLU while staging (fused._BnActConv)
             name = (name.replace("conv_fwd_kernel", "conv_fwd_bn_kernel").replace("conv_wrw_kernel", "conv_wrw_bn_kernel")
-                    .replace("conv_sfwd_kernel", "conv_sfwd_bn_kernel").replace("conv_s32_kernel", "conv_s32_bn_kernel").replace("conv_swrw_kernel", "conv_swrw_bn_kernel"))
+                    .replace("conv_sfwd_kernel", "conv_sfwd_bn_kernel").replace("conv_s32_kernel", "conv_s32_bn_kernel").replace("conv_swrw_kernel", "conv_swrw_bn_kernel")
+                    .replace("conv_small_kernel", "conv_small_bn_kernel").replace("conv_small_wrw_kernel", "conv_small_wrw_bn_kernel"))
         _variant_cache[key] = name
     return name
 
 
 class _timed:
-    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False):
+    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False, stats=False):
         self.on = False
         if KERNEL_EVENTS is not None:
             self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg)
+            if stats and self.name.startswith("conv_small"):      # the exact-N kernels have no statistics epilogue: the matrix kernel ran
+                self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg | (1 << 28))
             if h16:                   # every tensor operand carried a bound: the fp16 two-piece instantiation of the same plan ran
                 kin = Cout if kind == "bwd_data" else Cin
                 if self.name.startswith("conv_sfwd") and "<3, 8, 32, 16," in self.name and 8 < kin <= 32:
@@ -225,7 +228,7 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     if want_stats:
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
-    with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb)):
+    with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb), want_stats):
         if xb is not None:
             _lib.hints((xb,))
         if want_stats:

@@ -6,6 +6,7 @@
 #include "conv_kernels.hpp"
 #include "conv_split.hpp"
 #include "conv_split_n16.hpp"
+#include "conv_small.hpp"
 #include "hints.hpp"
 using namespace uaps;
 
@@ -120,6 +121,18 @@ int launch_hp16(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+int launch_small(ConvFwdArgs a, int kind, hipStream_t s) {
+    a.tiles_x = (a.W + 63) / 64;
+    a.tiles_y = (a.H + 15) / 16;
+    a.nblk = 1;
+    const long grid = ((long)a.B * a.tiles_x * a.tiles_y + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    (void)kind;
+    if (a.xf) hipLaunchKernelGGL((conv_small_bn_kernel<8, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else hipLaunchKernelGGL((conv_small_kernel<8, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 template <int BN>
 int launch_s32(ConvFwdArgs a, hipStream_t s) {
     a.tiles_x = (a.W + 31) / 32;
@@ -138,7 +151,8 @@ int launch_s32(ConvFwdArgs a, hipStream_t s) {
 }
 
 // split: one of the bf16-split kernels runs; s32: the 32x32x16 form (3x3, 8x32 tiles, >= 32 output channels)
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; };
+// small: 1 = the exact-N VALU kernel for <= 4 output channels (conv_small.hpp)
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
@@ -160,6 +174,12 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     if (cfg & 0xff) { bn = cfg & 0xff; if ((bn != 16 && bn != 32 && bn != 64) || p->CoutP % bn) return UAPS_EINVAL; }
     if (p->ck == 4) bn = 16;
     p->bn = bn;
+    p->small = 0;
+    if (ks == 3 && p->dil == 1 && W % 4 == 0 && W >= 64 && H >= 8 && !(cfg & 0x70ffffff)) {
+        if (Cout <= 4 && Cin % 8 == 0 && Cin <= 64) p->small = 1;
+        // (the mirror case, <= 4 contraction channels -> 16 outputs, measured 52 us against 47 us of the fp32 MFMA kernel at
+        // 4 -> 16 @ 256 x 256, B = 32: not used)
+    }
     // the split-bf16 form: 16-byte rows, no dilation, no forced tile / LDS settings; cfg bit 28 forces the exact kernels
     // cfg bits 29-30 select among them for tools/bench_modes.py: 1 = the 16x16x32 form, 2 = the 32x32x16 form (low byte: BN)
     // measured (tools/bench_modes.py, B = 32): the split forms win 1.2-1.7x on every 3x3 layer with more than 8 contraction
@@ -204,6 +224,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool wide = p.tw == 32;
+    // a side with <= 4 channels: the exact-N fp32 kernels (no BatchNorm statistics epilogue, one tensor per side)
+    if (p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
     if (p.split) {
         // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
         a.wp = wp + (size_t)ks * ks * p.CinP * p.CoutP;
@@ -347,7 +369,8 @@ extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int
     const int rc = plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
     if (!buf || buflen < 64) return UAPS_EINVAL;
-    if (p.s32) snprintf(buf, buflen, "conv_s32_kernel<%d>", p.sbn);
+    if (p.small) snprintf(buf, buflen, "conv_small_kernel<8, 4>");
+    else if (p.s32) snprintf(buf, buflen, "conv_s32_kernel<%d>", p.sbn);
     else if (p.split) snprintf(buf, buflen, "conv_sfwd_kernel<%d, %d, %d, %d, %d>", ks, p.th, p.tw, p.sbn, p.sck);
     else snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);
     return UAPS_OK;

@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include "conv_kernels.hpp"
 #include "conv_split_wrw.hpp"
+#include "conv_small.hpp"
 #include "hints.hpp"
 using namespace uaps;
 
@@ -12,7 +13,7 @@ namespace {
 
 // wave arrangement: (WCO, WCI) 16-channel blocks per workgroup, the remaining factor of 4 splits the tile rows
 // split: the bf16-split kernels of conv_split_wrw.hpp (3x3, no dilation, 16-byte rows, >= 16 input channels)
-struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; bool split; };
+struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; bool split, small; };
 
 WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     WrwPlan p{};
@@ -20,6 +21,17 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     const bool force_exact = (cfg >> 28) & 1, force_split = (cfg >> 29) & 1;
     cfg &= 0xffffff;
     p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() >= 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
+    // <= 4 output channels x 16 input channels on a wide map: the exact-N VALU kernel (conv_small.hpp), slabs [tap][4][16]
+    p.small = ks == 3 && p.dil == 1 && W % 4 == 0 && W >= 64 && Cout <= 4 && Cin == 16 && !force_exact && !force_split;
+    if (p.small) {
+        p.split = false;
+        p.wco = p.wci = 1; p.TH = 8; p.TW = 64; p.ncob = p.ncib = 1; p.CoutS = 4; p.CinS = 16;
+        p.tiles = (long)B * ((H + p.TH - 1) / p.TH) * ((W + p.TW - 1) / p.TW);
+        long want = cfg > 0 ? cfg : 512;
+        if (want > p.tiles) want = p.tiles;
+        p.nsplit = (int)(want < 1 ? 1 : want);
+        return p;
+    }
     if (p.split) {
         p.wco = Cout > 16 ? 2 : 1; p.wci = Cin > 16 ? 2 : 1;
         p.TH = 4; p.TW = 32;
@@ -132,7 +144,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     const int taps = ks * ks;
     WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg, ks);
     const bool vec16 = (W % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && (!x2 || (uintptr_t)x2 % 16 == 0);
-    if (p.split && !vec16) return UAPS_ERANGE;      // the split kernels stream 16-byte pieces (W % 4 == 0 is part of the plan; pass cfg bit 28 for odd pointers)
+    if ((p.split || p.small) && !vec16) return UAPS_ERANGE;      // the split kernels stream 16-byte pieces (W % 4 == 0 is part of the plan; pass cfg bit 28 for odd pointers)
     if (p.dil != 1 && (ks != 3 || (p.dil != 2 && p.dil != 4))) return UAPS_ERANGE;
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
     ConvWrwArgs a{};
@@ -144,6 +156,13 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
+    if (p.small) {
+        if (x2) return UAPS_EINVAL;
+        const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
+        if (a.xf) hipLaunchKernelGGL(conv_small_wrw_bn_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
+        else hipLaunchKernelGGL(conv_small_wrw_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (p.split) {
         // mode 2 and every tensor operand bounded (uaps_next_call_hints: 0 = dy, 1 = x, 2 = x2): the two-piece fp16 form
         if (uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1] && (!x2 || Csplit >= Cin || hints.bound[2])) {
@@ -210,7 +229,8 @@ extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, 
 extern "C" int uaps_conv_wrw_variant(int B, int Cin, int Cout, int H, int W, int ks, int cfg, char* buf, size_t buflen) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || !buf || buflen < 64) return UAPS_EINVAL;
     const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg, ks);
-    if (p.split) snprintf(buf, buflen, "conv_swrw_kernel<%d, %d, %d>", p.TH, p.wco, p.wci);
+    if (p.small) snprintf(buf, buflen, "conv_small_wrw_kernel");
+    else if (p.split) snprintf(buf, buflen, "conv_swrw_kernel<%d, %d, %d>", p.TH, p.wco, p.wci);
     else snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1, p.dil);
     return UAPS_OK;
 }
