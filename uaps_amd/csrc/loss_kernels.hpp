@@ -564,7 +564,7 @@ static __global__ __launch_bounds__(kFinalizeThreads) void pair_finalize_sums_ke
 // F2: unsupervised backward.  Bytes per pixel: 4DC + 8 read, 4DC written.
 // --------------------------------------------------------------------------------------------------
 // N: the pixel count the loss was averaged over (local batch, or the gathered global batch)
-template <int D, int C, int VEC>
+template <int D, int C, int VEC, bool TRACK = false>
 __device__ __forceinline__ void unsup_bwd_body(const HeadPtrs<D>& z, const HeadOutPtrs<D>& dz, int HW, long ngroups, long N,
                                                const int64_t* __restrict__ pseudo,
                                                const float* __restrict__ sc, float cw1, float cw2,
@@ -644,7 +644,7 @@ __device__ __forceinline__ void unsup_bwd_body(const HeadPtrs<D>& z, const HeadO
                                    - gk[j] * (m[c] - p[j][c])
                                    + p[j][c] * (h[c] - ph);
                     zv[j][c][v] = gr;
-                    am = fmaxf(am, fabsf(gr));
+                    if constexpr (TRACK) am = fmaxf(am, fabsf(gr));
                 }
             }
         }
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kThreads) void unsup_bwd_kernel(HeadPtrs<D> z, Head
 // --------------------------------------------------------------------------------------------------
 // F3 backward.  Bytes per pixel: 4DC + 8 read, 4DC written.
 // --------------------------------------------------------------------------------------------------
-template <int D, int C, int VEC>
+template <int D, int C, int VEC, bool TRACK = false>
 __device__ __forceinline__ void sup_bwd_body(const HeadPtrs<D>& z, const HeadOutPtrs<D>& dz, int HW, long ngroups, long N,
                                              const int64_t* __restrict__ labels,
                                              const float* __restrict__ sc, float ce_coef,
@@ -703,7 +703,7 @@ __device__ __forceinline__ void sup_bwd_body(const HeadPtrs<D>& z, const HeadOut
                 for (int c = 0; c < C; ++c) {
                     const float oh = (y == c) ? 1.f : 0.f;
                     zv[c][v] = gce * (p[c] - oh) + gdc * p[c] * (a[c] - pa);
-                    am = fmaxf(am, fabsf(zv[c][v]));
+                    if constexpr (TRACK) am = fmaxf(am, fabsf(zv[c][v]));
                 }
             }
 #pragma unroll
@@ -749,7 +749,8 @@ __global__ __launch_bounds__(kThreads, MINW) void pair_fwd_kernel(HeadPtrs<D> zl
     }
 }
 // Nloss: the pixel count the scalars were finalised with (= N, or the global count after an exchange of the sums)
-template <int D, int C, int VS, int VU>
+// TRACK: also raise *amax_out to max|gradient element| (uaps_call_hints::out_amax; costs ~17 us of VALU work at 16 + 16 images)
+template <int D, int C, int VS, int VU, bool TRACK = false>
 __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(HeadPtrs<D> zl, HeadPtrs<D> zu, HeadOutPtrs<D> dl, HeadOutPtrs<D> du, int HW,
                                                             long N, long Nloss, const int64_t* __restrict__ labels,
                                                             const int64_t* __restrict__ pseudo, const float* __restrict__ sscal,
@@ -758,9 +759,9 @@ __global__ __launch_bounds__(kThreads) void pair_bwd_kernel(HeadPtrs<D> zl, Head
                                                             const uint32_t* __restrict__ st, float* __restrict__ amax_out) {
     cw1 = step_f(st, kStepCw1, cw1); cw2 = step_f(st, kStepCw2, cw2);
     float am = 0.f;                              // max|gradient element| written by this thread (uaps_call_hints::out_amax)
-    if ((int)blockIdx.x < nb_s) sup_bwd_body<D, C, VS>(zl, dl, HW, N / VS, Nloss, labels, sscal, ce_coef, dice_coef, gscale, (int)blockIdx.x, nb_s, am);
-    else unsup_bwd_body<D, C, VU>(zu, du, HW, N / VU, Nloss, pseudo, uscal, cw1, cw2, gscale, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s, am);
-    if (amax_out) {                              // uniform branch
+    if ((int)blockIdx.x < nb_s) sup_bwd_body<D, C, VS, TRACK>(zl, dl, HW, N / VS, Nloss, labels, sscal, ce_coef, dice_coef, gscale, (int)blockIdx.x, nb_s, am);
+    else unsup_bwd_body<D, C, VU, TRACK>(zu, du, HW, N / VU, Nloss, pseudo, uscal, cw1, cw2, gscale, (int)blockIdx.x - nb_s, (int)gridDim.x - nb_s, am);
+    if (TRACK && amax_out) {                              // uniform branch
         __shared__ float sm[16];
         block_amax_to(amax_out, am, sm);
     }

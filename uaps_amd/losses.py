@@ -345,7 +345,10 @@ class _PairLoss(torch.autograd.Function):
             dlab_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz[:D]])
             dun_p = (C.c_void_p * D)(*[z.data_ptr() for z in dz[D:]])
         from . import bounds
-        am = bounds.new_amax(dev) if bounds.enabled() else None      # max|d logits|: operand bound of out_conv's weight gradient
+        # max|d logits|: operand bound of out_conv's weight gradient -- only where that runs on the matrix core: with <= 4 classes
+        # on >= 64-pixel-wide maps it is the exact-N fp32 kernel (csrc/conv_small.hpp), which needs no bound, and the
+        # tracking costs the backward kernel 17 us of VALU work (53 -> 70 us at 16 + 16 images of 256 x 256)
+        am = bounds.new_amax(dev) if bounds.enabled() and not (Cc <= 4 and W >= 64 and W % 4 == 0) else None
         with _lib.device_guard(dev), _timed("uaps_pair_bwd"):
             if am is not None:
                 _lib.hints((), am)
