@@ -49,10 +49,15 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--cfg-sweep", action="store_true")
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--mode", default="h16", choices=["h16", "split", "exact"],
+                    help="convolution arithmetic (uaps_amd.conv.set_mode); h16 passes the operands' magnitude bounds like the step does")
     ap.add_argument("--lds-sweep", action="store_true", help="forward kernel with 0..56 KB of extra (unused) LDS = fewer workgroups per CU")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
+    C.set_mode(args.mode)
+    from uaps_amd import bounds
+    bnd = (lambda t: (bounds.from_value(t.abs().max()), 1.0)) if args.mode == "h16" else (lambda t: None)
     tot = {k: 0.0 for k in ("fwd", "bwd", "wrw", "mfwd", "mbwd", "mwrw")}
     print(f"{'layer':28s} {'GF':>6s} | {'fwd us':>8s} {'TF/s':>6s} {'miopen':>8s} | {'bwdD us':>8s} {'TF/s':>6s} {'miopen':>8s} | {'wrw us':>8s} {'TF/s':>6s} {'miopen':>8s}")
     for name, Cin, Cout, HW, ks, calls in LAYERS:
@@ -63,9 +68,10 @@ def main():
         dy = torch.randn(B, Cout, HW, HW, device=dev)
         wf, wb = C.pack_weights(w)
         gf = 2.0 * B * HW * HW * Cin * Cout * ks * ks / 1e9
-        t_f = timeit(lambda: C.conv_fwd_raw(x, wf, None, Cout, ks))
-        t_b = timeit(lambda: C.conv_bwd_data_raw(dy, wb, Cin, ks))
-        t_w = timeit(lambda: C.conv_bwd_weight_raw(dy, x, ks, False))
+        xb, dyb = bnd(x), bnd(dy)
+        t_f = timeit(lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, xb=xb))
+        t_b = timeit(lambda: C.conv_bwd_data_raw(dy, wb, Cin, ks, dyb=dyb))
+        t_w = timeit(lambda: C.conv_bwd_weight_raw(dy, x, ks, False, dyb=dyb, xb=xb))
         m_f = timeit(lambda: F.conv2d(x, w, None, padding=ks // 2))
         m_b = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [ks // 2] * 2, [1, 1], False, [0, 0], 1, [True, False, False]))
         m_w = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [ks // 2] * 2, [1, 1], False, [0, 0], 1, [False, True, False]))
