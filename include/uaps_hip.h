@@ -330,7 +330,8 @@ int uaps_bn_param_bounds(const float* const* gamma_host, const float* const* bet
 int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above; process-wide, not stream-ordered: set it between steps */
 
 /* One-shot side arguments for the NEXT kernel entry point called on this thread; that call consumes and clears them
- * (every convolution entry point, uaps_bn_act_bwd*, uaps_pairloss_bwd and uaps_upsample2x do; NULL clears).
+ * (every convolution entry point, uaps_bn_act_fwd_train_partials, uaps_bn_finalize_train, uaps_bn_act_bwd*,
+ * uaps_pairloss_bwd and uaps_up_cat_fwd do; NULL clears).
  *   bound[i], mul[i]  device bound b and host factor m > 0 with |operand i| <= value(b) * m for every element; NULL = unknown.
  *                     A bound is UAPS_BOUND_FLOATS floats (16-byte aligned): value(b) = max over the UAPS_BOUND_SLOTS
  *                     floats b[k * UAPS_BOUND_STRIDE], the rest is padding -- the producing kernels raise the slots with
@@ -340,6 +341,13 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above; process-wide, not 
  *                     In mode 2 a 3x3 convolution whose tensor operands all carry a bound runs in the two-piece fp16 form;
  *                     without bounds it runs as in mode 1.  A bound that is too small makes the result wrong (fp16
  *                     overflow), one that is too large by up to 2^10 costs no accuracy.
+ *   stats_mean, stats_bias   per-channel device arrays [Cout] (either may be NULL = 0): a convolution that writes BatchNorm
+ *                     partial sums (uaps_conv_fwd_stats, the stats output of uaps_conv_fwd_bn / _cat) forms them about the
+ *                     shift s_c = stats_mean[c] - stats_bias[c], i.e. sum(v - s), sum((v - s)^2) -- pass the BatchNorm's
+ *                     running_mean and the bias of the convolution in front of it, and the variance E[d^2] - E[d]^2 no
+ *                     longer cancels for channels with |mean| >> std (fp32 partial sums).  The call that CONSUMES those
+ *                     partials (uaps_bn_act_fwd_train_partials, uaps_bn_finalize_train) must be given the same two
+ *                     pointers in its own hints; it reads them before it updates running_mean.
  *   out_amax          a bound (UAPS_BOUND_FLOATS floats, zero-initialised by the caller) whose slots the producing kernel raises
  *                     atomically so that value(out_amax) = maximum |element| of its output tensor: the bound of a later
  *                     convolution's operand. */
@@ -350,6 +358,8 @@ typedef struct uaps_call_hints {
     const float* bound[3];
     float mul[3];
     float* out_amax;
+    const float* stats_mean;     /* see below */
+    const float* stats_bias;
 } uaps_call_hints;
 int uaps_next_call_hints(const uaps_call_hints* hints);
 int uaps_conv_get_mode(void);

@@ -137,14 +137,17 @@ def test_upsample2x_vs_torch_and_gather_kernel(B, Cl, h, w):
 
 @pytest.mark.parametrize("in_chns,C,n_aux,H,W", [(3, 4, 3, 32, 32), (1, 7, 3, 48, 80), (1, 2, 5, 64, 64)],
                          ids=["neu", "dagm_7class_partial_tiles", "k5_2class"])
-def test_forward_pair_equals_two_forwards(in_chns, C, n_aux, H, W):
+def test_forward_pair_equals_two_forwards(in_chns, C, n_aux, H, W, monkeypatch):
     """UNet_UAPS.forward_pair (one pass over labelled+unlabelled, 2 BatchNorm statistics groups) must compute what
     the reference's two forwards compute (UAPS_train.py:177,185): same logits, same running statistics after the
     two successive updates, same loss and parameter gradients.  Randomness is switched off (dropout 0, identity
     perturbations) so the two routes are comparable."""
     import copy
     import uaps_amd
-    from uaps_amd import losses
+    from uaps_amd import losses, unet
+    # plain statistics sums: with the running-mean shift the second of two forwards sees an updated running mean, i.e. another
+    # rounding of the same batch statistics, and the two routes agree to a few ulp instead of bit for bit
+    monkeypatch.setattr(unet, "_STAT_SHIFT", False)
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
     m1 = uaps_amd.UNet_UAPS(in_chns, C, n_aux=n_aux, dropout=(0.0,) * 5).to(dev).train()
@@ -358,3 +361,34 @@ def test_fused_fan_out_forward_equals_the_per_perturbation_kernels(B, C, H, W, g
     for a, b in zip(res[0][0], res[1][0]):
         assert torch.equal(a, b)
     assert torch.equal(res[0][1], res[1][1])          # the backward re-applies the same masks / noise
+
+
+@pytest.mark.parametrize("epilogue", [True, False])
+def test_batchnorm_statistics_survive_a_large_channel_mean(epilogue):
+    """Train-mode BatchNorm on a conv output whose channel means are thousands of standard deviations: fp32 sums of y and y^2 lose
+    the variance to cancellation.  The partial sums (conv epilogue, or the kernel's own statistics pass) are formed about
+    running_mean - conv_bias, so a BatchNorm whose running mean tracks the data (any trained checkpoint) normalises correctly."""
+    from uaps_amd import conv, fused
+    torch.manual_seed(3)
+    B, Cc, H, W = 4, 16, 64, 64
+    x = (1.0 + 1e-3 * torch.randn(B, Cc, H, W)).to(DEV)
+    w = (0.5 + 0.1 * torch.rand(Cc, Cc, 1, 1)).to(DEV)                  # 1x1: no zero-padding border in the statistics
+    bn = torch.nn.BatchNorm2d(Cc).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    y_ref = F.conv2d(x.double().cpu(), w.double().cpu())
+    mean, var = y_ref.mean((0, 2, 3)), y_ref.var((0, 2, 3), unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 2e3                 # the regime this test is about
+    with torch.no_grad():
+        bn.running_mean.copy_(mean.float() * (1 + 1e-4))                 # a running mean that tracks the data, not exactly
+    if epilogue:
+        y, st = conv.conv2d_with_stats(x, w, None, stat_shift=(bn.running_mean, None))
+        out = fused.bn_act(y, None, bn, 1.0, 0.0, True, st)              # slope 1: plain BatchNorm
+    else:
+        y = conv.conv2d(x, w, None)
+        out = fused.bn_act(y, None, bn, 1.0, 0.0, True)
+    yd = y.double().cpu()                                               # normalise the kernel's own fp32 y in float64
+    m2, v2 = yd.mean((0, 2, 3), keepdim=True), yd.var((0, 2, 3), unbiased=False, keepdim=True)
+    ref = (yd - m2) / torch.sqrt(v2 + bn.eps) * bn.weight.double().cpu().view(1, -1, 1, 1) + bn.bias.double().cpu().view(1, -1, 1, 1)
+    err = float((out.double().cpu() - ref).abs().max())
+    assert err < 5e-3, err

@@ -147,12 +147,19 @@ def lib() -> C.CDLL:
 
 class CallHints(C.Structure):
     """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
-    _fields_ = [("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p)]
+    _fields_ = [("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
+                ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p)]
 
 
-def hints(bounds=(), out_amax=None) -> None:
-    """bounds: up to three (1-element device tensor, host factor) pairs or None; out_amax: a zeroed 1-element device tensor."""
+def hints(bounds=(), out_amax=None, stats=None) -> None:
+    """bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
+    None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about."""
     h = CallHints()
+    if stats is not None:
+        if stats[0] is not None:
+            h.stats_mean = stats[0].data_ptr()
+        if stats[1] is not None:
+            h.stats_bias = stats[1].data_ptr()
     for i, b in enumerate(bounds):
         if b is not None:
             h.bound[i], h.mul[i] = b[0].data_ptr(), float(b[1])

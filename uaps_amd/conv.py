@@ -218,7 +218,7 @@ def _h16(*bs) -> bool:
 
 
 def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ks: int, cfg: int = 0,
-                 want_stats: bool = False, xb=None):
+                 want_stats: bool = False, xb=None, stat_shift=None):
     """y = conv(x); with want_stats also the per-tile (sum, sum of squares) of y as float2 [Cout][B][parts_per_image]
     (the first pass of the BatchNorm that follows), returned as (y, stats, parts_per_image)."""
     B, Cin, H, W = x.shape
@@ -229,8 +229,8 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
     with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb), want_stats):
-        if xb is not None:
-            _lib.hints((xb,))
+        if xb is not None or (want_stats and stat_shift is not None):
+            _lib.hints((xb,), None, stat_shift if want_stats else None)
         if want_stats:
             rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
                                        _lib.current_stream(x.device))
@@ -287,7 +287,7 @@ def _dil_cfg(dilation: int) -> int:
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, want_stats=False, dilation=1):
+    def forward(ctx, x, weight, bias, want_stats=False, dilation=1, stat_shift=None):
         _lib.require_device(x, "conv2d")
         ctx.set_materialize_grads(False)          # no zero tensors for the unused gradient of `stats`
         if x.dtype != torch.float32 or weight.dtype != torch.float32:
@@ -304,7 +304,8 @@ class _Conv2d(torch.autograd.Function):
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
         ctx.xb = xb = bounds.get(x)
         if want_stats:
-            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True, xb=xb)
+            y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True, xb=xb, stat_shift=stat_shift)
+            stats._uaps_shifted = stat_shift is not None
             ctx.mark_non_differentiable(stats)
             return y, stats
         return conv_fwd_raw(x, wf, bias, Cout, ks, cfg, xb=xb)
@@ -312,7 +313,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         x, wb = ctx.saved_tensors
         Cin, Cout, ks, has_bias, cfg = ctx.meta
         dyb = bounds.get(dy)
@@ -321,7 +322,7 @@ class _Conv2d(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1) -> torch.Tensor:
@@ -330,10 +331,20 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _Conv2d.apply(x, weight, bias, False, dilation)
 
 
-def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1):
+def _mark(res, shifted):
+    # the statistics tensor remembers whether its sums are taken about a shift (fused.bn_act / bn_act_conv must tell the finalize)
+    res[1]._uaps_shifted = shifted
+    return res
+
+
+def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, dilation: int = 1,
+                      stat_shift=None):
     """conv2d that also returns the per-tile (sum, sum of squares) of its output, float32 [Cout, B, parts, 2], for
-    fused.bn_act(..., stats=...): the BatchNorm statistics pass rides in the convolution's epilogue."""
-    return _Conv2d.apply(x, weight, bias, True, dilation)
+    fused.bn_act(..., stats=...): the BatchNorm statistics pass rides in the convolution's epilogue.
+    stat_shift = (bn.running_mean or None, the conv bias that BatchNorm will add or None): the sums are then taken about
+    running_mean - bias per channel (no cancellation in the variance of channels with |mean| >> std); hand the result to
+    bn_act / bn_act_conv of that same BatchNorm."""
+    return _mark(_Conv2d.apply(x, weight, bias, True, dilation, stat_shift), stat_shift is not None)
 
 
 class _Conv2dCat(torch.autograd.Function):
@@ -341,7 +352,7 @@ class _Conv2dCat(torch.autograd.Function):
     UAPS_unet.py:84-85): the kernels read the two tensors, the input gradient comes back as two tensors."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, want_stats):
+    def forward(ctx, x1, x2, weight, bias, want_stats, stat_shift=None):
         _lib.require_device(x1, "conv2d_cat")
         ctx.set_materialize_grads(False)
         x1, x2 = x1.contiguous(), x2.contiguous()
@@ -361,8 +372,8 @@ class _Conv2dCat(torch.autograd.Function):
         b1, b2 = bounds.get(x1), bounds.get(x2)
         ctx.xb = (b1, b2)
         with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0, _h16(b1, b2)):
-            if b1 is not None and b2 is not None:
-                _lib.hints((b1, b2))
+            if (b1 is not None and b2 is not None) or (want_stats and stat_shift is not None):
+                _lib.hints((b1, b2) if (b1 is not None and b2 is not None) else (), None, stat_shift if want_stats else None)
             rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
                                               bias.data_ptr() if bias is not None else None, y.data_ptr(),
                                               stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, 0, _lib.current_stream(dev))
@@ -378,7 +389,7 @@ class _Conv2dCat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         x1, x2, wb = ctx.saved_tensors
         C1, C2, Cout, ks, has_bias = ctx.meta
         dyb = bounds.get(dy)
@@ -415,13 +426,15 @@ class _Conv2dCat(torch.autograd.Function):
                 rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
                                                    H, W, ks, 0, st)
                 _lib.check(rc, "uaps_conv_bwd_weight_reduce")
-        return dx1, dx2, dw, db, None
+        return dx1, dx2, dw, db, None, None
 
 
 def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               with_stats: bool = False):
-    """F.conv2d(torch.cat([x1, x2], 1), weight, bias, padding=k//2) reading the two tensors in place."""
-    return _Conv2dCat.apply(x1, x2, weight, bias, with_stats)
+               with_stats: bool = False, stat_shift=None):
+    """F.conv2d(torch.cat([x1, x2], 1), weight, bias, padding=k//2) reading the two tensors in place (stat_shift: see
+    conv2d_with_stats)."""
+    res = _Conv2dCat.apply(x1, x2, weight, bias, with_stats, stat_shift)
+    return _mark(res, stat_shift is not None) if with_stats else res
 
 
 # ---- general strided convolutions + the stem max-pool (csrc/conv_strided.hip) --------------------------------------------------

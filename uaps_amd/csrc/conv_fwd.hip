@@ -220,7 +220,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     if (!p.vec || (Csplit < Cin && Csplit % p.sck)) p.split = false;      // unaligned tensors / odd concat split: exact kernels
     ConvFwdArgs a{};
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
-    a.wp = wp; a.bias = bias; a.out = y; a.stats = stats; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    a.wp = wp; a.bias = bias; a.out = y; a.stats = stats;
+    if (stats) { a.stats_mean = hints.stats_mean; a.stats_bias = hints.stats_bias; } a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool wide = p.tw == 32;

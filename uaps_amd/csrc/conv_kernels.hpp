@@ -128,6 +128,10 @@ struct ConvFwdArgs {
     float* out2;        // [B, Cout - Osplit, H, W] or nullptr
     int Csplit, Osplit;
     float2* stats;      // optional [Cout][B][tiles_y*tiles_x] per-tile (sum, sum of squares) of the output, or nullptr
+    // the sums are formed about a per-channel shift s = stats_mean[c] - stats_bias[c] (either may be null = 0): sum(v - s),
+    // sum((v - s)^2) -- with s near the channel mean (the BatchNorm's running mean minus the conv bias) the variance
+    // E[d^2] - E[d]^2 does not cancel when |mean| >> std; the consumer of the partials must be given the same pointers
+    const float* stats_mean; const float* stats_bias;
     int B, Cin, Cout, H, W;
     int CinP, CoutP;
     int tiles_x, tiles_y, nblk;
@@ -143,6 +147,11 @@ struct ConvFwdArgs {
     const float* in_bound; const float* in2_bound; const float* wscale;
     float in_mul, in2_mul;
 };
+
+__device__ __forceinline__ float stats_shift(const ConvFwdArgs& a, int co, bool co_ok) {
+    if (!co_ok || a.stats == nullptr) return 0.f;
+    return (a.stats_mean ? a.stats_mean[co] : 0.f) - (a.stats_bias ? a.stats_bias[co] : 0.f);
+}
 
 template <int KS, int TH, int TW, int BN, int CK, int VEC, int DIL, bool XF>
 __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
@@ -308,6 +317,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
         const int co = co0 + n * 16 + j;
         const bool co_ok = co < a.Cout;
         const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+        const float sh = stats_shift(a, co, co_ok);
         const int coc = co_ok ? co : 0;
         float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
                                       : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
@@ -322,11 +332,11 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
             if (VEC == 4) {                       // W % 4 == 0: the 4 pixels are all inside or all outside
                 const bool ok = row_ok && gx < a.W;
                 if (ok) *reinterpret_cast<f32x4*>(p) = v;
-                if (ok) { st_s[n] += (v.x + v.y) + (v.z + v.w); st_q[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w); }
+                if (ok) { const f32x4 d = v - sh; st_s[n] += (d.x + d.y) + (d.z + d.w); st_q[n] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (row_ok && gx + r < a.W) { p[r] = v[r]; st_s[n] += v[r]; st_q[n] += v[r] * v[r]; }
+                    if (row_ok && gx + r < a.W) { p[r] = v[r]; const float d = v[r] - sh; st_s[n] += d; st_q[n] += d * d; }
             }
         }
     }

@@ -300,6 +300,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
         const int co = co0 + n * 16 + j;
         const bool co_ok = co < a.Cout;
         const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+        const float sh = stats_shift(a, co, co_ok);
         const int coc = co_ok ? co : 0;
         float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
                                       : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
@@ -313,8 +314,9 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
             const bool ok = co_ok && gy < a.H && gx < a.W;      // W % 4 == 0: the 4 pixels are all inside or all outside
             if (ok) {
                 *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
-                st_s[n] += (v.x + v.y) + (v.z + v.w);
-                st_q[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                const f32x4 d = v - sh;
+                st_s[n] += (d.x + d.y) + (d.z + d.w);
+                st_q[n] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
     }
@@ -564,6 +566,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         const int co = co0 + n * 32 + r;
         const bool co_ok = co < a.Cout;
         const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+        const float sh = stats_shift(a, co, co_ok);
         const int coc = co_ok ? co : 0;
         float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
                                       : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
@@ -578,8 +581,9 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
                 v += bv;
                 if (co_ok && gy < a.H && gx < a.W) {
                     *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
-                    st_s[n] += (v.x + v.y) + (v.z + v.w);
-                    st_q[n] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    const f32x4 d = v - sh;
+                    st_s[n] += (d.x + d.y) + (d.z + d.w);
+                    st_q[n] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
                 }
             }
         }

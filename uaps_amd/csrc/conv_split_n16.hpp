@@ -57,6 +57,7 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
     const int co = j;
     const bool co_ok = co < a.Cout;
     const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+    const float sh = stats_shift(a, co, co_ok);
 
     // ---- staging units: 4 consecutive pixels x the 8 channels of one channel group ----
     int ucg[NU], ur[NU], ucu[NU], uloff[NU];
@@ -182,8 +183,9 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
             v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             if (co_ok && gy < a.H && gx < a.W) {      // W % 4 == 0: the 4 pixels are all inside or all outside
                 *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
-                st_s += (v.x + v.y) + (v.z + v.w);
-                st_q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                const f32x4 d = v - sh;
+                st_s += (d.x + d.y) + (d.z + d.w);
+                st_q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
         if (a.stats != nullptr) {

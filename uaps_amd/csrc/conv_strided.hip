@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void convs_fwd_kernel(SConvArgs a, int tiles_x
                 const int ci = c0 + kq;
                 const float av = (okx && ci < a.Cin) ? xp[(size_t)ci * HW] : 0.f;
 #pragma unroll
-                for (int n = 0; n < NW; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(size_t)ci * a.CoutP + n * 16], acc[n], 0, 0, 0);
+                for (int n = 0; n < NW; ++n)          // a channel block past CoutP (CoutP not a multiple of 16 NW) re-reads block 0: never stored
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(size_t)ci * a.CoutP + (co0 + n * 16 < a.CoutP ? n * 16 : 0)], acc[n], 0, 0, 0);
             }
         }
     }
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void convs_bwd_data_kernel(SConvArgs a, int ti
                 const int co = c0 + kq;
                 const float av = (okx && co < a.Cout) ? dp[(size_t)co * OHW] : 0.f;
 #pragma unroll
-                for (int n = 0; n < NW; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(size_t)co * a.CinP + n * 16], acc[n], 0, 0, 0);
+                for (int n = 0; n < NW; ++n)          // as in the forward: blocks past CinP re-read block 0 and are never stored
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wrow[(size_t)co * a.CinP + (ci0 + n * 16 < a.CinP ? n * 16 : 0)], acc[n], 0, 0, 0);
             }
         }
     }

@@ -51,20 +51,24 @@ __device__ __forceinline__ float2 block_sum2(float a, float b) {
 // ---- forward pass 1: per-chunk (sum, sum of squares) ------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float* __restrict__ y, int C, long HW, int nchunks,
-                                                            float2* __restrict__ partials) {
+                                                            float2* __restrict__ partials, const float* __restrict__ shift_mean,
+                                                            const float* __restrict__ shift_bias) {
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C;
     const float* p = y + (long)plane * HW;
     const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    // sums about the channel's shift (running mean minus conv bias): no cancellation in E[d^2] - E[d]^2 when |mean| >> std
+    const float sh = (shift_mean ? shift_mean[c] : 0.f) - (shift_bias ? shift_bias[c] : 0.f);
     float s = 0.f, ss = 0.f;
     if (VEC) {
         for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
-            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            float4 v = *reinterpret_cast<const float4*>(p + i);
+            v.x -= sh; v.y -= sh; v.z -= sh; v.w -= sh;
             s += (v.x + v.y) + (v.z + v.w);
             ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
     } else {
-        for (long i = lo + threadIdx.x; i < hi; i += kThreads) { const float v = p[i]; s += v; ss += v * v; }
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) { const float v = p[i] - sh; s += v; ss += v * v; }
     }
     const float2 r = block_sum2(s, ss);
     if (threadIdx.x == 0) partials[((long)c * gridDim.y / C + b) * nchunks + chunk] = r;
@@ -82,9 +86,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd(const float2* __restrict
                                                         float* __restrict__ running_var, int64_t* __restrict__ nbt,
                                                         float momentum, float eps, float* __restrict__ save_mean,
                                                         float* __restrict__ save_invstd, float* __restrict__ coef, int C,
-                                                        float2* __restrict__ xf = nullptr) {
+                                                        float2* __restrict__ xf, const float* __restrict__ shift_mean,
+                                                        const float* __restrict__ shift_bias) {
     __shared__ double red[4][2][kThreads / 64];
     const int c = blockIdx.x, GP = blockDim.x / kThreads;
+    // the shift the partial sums were formed about; read by every thread before the first barrier, i.e. before thread 0
+    // updates running_mean (shift_mean may be running_mean itself)
+    const double sh = (double)(shift_mean ? shift_mean[c] : 0.f) - (double)(shift_bias ? shift_bias[c] : 0.f);
     const int slice = threadIdx.x / kThreads, t = threadIdx.x % kThreads, lane = t & 63, wave = t >> 6;
     const int G = B / Bg, nparts = Bg * nch;      // nparts reaches a few thousand when the partials come per conv tile
     const double M = (double)Bg * HW;
@@ -105,9 +113,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd(const float2* __restrict
                 const int gg = g0 + q;
                 s = (red[q][0][0] + red[q][0][1]) + (red[q][0][2] + red[q][0][3]);
                 ss = (red[q][1][0] + red[q][1][1]) + (red[q][1][2] + red[q][1][3]);
-                const double mean = s / M;
-                double var = ss / M - mean * mean;
+                const double dm = s / M;
+                double var = ss / M - dm * dm;
                 if (var < 0.0) var = 0.0;
+                const double mean = sh + dm;
                 const float invstd = (float)(1.0 / sqrt(var + (double)eps));
                 save_mean[gg * C + c] = (float)mean;
                 save_invstd[gg * C + c] = invstd;
@@ -368,6 +377,10 @@ static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_i
                                              float momentum, float eps, float slope, float drop_p, uint64_t seed, uint64_t offset,
                                              int B, int C, int H, int W, int groups, float* out, float* save_mean,
                                              float* save_invstd, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    const uaps_call_hints hints = uaps::take_hints();
+    // given partials: formed about the shift the caller names; own statistics pass: about running_mean - conv_bias
+    const float* shm = given_partials ? hints.stats_mean : running_mean;
+    const float* shb = given_partials ? hints.stats_bias : conv_bias;
     int rc = check(y, out, B, C, H, W);
     if (rc) return rc;
     if (!gamma || !beta || !save_mean || !save_invstd || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
@@ -380,12 +393,12 @@ static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_i
     const dim3 grid(nch, B * C);
     const bool vec = (HW % 4 == 0) && al16(y) && al16(out);
     if (!given_partials) {
-        if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
-        else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials);
+        if (vec) hipLaunchKernelGGL(bn_stats_kernel<true>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials, shm, shb);
+        else hipLaunchKernelGGL(bn_stats_kernel<false>, grid, dim3(kThreads), 0, s, y, C, HW, nch, w.partials, shm, shb);
     }
     hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads * (groups < 4 ? groups : 4)), 0, s, given_partials ? given_partials : w.partials, B, Bg,
                        given_partials ? given_parts_per_image : nch, (double)HW, conv_bias, gamma, beta, running_mean,
-                       running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C);
+                       running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C, (float2*)nullptr, shm, shb);
     const float dscale = 1.f / (1.f - drop_p);
 #define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state())
     if (vec) { if (drop_p > 0.f) UAPS_APPLY(true, true); else UAPS_APPLY(true, false); }
@@ -424,11 +437,12 @@ extern "C" int uaps_bn_finalize_train(const void* partials, int parts_per_image,
                                       const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float momentum, float eps, int B, int C, int H, int W, int groups, float* save_mean,
                                       float* save_invstd, void* xf, uaps_stream_t stream) {
+    const uaps_call_hints hints = uaps::take_hints();
     if (!partials || parts_per_image <= 0 || !gamma || !beta || !save_mean || !save_invstd || !xf || ((uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
     hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads * (groups < 4 ? groups : 4)), 0, (hipStream_t)stream, (const float2*)partials, B, B / groups,
                        parts_per_image, (double)H * W, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked,
-                       momentum, eps, save_mean, save_invstd, (float*)nullptr, C, (float2*)xf);
+                       momentum, eps, save_mean, save_invstd, (float*)nullptr, C, (float2*)xf, hints.stats_mean, hints.stats_bias);
     return (int)hipGetLastError();
 }
 

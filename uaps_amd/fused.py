@@ -74,6 +74,8 @@ class _BnActTrain(torch.autograd.Function):
         else:
             fn, head = _lib.lib().uaps_bn_act_fwd_train_grouped, ()
         with _lib.device_guard(dev):
+            if stats_partials is not None and getattr(stats_partials, "_uaps_shifted", False):
+                _lib.hints((), None, (running_mean, conv_bias))      # the shift the producing conv formed its sums about
             rc = fn(
                 *head, y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
@@ -176,7 +178,7 @@ class _BnActConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, stats_partials, conv_bias, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, groups,
-                weight, bias, want_stats, xb=None):
+                weight, bias, want_stats, xb=None, stat_shift=None):
         from . import conv as _conv
         _lib.require_device(y, "bn_act_conv")
         ctx.set_materialize_grads(False)
@@ -200,6 +202,8 @@ class _BnActConv(torch.autograd.Function):
             zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
+            if getattr(stats_partials, "_uaps_shifted", False):
+                _lib.hints((), None, (running_mean, conv_bias))
             rc = L.uaps_bn_finalize_train(stats_partials.data_ptr(), int(stats_partials.shape[2]),
                                           conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(),
                                           beta.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
@@ -208,8 +212,8 @@ class _BnActConv(torch.autograd.Function):
                                           groups, stats[0].data_ptr(), stats[1].data_ptr(), xf.data_ptr(), st)
             _lib.check(rc, "uaps_bn_finalize_train")
             with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, 0, _conv._h16(xb)):
-                if xb is not None:
-                    _lib.hints((xb,))
+                if xb is not None or (want_stats and stat_shift is not None):
+                    _lib.hints((xb,), None, stat_shift if want_stats else None)
                 rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, z.data_ptr(),
                                         zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, 0, st)
@@ -219,6 +223,7 @@ class _BnActConv(torch.autograd.Function):
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
         ctx.xb = xb
         if want_stats:
+            zstats._uaps_shifted = stat_shift is not None
             ctx.mark_non_differentiable(zstats)
             return z, zstats
         return z
@@ -227,7 +232,7 @@ class _BnActConv(torch.autograd.Function):
     def backward(ctx, dz, *_unused):
         from . import conv as _conv
         if dz is None:
-            return (None,) * 16
+            return (None,) * 17
         y, gamma, beta, stats, xf, wb = ctx.saved_tensors
         slope, groups, has_cbias, has_bias, Cout, ks = ctx.meta
         dzb, xb = bounds.get(dz), ctx.xb
@@ -264,7 +269,7 @@ class _BnActConv(torch.autograd.Function):
                                                 dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), st)
             _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
         bounds.put(dy, am)
-        return dy, None, (dgb[2] if has_cbias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None, None
+        return dy, None, (dgb[2] if has_cbias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None, None, None
 
 
 def can_fuse_bn_into_conv(y: torch.Tensor, weight: torch.Tensor) -> bool:
@@ -273,13 +278,16 @@ def can_fuse_bn_into_conv(y: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, slope: float,
-                weight: torch.Tensor, bias: Optional[torch.Tensor], want_stats: bool = False):
+                weight: torch.Tensor, bias: Optional[torch.Tensor], want_stats: bool = False, stat_shift=None):
     """conv2d(leaky_relu(bn_train(y + conv_bias)), weight, bias) (+ the epilogue statistics of the result) where `y`,
     `stats` come from conv2d_with_stats: train-mode only, no dropout between the two (decoder ConvBlocks)."""
     mom = 0.1 if bn.momentum is None else bn.momentum
     xb = bounds.bn_output_bound(bn, y.shape[0] // STAT_GROUPS * y.shape[2] * y.shape[3]) if slope <= 1.0 else None
-    return _BnActConv.apply(y, stats, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                            mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats, xb)
+    res = _BnActConv.apply(y, stats, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                           mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats, xb, stat_shift)
+    if want_stats:
+        res[1]._uaps_shifted = stat_shift is not None
+    return res
 
 
 class _UpCat(torch.autograd.Function):

@@ -35,6 +35,10 @@ _FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
 # One HIP stream per auxiliary decoder (see UNet_UAPS.forward): +5 % images/s on the bench step, opt-in because kernels of
 # different decoders then overlap and per-launch timings (bench.py's roofline, rocprof averages) stop describing one kernel.
 _DECODER_STREAMS = os.environ.get("UAPS_DECODER_STREAMS", "0") != "0"
+# BatchNorm partial sums in the conv epilogues are taken about running_mean - conv bias (no variance cancellation for channels
+# with |mean| >> std).  Off: plain sums, as in round 1 -- then forward_pair and two successive forwards agree bit for bit (with
+# the shift the second forward already sees the running mean the first one updated: another rounding of the same statistics)
+_STAT_SHIFT = os.environ.get("UAPS_STAT_SHIFT", "1") != "0"
 
 
 class ConvBlock(nn.Module):
@@ -58,15 +62,18 @@ class ConvBlock(nn.Module):
         # fused kernel folds it into running_mean / the eval shift) + the fused BN+LeakyReLU+Dropout kernels
         c0, b0, _, d0, c1, b1, _ = self.conv_conv
         if self.training and _EPILOGUE_STATS:      # batch statistics: their first pass rides in the conv epilogue
-            y, st = conv.conv2d_with_stats(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None, True)
+            # the epilogue sums are taken about running_mean - conv bias of the BatchNorm they feed (no variance cancellation)
+            sh0, sh1 = ((b0.running_mean, c0.bias), (b1.running_mean, c1.bias)) if _STAT_SHIFT else (None, None)
+            y, st = (conv.conv2d_with_stats(x, c0.weight, None, stat_shift=sh0) if x2 is None
+                     else conv.conv2d_cat(x, x2, c0.weight, None, True, stat_shift=sh0))
             if d0.p == 0.0 and _FUSED_BN_CONV and fused.can_fuse_bn_into_conv(y, c1.weight):
                 # no dropout in between (decoder blocks): the second conv normalises + activates while staging its input
-                y, st = fused.bn_act_conv(y, st, c0.bias, b0, LEAKY_SLOPE, c1.weight, None, want_stats=True)
+                y, st = fused.bn_act_conv(y, st, c0.bias, b0, LEAKY_SLOPE, c1.weight, None, want_stats=True, stat_shift=sh1)
                 if lazy and y.shape[1] > 4:
                     return PendingBnAct(y, st, c1.bias, b1)
                 return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
             a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, True, st)
-            y, st = conv.conv2d_with_stats(a, c1.weight, None)
+            y, st = conv.conv2d_with_stats(a, c1.weight, None, stat_shift=sh1)
             return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
         y = conv.conv2d(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None)
         a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
