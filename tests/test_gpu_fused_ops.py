@@ -392,3 +392,25 @@ def test_batchnorm_statistics_survive_a_large_channel_mean(epilogue):
     ref = (yd - m2) / torch.sqrt(v2 + bn.eps) * bn.weight.double().cpu().view(1, -1, 1, 1) + bn.bias.double().cpu().view(1, -1, 1, 1)
     err = float((out.double().cpu() - ref).abs().max())
     assert err < 5e-3, err
+
+
+@pytest.mark.parametrize("n_aux", [6, 7])
+def test_more_than_five_auxiliary_decoders_run(n_aux):
+    """n_aux >= 6 cycles the three perturbations twice, i.e. two FeatureDropout decoders: the one-pass fan-out kernel carries one set
+    of thresholds, so these models take the per-perturbation kernels (decided before any random number is reserved).  Forward,
+    loss and backward must run and give finite logits and gradients for every head."""
+    import uaps_amd
+    from uaps_amd import losses
+    torch.manual_seed(n_aux)
+    m = uaps_amd.UNet_UAPS(3, 4, n_aux=n_aux, feature_chns=[8, 16, 16, 32, 32]).to(DEV).train()
+    B, H, W = 2, 32, 32
+    xa, xb = torch.randn(B, 3, H, W, device=DEV), torch.randn(B, 3, H, W, device=DEV)
+    y = torch.randint(0, 4, (B, H, W), device=DEV)
+    both = m.forward_pair(xa, xb)
+    assert len(both) == n_aux + 1 and all(z.shape == (2 * B, 4, H, W) and bool(torch.isfinite(z).all()) for z in both)
+    w = np.random.default_rng(1).dirichlet(np.ones(n_aux + 1))
+    out = losses.uaps_pair_loss(both, y, w, 0.05, 0.05)
+    out.loss.backward()
+    assert np.isfinite(float(out.loss))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert len({float(z.detach().abs().sum()) for z in both}) == n_aux + 1        # every head sees its own perturbed features

@@ -265,7 +265,8 @@ class UNet_UAPS(nn.Module):
             enc = self.encoder
             fans, f = [], enc.in_conv(x)
             for blk in (enc.down1, enc.down2, enc.down3, enc.down4, None):
-                pool = blk is not None and _FUSED_POOL and f.shape[2] % 2 == 0 and f.shape[3] % 8 == 0
+                # (the fan-in kernel sums at most 8 gradients: clean + n_aux perturbed + the pooled one)
+                pool = blk is not None and _FUSED_POOL and f.shape[2] % 2 == 0 and f.shape[3] % 8 == 0 and self.n_aux + 2 <= 8
                 fan = perturb.perturbed_fan_out(f, kinds, _groups, self._noise.uniform_range, with_pool=pool)
                 fans.append(fan)
                 if blk is not None:
