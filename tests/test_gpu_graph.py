@@ -133,3 +133,32 @@ def test_device_drawn_feature_dropout_threshold():
         perturb.DEVICE_THRESHOLDS = prev
         StepState.deactivate()
     assert not (torch.equal(brackets[0][0], brackets[1][0]) and torch.equal(brackets[0][1], brackets[1][1]))
+
+
+def test_validation_between_replays_leaves_the_captured_step_intact():
+    """An eval-mode forward between replays (UAPSTrainer.validate: other packed-weight buffers, no statistics groups, no bounds)
+    must neither disturb the graph nor read stale weights: the eager state-mode trainer doing the same sequence stays
+    bit-identical, and both validations agree."""
+    import uaps_amd
+    m0 = _model(8)
+    m1 = copy.deepcopy(m0)
+    m0.to(DEV), m1.to(DEV)
+    eager = uaps_amd.UAPSTrainer(m0, base_lr=1e-3, seed=5, step_state=True)
+    graph = uaps_amd.UAPSTrainer(m1, base_lr=1e-3, seed=5, use_graph=True)
+    batches = _batches(7, 2, 64, 64, seed=21)
+    val = [(b[0], b[1]) for b in _batches(2, 2, 64, 64, seed=22)]
+    vals = []
+    for i, (xl, y, xu) in enumerate(batches):
+        for tr in (eager, graph):
+            uaps_amd.perturb.manual_seed(5, 0)
+            np.random.seed(5)
+            tr.train_step(xl, y, xu)
+        if i in (3, 5):                               # after the capture (step 2) and between replays
+            vals.append((eager.validate(val), graph.validate(val)))
+    assert graph.step_graph.graph is not None
+    for ve, vg in vals:
+        assert ve == vg
+    for (n, pa), pb in zip(m0.named_parameters(), m1.parameters()):
+        assert torch.equal(pa, pb), n
+    for (n, ba), bb in zip(m0.named_buffers(), m1.buffers()):
+        assert torch.equal(ba, bb), n

@@ -27,7 +27,7 @@ from . import _lib
 ATTR = "_uaps_bound"
 Bound = Tuple[torch.Tensor, float]
 
-_pool = {}          # device index -> [chunk tensor, next free bound]
+_pool = {}          # (device index, stream) -> [chunk tensor, next free bound]
 _CHUNK = 64
 # a bound is FLOATS floats: SLOTS values STRIDE apart whose maximum counts (include/uaps_hip.h: UAPS_BOUND_*); the kernels that
 # raise it atomically spread their workgroups over the slots
@@ -55,9 +55,10 @@ def carry(src: torch.Tensor, dst: torch.Tensor, factor: float = 1.0) -> torch.Te
 
 def new_amax(dev: torch.device) -> torch.Tensor:
     """A zeroed device bound for uaps_call_hints::out_amax: a view into a chunk of zeros (one fill launch per 64 bounds)."""
-    ent = _pool.get(dev.index)
+    key = (dev.index, _lib.current_stream(dev))      # a chunk is zero-filled on, and handed out for, one stream
+    ent = _pool.get(key)
     if ent is None or ent[1] >= _CHUNK:
-        ent = _pool[dev.index] = [torch.zeros(_CHUNK * FLOATS, dtype=torch.float32, device=dev), 0]
+        ent = _pool[key] = [torch.zeros(_CHUNK * FLOATS, dtype=torch.float32, device=dev), 0]
     s = ent[0][ent[1] * FLOATS:(ent[1] + 1) * FLOATS]
     ent[1] += 1
     return s

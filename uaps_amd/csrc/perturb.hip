@@ -9,6 +9,16 @@
 using uaps::mul_rn; using uaps::add_rn; using uaps::U4; using uaps::philox4x32_10; using uaps::u01;
 
 namespace {
+// Zero-fill as a kernel of this library.  hipMemsetAsync in front of the atomics that accumulate into the same words is ordered
+// with them in a stream, but under hipGraph replay the FeatureDropout maxima were observed to differ from the eager step from
+// the third replay on (tools/diag/graph_val_debug.py): memset nodes and kernel nodes are different engines' work.
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+}  // namespace
+
+namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxBlocks = 2048;
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void fdrop_apply(const float* __restrict_
                                                         const float* __restrict__ att, const uint32_t* __restrict__ maxkey,
                                                         float u, uint8_t* __restrict__ keep) {
     const int b = blockIdx.y;
-    const float thr = mul_rn(fkey_inv(maxkey[b]), u);
+    const float thr = mul_rn(fkey_inv(__hip_atomic_load(maxkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), u);
     const float* xb = x + (long)b * C * HW;
     float* yb = y + (long)b * C * HW;
     for (long i = ((long)blockIdx.x * kThreads + threadIdx.x) * V; i < HW; i += (long)gridDim.x * kThreads * V) {
@@ -414,7 +424,9 @@ __global__ __launch_bounds__(kThreads) void fanout_perturbed_kernel(const float4
                 // threshold factor U(0.7, 0.9) (UAPS_unet.py:164): the host's draw, or -- a negative value asks for it -- one
                 // Philox draw per (call, statistics group) on the device (captured steps cannot take a new host number)
                 const float uf = a.u[grp] >= 0.f ? a.u[grp] : 0.7f + 0.2f * u01(philox4x32_10(a.off[k][grp], seed).x);
-                const float thr = mul_rn(fkey_inv(a.maxkey[b]), uf);
+                // agent-scope load: the maximum was raised by memory-side atomics of the previous kernel; a plain load may be served
+                // from a line this XCD's L2 still holds from the memset before them (seen under hipGraph replay)
+                const float thr = mul_rn(fkey_inv(__hip_atomic_load(a.maxkey + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), uf);
                 const float4 t = a.att[b * a.hw4 + pix];
                 const bool k0 = t.x < thr, k1 = t.y < thr, k2 = t.z < thr, k3 = t.w < thr;
                 if (ce < a.hw4) a.keep[k][b * a.hw4 + pix] = make_uchar4(k0, k1, k2, k3);      // channel 0 writes the mask
@@ -504,7 +516,8 @@ extern "C" int uaps_feat_dropout_fwd(const float* x, float* y, int B, int C, int
     const long HW = (long)H * W;
     uint32_t* maxkey = (uint32_t*)ws;
     float* att = (float*)((char*)ws + (((size_t)B * 4 + 255) / 256) * 256);
-    hipError_t e = hipMemsetAsync(maxkey, 0, (size_t)B * 4, s);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, maxkey, (long)B);      // a kernel, not hipMemsetAsync: see zero_words_kernel
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)keep % 4 == 0);
     int gx = grid_for(vec ? HW / 4 : HW); if ((long)gx * B > 4096) gx = (int)((4096 + B - 1) / B);
@@ -539,7 +552,8 @@ extern "C" int uaps_feat_dropout_stats(const float* x, int B, int C, int H, int 
     const long HW = (long)H * W;
     uint32_t* maxkey = (uint32_t*)ws;
     float* att = (float*)((char*)ws + (((size_t)B * 4 + 255) / 256) * 256);
-    hipError_t e = hipMemsetAsync(maxkey, 0, (size_t)B * 4, s);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, maxkey, (long)B);      // a kernel, not hipMemsetAsync: see zero_words_kernel
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0);
     if (vec && C >= 64 && C % 4 == 0 && HW <= 4096) {      // deep levels: split the channels over the waves of a block
@@ -642,7 +656,8 @@ extern "C" int uaps_seg_confusion(const float* logits, const int64_t* labels, in
     if (C < 1 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const long HW = (long)H * W, N = (long)B * HW;
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int64_t) * C * C, s);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((2 * C * C + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(counts), (long)2 * C * C);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(N) > 512 ? 512 : grid_for(N)), dim3(kThreads), 0, s, logits, labels, C, HW, N,
                        (unsigned long long*)counts);

@@ -7,8 +7,8 @@ Why: a step is ~450 kernel launches driven by ~9 ms of Python (autograd Function
 
 What changes per step can no longer travel in kernel arguments (a graph freezes them), so it lives in the device-resident
 *step state* (include/uaps_hip.h, uaps_set_step_state): the Philox key increment, the Dirichlet mixing weights, the two
-consistency weights and Adam's two step scalars.  The host refreshes a pinned mirror before every step; the upload is the first
-node of the graph.  `UAPSTrainer(step_state=True)` runs the same code path eagerly (bit-identical to the replay, which is
+consistency weights and Adam's two step scalars.  The host fills a slot of a ring of pinned mirrors before every step and enqueues its
+upload in front of the replay (stream-ordered).  `UAPSTrainer(step_state=True)` runs the same code path eagerly (bit-identical to the replay, which is
 how tests/test_gpu_graph.py pins the capture); `use_graph=True` adds the capture.  Single-process only (world size 1).
 """
 from __future__ import annotations
@@ -26,25 +26,41 @@ NAN = float("nan")
 
 
 class StepState:
-    """Pinned host mirror + device buffer of the 16-word step state."""
+    """Device buffer of the 16-word step state and a ring of pinned host mirrors.
+
+    The upload is asynchronous and the host runs steps ahead of the GPU (a replay costs it half a millisecond), so a single
+    pinned mirror would be overwritten for step n + 1 before the copy of step n has executed: every step fills its own ring
+    slot, and a slot is reused only after the event recorded behind its last copy has completed.  The copy is issued on the
+    step's stream in front of the replay -- it is not a node of the graph, whose source address would be fixed."""
+    RING = 8
 
     def __init__(self, device: torch.device):
-        self.host = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.hosts = [torch.zeros(16, dtype=torch.int32).pin_memory() for _ in range(self.RING)]
+        self.events = [None] * self.RING
+        self.slot = 0
         self.dev = torch.zeros(16, dtype=torch.int32, device=device)
-        self._u32 = self.host.numpy().view(np.uint32)
-        self._f32 = self.host.numpy().view(np.float32)
         self.key = 0
 
     def fill(self, w, cw1: float, cw2: float, adam_step_size: float, adam_inv_sqrt_bc2: float) -> None:
+        self.slot = (self.slot + 1) % self.RING
+        if self.events[self.slot] is not None:
+            self.events[self.slot].synchronize()          # RING steps ago: done long since
+        host = self.hosts[self.slot].numpy()
+        u32, f32 = host.view(np.uint32), host.view(np.float32)
         self.key = (self.key + _KEY_STEP) & 0xFFFFFFFFFFFFFFFF
-        self._u32[0], self._u32[1] = self.key & 0xFFFFFFFF, self.key >> 32
-        self._f32[2:10] = 0.0
-        self._f32[2:2 + len(w)] = np.asarray(w, dtype=np.float64).astype(np.float32)
-        self._f32[10], self._f32[11] = cw1, cw2
-        self._f32[12], self._f32[13] = adam_step_size, adam_inv_sqrt_bc2
+        u32[0], u32[1] = self.key & 0xFFFFFFFF, self.key >> 32
+        f32[2:10] = 0.0
+        f32[2:2 + len(w)] = np.asarray(w, dtype=np.float64).astype(np.float32)
+        f32[10], f32[11] = cw1, cw2
+        f32[12], f32[13] = adam_step_size, adam_inv_sqrt_bc2
 
     def upload(self) -> None:
-        self.dev.copy_(self.host, non_blocking=True)
+        """Enqueue the copy of the slot fill() wrote on the current stream (never inside a capture)."""
+        self.dev.copy_(self.hosts[self.slot], non_blocking=True)
+        ev = self.events[self.slot]
+        if ev is None:
+            ev = self.events[self.slot] = torch.cuda.Event()
+        ev.record()
 
     def activate(self) -> None:
         _lib.check(_lib.lib().uaps_set_step_state(self.dev.data_ptr()), "uaps_set_step_state")
@@ -117,6 +133,7 @@ class StepGraph:
             w, cw1, cw2 = self._refresh()
             if self.graph is not None and self._matches(x_l, y_l, x_u):
                 self._copy_in(x_l, y_l, x_u)
+                self.state.upload()                    # stream-ordered in front of the replay
                 self.graph.replay()
                 self._after_replay()
                 out, cm = self.static["out"], self.static["cm"]
@@ -163,7 +180,6 @@ class StepGraph:
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.state.upload()
             out, cm = self._body(self.static["x_l"], self.static["y_l"], self.static["x_u"])
         self.graph = g
         bounds.reset_pool()                          # eager code must not be handed scalars the replays re-zero
@@ -174,6 +190,7 @@ class StepGraph:
         opt = tr.optimizer
         steps = [opt.state[p]["step"] for gr in opt.param_groups for p in gr["params"] if p in opt.state]
         torch._foreach_add_(steps, -1)
+        self.state.upload()
         g.replay()
         self._after_replay()
         return out, cm
