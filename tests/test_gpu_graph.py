@@ -162,3 +162,32 @@ def test_validation_between_replays_leaves_the_captured_step_intact():
         assert torch.equal(pa, pb), n
     for (n, ba), bb in zip(m0.named_buffers(), m1.buffers()):
         assert torch.equal(ba, bb), n
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_long_unsynchronised_replay_run_matches_the_eager_state_steps(streams, monkeypatch):
+    """24 steps with no host synchronisation inside the loop (the host runs many replays ahead of the GPU: what bench.py and a
+    training loop do): parameters, buffers and Adam state of the replayed run equal the eager state-mode run bit for bit."""
+    import uaps_amd
+    from uaps_amd import unet
+    monkeypatch.setattr(unet, "_DECODER_STREAMS", streams)
+    m0 = _model(12)
+    m1 = copy.deepcopy(m0)
+    m0.to(DEV), m1.to(DEV)
+    data = _batches(4, 2, 64, 64, seed=31)
+    runs = []
+    for model, kw in ((m0, {"step_state": True}), (m1, {"use_graph": True})):
+        tr = uaps_amd.UAPSTrainer(model, base_lr=1e-3, seed=9, **kw)
+        uaps_amd.perturb.manual_seed(9, 0)
+        np.random.seed(9)
+        for i in range(24):
+            tr.train_step(*data[i % 4])
+        runs.append(tr)
+    torch.cuda.synchronize()
+    assert runs[1].step_graph.graph is not None
+    for (n, pa), pb in zip(m0.named_parameters(), m1.parameters()):
+        assert torch.equal(pa, pb), n
+    for (n, ba), bb in zip(m0.named_buffers(), m1.buffers()):
+        assert torch.equal(ba, bb), n
+    assert float(runs[0].last["loss"]) == float(runs[1].last["loss"])
+    assert runs[0].epoch_metrics() == runs[1].epoch_metrics()
