@@ -73,6 +73,18 @@ int launch_swrw(const ConvWrwArgs& a, hipStream_t s) {
     const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     if (a.dy_bound) {                                 // the fp16 two-piece form
+        if constexpr (WCO == 1 && TH == 4) {          // 16 output channels (the 256 x 256 level): 8-row tiles, halo rows 10/8 instead of 6/4 and
+            // half the barriers -- measured 161 -> 150 us (32 -> 16 channels) and 103 -> 90 us (16 -> 16 with the staging-time
+            // BatchNorm) at B = 32; the 32 x 16 channel block of the 128 x 128 level loses 10 % and keeps 4 rows
+            static const int tall = getenv("UAPS_WRW_TALL") ? atoi(getenv("UAPS_WRW_TALL")) : 1;
+            if (tall && a.H >= 8) {
+                ConvWrwArgs b = a;
+                b.tiles_y = (a.H + 7) / 8;
+                if (b.xf) hipLaunchKernelGGL((conv_hwrw_bn_kernel<8, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, b);
+                else hipLaunchKernelGGL((conv_hwrw_kernel<8, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, b);
+                return (int)hipGetLastError();
+            }
+        }
         if (a.xf) hipLaunchKernelGGL((conv_hwrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
         else hipLaunchKernelGGL((conv_hwrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
         return (int)hipGetLastError();
