@@ -125,6 +125,8 @@ def main():
                          "bit-identical results, launches of different decoders overlap)")
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1 only: run the timed steps eagerly instead of replaying the captured hipGraph of the step (uaps_amd/graph.py)")
+    ap.add_argument("--exact-steps", type=int, default=5,
+                    help="steps timed with every convolution on the fp32 matrix instruction after the headline (0 = skip)")
     ap.add_argument("--analysis-steps", type=int, default=6, help="single-stream steps after the timed region for the per-kernel figures")
     args = ap.parse_args()
 
@@ -242,6 +244,27 @@ def main():
     else:
         dominant = None
 
+    # ---- the same step on the fp32 matrix instruction everywhere (UAPS_CONV_MODE=0), a few eager steps in the headline stream
+    # mode: the figure to hold against `value` for anyone who does not accept split arithmetic as fp32 ----
+    exact_ms = None
+    if args.exact_steps > 0 and conv.get_mode() != "exact":
+        prev_mode = conv.get_mode()
+        trainer.step_graph, trainer.optimizer.from_step_state = None, False
+        conv.set_mode("exact")
+        for i in range(2):
+            trainer.train_step(*data.next())
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x0.record()
+        for i in range(args.exact_steps):
+            trainer.train_step(*data.next())
+        x1.record()
+        torch.cuda.synchronize()
+        exact_ms = x0.elapsed_time(x1) / args.exact_steps
+        conv.set_mode(prev_mode)
+
     if rank == 0:
         npix = b * H * W
         n_an = max(args.analysis_steps, 1)
@@ -333,6 +356,10 @@ def main():
         if single_ms:
             res["single_stream"] = {"ms_per_step": round(single_ms, 3), "images_per_s": round(2 * b / single_ms * 1e3, 1),
                                     "steps": args.analysis_steps, "note": "the analysis pass the per-kernel figures come from (rank 0, HIP events)"}
+        if exact_ms:
+            res["fp32_mfma_everywhere"] = {"ms_per_step": round(exact_ms, 3), "images_per_s": round(2 * b / exact_ms * 1e3, 1),
+                                           "steps": args.exact_steps,
+                                           "note": "UAPS_CONV_MODE=0: v_mfma_f32_16x16x4_f32 for every convolution, eager launches, headline stream mode, rank 0"}
         if args.net != "unet_uaps":
             res["config"]["workload"] = f"{args.net} K={args.aux}, {H}x{W} {C}-class, batch {b}+{b} per GPU (not the BASELINE metric config)"
         if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
