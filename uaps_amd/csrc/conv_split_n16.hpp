@@ -70,8 +70,9 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
         uloff[n] = (ucg[n] * IH + ur[n]) * IW + ucu[n] * 4;
     }
     float rin[NU][8][4];
-    f32x2 rxf[XF ? NU : 1][XF ? 8 : 1];
-    bool uin[NU];
+    f32x2 rxf[XF ? NU : 1][XF ? 8 : 1];      // (scale, shift) of this thread's channels: reloaded only when the statistics group changes
+    int xf_group = -1;
+    bool uin[NU], uin_next[NU];
 
     auto tile_of = [&](int t, int& b, int& y0, int& x0, int& part) {
         b = t / tpi;
@@ -83,24 +84,32 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
         tile_of(t, b, y0, x0, part);
         const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
         const __amdgpu_buffer_rsrc_t rs2 = a.Csplit < a.Cin ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4) : rs1;
-        const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u) : rs1;
+        if constexpr (XF) {
+            const int g = b / a.xf_Bg;
+            if (g != xf_group) {                      // workgroup-uniform; a run of tiles crosses a group boundary at most once
+                xf_group = g;
+                const __amdgpu_buffer_rsrc_t rs_xf = make_rsrc(a.xf + (size_t)g * a.Cin, (uint32_t)a.Cin * 8u);
+#pragma unroll
+                for (int n = 0; n < NU; ++n)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)       // channels past Cin read (0, 0)
+                        rxf[n][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, (int)((uint32_t)(ucg[n] * 8 + c) * 8u), 0, 0));
+            }
+        }
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
             const int gy = y0 - 1 + ur[n], gx = x0 - 4 + ucu[n] * 4, c0 = ucg[n] * 8;
-            uin[n] = has[n] && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 < a.Cin;      // W % 4 == 0: all 4 pixels in or out
+            uin_next[n] = has[n] && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 < a.Cin;      // W % 4 == 0: all 4 pixels in or out
             const bool second = c0 >= a.Csplit;       // a channel group lies in one source (Csplit % 8 == 0)
             const uint32_t off = (uint32_t)((second ? c0 - a.Csplit : c0) * HW + gy * a.W + gx) * 4u;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) buf_load<4>(second ? rs2 : rs1, uin[n] ? off + (uint32_t)c * HW4 : kOob, rin[n][c]);
-            if constexpr (XF) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    rxf[n][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, uin[n] ? (int)((uint32_t)(c0 + c) * 8u) : (int)kOob, 0, 0));
-            }
+            for (int c = 0; c < 8; ++c) buf_load<4>(second ? rs2 : rs1, uin_next[n] ? off + (uint32_t)c * HW4 : kOob, rin[n][c]);
         }
     };
     // fetched unit -> two fp16 pieces per element (XF: leaky_relu(fma(y, scale, shift)) first; padding stays zero), into LDS
     auto store_tile = [&]() {
+#pragma unroll
+        for (int n = 0; n < NU; ++n) uin[n] = uin_next[n];       // the tile whose registers are being split
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
             if (!has[n]) continue;
@@ -110,9 +119,9 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
 #pragma unroll
                 for (int c2 = 0; c2 < 4; ++c2) {
                     float v0 = rin[n][2 * c2][p], v1 = rin[n][2 * c2 + 1][p];
-                    if constexpr (XF) {
+                    if constexpr (XF) {               // padding pixels stay zero (the coefficients are not zeroed per pixel any more)
                         const float z0 = __builtin_fmaf(v0, rxf[n][2 * c2].x, rxf[n][2 * c2].y), z1 = __builtin_fmaf(v1, rxf[n][2 * c2 + 1].x, rxf[n][2 * c2 + 1].y);
-                        v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
+                        v0 = uin[n] ? __builtin_fmaxf(z0, z0 * a.xf_slope) : 0.f; v1 = uin[n] ? __builtin_fmaxf(z1, z1 * a.xf_slope) : 0.f;
                     }
                     unsigned q0, q1;
                     conv_split2h(v0 * in_scale, v1 * in_scale, q0, q1);
