@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("UAPS_HIP_LIB") or os.path.join(_HERE, "lib", "libuaps
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()
+_tls = threading.local()      # one reusable uaps_call_hints per thread (uaps_next_call_hints copies it)
 _lib = None
 
 c_float_p = C.POINTER(C.c_float)
@@ -154,7 +155,12 @@ class CallHints(C.Structure):
 def hints(bounds=(), out_amax=None, stats=None) -> None:
     """bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
     None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about."""
-    h = CallHints()
+    h = getattr(_tls, "hints", None)
+    if h is None:
+        h = _tls.hints = CallHints()
+    for i in range(3):
+        h.bound[i] = None
+    h.out_amax = h.stats_mean = h.stats_bias = None
     if stats is not None:
         if stats[0] is not None:
             h.stats_mean = stats[0].data_ptr()

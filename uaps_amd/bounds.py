@@ -58,8 +58,9 @@ def new_amax(dev: torch.device) -> torch.Tensor:
     key = (dev.index, _lib.current_stream(dev))      # a chunk is zero-filled on, and handed out for, one stream
     ent = _pool.get(key)
     if ent is None or ent[1] >= _CHUNK:
-        ent = _pool[key] = [torch.zeros(_CHUNK * FLOATS, dtype=torch.float32, device=dev), 0]
-    s = ent[0][ent[1] * FLOATS:(ent[1] + 1) * FLOATS]
+        # all views of a chunk are made by one call (a Python-level slice per bound costs more than the kernels' hints)
+        ent = _pool[key] = [torch.zeros((_CHUNK, FLOATS), dtype=torch.float32, device=dev).unbind(0), 0]
+    s = ent[0][ent[1]]
     ent[1] += 1
     return s
 

@@ -102,13 +102,21 @@ def set_mode(mode) -> None:
     'split' / 1 = exact three-way bf16 split of both fp32 operands on the bf16 matrix pipe (csrc/conv_split.hpp, fp32-chain
     accuracy at 2.67x the fp32 matrix rate); 'exact' / 0 = the fp32 matrix instruction everywhere.  Process-wide; also
     UAPS_CONV_MODE=0/1/2 in the environment."""
+    global _mode_name
     m = {"h16": 2, "split": 1, "bf16": 1, "exact": 0, "f32": 0}.get(mode, mode)
     _lib.check(_lib.lib().uaps_conv_set_mode(int(m)), "uaps_conv_set_mode")
     _variant_cache.clear()
+    _mode_name = None
+
+
+_mode_name = None      # cached (the hot path asks once per launch); uaps_conv_set_mode from elsewhere is not seen until set_mode()
 
 
 def get_mode() -> str:
-    return {2: "h16", 1: "split"}.get(_lib.lib().uaps_conv_get_mode(), "exact")
+    global _mode_name
+    if _mode_name is None:
+        _mode_name = {2: "h16", 1: "split"}.get(_lib.lib().uaps_conv_get_mode(), "exact")
+    return _mode_name
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
