@@ -144,6 +144,11 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    # test hooks (tests/test_gpu_two_ranks.py runs the N = 2 code path on a one-GPU box): every rank on one device, gloo
+    # instead of RCCL, which refuses two ranks on a device
+    backend = os.environ.get("UAPS_BENCH_BACKEND", "nccl")
+    if "UAPS_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["UAPS_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the process group is created even for one rank, so the barrier /
@@ -157,7 +162,10 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     torch.manual_seed(1337)
     D, C, H, W, b = args.aux + 1, args.classes, args.size, args.size, args.batch

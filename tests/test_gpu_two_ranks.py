@@ -1,0 +1,135 @@
+"""The data-parallel step with TWO processes on the GPU box's one card (gloo carries the collectives; RCCL refuses two ranks
+on one device).  tests/test_ddp_gloo.py covers the exchange protocol on the CPU with a stand-in loss; here every rank runs
+the product step -- HIP kernels, gradients written into the flat buckets, decoder streams, the bucket all-reduces launched
+from the backward hooks -- and the parent process recomputes each rank's gradient on its own to check the average."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+SEED = 5
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _make_model(seed):
+    from uaps_amd import unet
+    torch.manual_seed(seed)
+    return unet.UNet_UAPS(3, 4, n_aux=3, feature_chns=[8, 16, 32, 64, 128]).to("cuda:0")
+
+
+def _batch(rank, step):
+    g = torch.Generator().manual_seed(1000 + 10 * step + rank)
+    return (torch.randn(2, 3, 64, 64, generator=g).to("cuda:0"), torch.randint(0, 4, (2, 64, 64), generator=g).to("cuda:0"),
+            torch.randn(2, 3, 64, 64, generator=g).to("cuda:0"))
+
+
+def _worker(rank, world, port, out_dir, gathered, streams, steps):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import uaps_amd
+    from uaps_amd import unet
+    unet._DECODER_STREAMS = streams
+    model = _make_model(seed=rank)                 # different init per rank: the broadcast must fix it
+    uaps_amd.dist.broadcast_model(model)
+    tr = uaps_amd.UAPSTrainer(model, seed=SEED, gathered_loss=gathered)
+    assert tr.world == world and tr.buckets is not None
+    rec = []
+    for s in range(steps):
+        res = tr.train_step(*_batch(rank, s))
+        rec.append({"w": res["w"], "loss": float(res["loss"]),
+                    "grads": {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}})
+    torch.cuda.synchronize()
+    torch.save({"steps": rec, "params": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, gathered, streams, steps):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), gathered, streams, steps), nprocs=2, join=True)
+    return [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+
+
+@pytest.mark.parametrize("streams", [False, True], ids=["single_stream", "decoder_streams"])
+def test_two_ranks_average_gradients(tmp_path, streams):
+    """After every step both ranks hold bitwise the same gradients and parameters, and the first step's gradients are
+    (g_rank0 + g_rank1) / 2 of the two shards' own gradients, recomputed here by one process."""
+    r0, r1 = _run(tmp_path, gathered=False, streams=streams, steps=2)
+    for s in range(2):
+        assert np.array_equal(r0["steps"][s]["w"], r1["steps"][s]["w"])          # same Dirichlet draw on every rank
+        for n, g in r0["steps"][s]["grads"].items():
+            assert torch.equal(g, r1["steps"][s]["grads"][n]), (s, n)
+    for k, v in r0["params"].items():
+        if "running_" in k or "num_batches" in k:
+            continue                                # BatchNorm statistics are per replica (nn.DataParallel keeps replica 0's)
+        assert torch.equal(v, r1["params"][k]), k
+
+    import uaps_amd
+    from uaps_amd import perturb, unet
+    unet._DECODER_STREAMS = streams
+    own = []
+    try:
+        for rank in range(2):
+            model = _make_model(seed=0)             # what the broadcast left on every rank
+            tr = uaps_amd.UAPSTrainer(model, seed=SEED)
+            np.random.seed(SEED + rank)             # the per-rank streams the trainer selects from dist.rank()
+            perturb.manual_seed(SEED, rank)
+            tr.train_step(*_batch(rank, 0))
+            own.append({n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+    finally:
+        unet._DECODER_STREAMS = False
+    for n, g in r0["steps"][0]["grads"].items():
+        want = (own[0][n] + own[1][n]) * 0.5
+        assert torch.equal(g, want), (n, float((g - want).abs().max()))
+
+
+def test_two_ranks_gathered_loss(tmp_path):
+    """gathered_loss=True (the reference's nn.DataParallel semantics: means and Dice sums over the batch of all ranks, one
+    exchange of the raw loss sums between the loss forward and backward kernels): the ranks report the same loss and stay in
+    lock-step (the protocol's arithmetic is checked against the oracle in tests/test_ddp_gloo.py)."""
+    r0, r1 = _run(tmp_path, gathered=True, streams=True, steps=2)
+    for s in range(2):
+        assert r0["steps"][s]["loss"] == r1["steps"][s]["loss"]
+        assert np.isfinite(r0["steps"][s]["loss"])
+        for n, g in r0["steps"][s]["grads"].items():
+            assert torch.equal(g, r1["steps"][s]["grads"][n]), (s, n)
+    for k, v in r0["params"].items():
+        if "running_" in k or "num_batches" in k:
+            continue
+        assert torch.equal(v, r1["params"][k]), k
+
+
+def test_bench_two_ranks_one_line(tmp_path):
+    """bench.py's N > 1 branch as the driver launches it (torch.distributed.run, one rank per process): barriers, the
+    max-over-ranks clock and ONE JSON line from rank 0.  Both ranks share this box's GPU and gloo stands in for RCCL
+    (the UAPS_BENCH_* test hooks); the bucket all-reduces, the eager decoder-stream step and the reporting are the code
+    the 8-GPU run executes."""
+    import json
+    import subprocess
+    env = dict(os.environ, UAPS_BENCH_BACKEND="gloo", UAPS_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "2", "--size", "64", "--analysis-steps", "1", "--exact-steps", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["config"]["parallelism"] == "dp2"
+    per_step = 2 * (2 + 2)                                  # images of the whole job per step: 2 ranks x (2 labelled + 2 unlabelled)
+    assert abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3)) / out["value"] < 0.02

@@ -8,6 +8,14 @@ static void launch_variant(const PairArgs& a, long N, int HW, const HeadPtrs<D>&
     hipLaunchKernelGGL((pair_fwd_kernel<D, C, VS, VU, PFS, PFU, MINW>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
                        a.pseudo, a.var, part_s, part_u, nb_s, a.w ? (const uint32_t*)nullptr : (const uint32_t*)uaps_get_step_state());
 }
+template <int D, int C, int VS, int VU, int MINW>
+static void launch_both(const PairArgs& a, long N, int HW, const HeadPtrs<D>& zl, const HeadPtrs<D>& zu, const HeadWeights<D>& w,
+                        float* part_s, float* part_u, int& nb_s, int& nb_u) {
+    const int cap = (a.cfg & 0xfff) ? (a.cfg & 0xfff) : 512;
+    nb_s = nb_u = pair_grid(N / (VS > VU ? VS : VU), cap);
+    hipLaunchKernelGGL((pair_fwd_both_kernel<D, C, VS, VU, MINW>), dim3(nb_s), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
+                       a.pseudo, a.var, part_s, part_u, a.w ? (const uint32_t*)nullptr : (const uint32_t*)uaps_get_step_state());
+}
 template <int D, int C> static int run_pair_fwd(const PairArgs& a) {
     constexpr int VU = unsup_vec<D, C>();
     const long HW = (long)a.H * a.W, N = (long)a.B * HW;
@@ -21,7 +29,7 @@ template <int D, int C> static int run_pair_fwd(const PairArgs& a) {
 #ifdef UAPS_LOSS_EXPERIMENT      // tools/bench_loss.py: kernel variants selected by cfg bits 28-30 (built for D*C <= 16 only)
         if constexpr (D * C <= 16 && D >= 4) {
             switch ((a.cfg >> 28) & 7) {
-                case 1: launch_variant<D, C, 4, 4, false, false, 2>(a, N, (int)HW, zl, zu, w, part_s, part_u, nb_s, nb_u); break;
+                case 1: launch_both<D, C, 4, 4, 2>(a, N, (int)HW, zl, zu, w, part_s, part_u, nb_s, nb_u); break;
                 case 2: launch_variant<D, C, 4, 1, false, false, 4>(a, N, (int)HW, zl, zu, w, part_s, part_u, nb_s, nb_u); break;
                 case 3: launch_variant<D, C, 4, 2, false, false, 3>(a, N, (int)HW, zl, zu, w, part_s, part_u, nb_s, nb_u); break;
                 case 4: launch_variant<D, C, 4, 4, true, false, 2>(a, N, (int)HW, zl, zu, w, part_s, part_u, nb_s, nb_u); break;
