@@ -38,7 +38,7 @@ def loss_kernel_bytes(name, D, C, npix):
               "uaps_unsup_bwd": 8 * D * C + 8,
               "uaps_sup_fwd": 4 * D * C + 8,
               "uaps_sup_bwd": 8 * D * C + 8,
-              "uaps_pair_fwd": 2 * (4 * D * C + 8),        # both branches in one launch (+ the one-block finalize)
+              "uaps_pair_fwd": 2 * (4 * D * C + 8),        # both branches in one launch (pair_fwd_kernel; the one-block finalize is not in the time)
               "uaps_pair_bwd": 2 * (8 * D * C + 8)}[name]
     return per_px * npix
 
@@ -218,8 +218,8 @@ def main():
         dt = float(t)
     last_loss = float(trainer.last["loss"])
 
-    # ---- per-kernel analysis pass, same process, SINGLE stream (a launch's event-to-event time is then that kernel alone):
-    # one step with every hand-written conv / loss launch bracketed by HIP events on its launch stream (finds the dominant
+    # ---- per-kernel analysis pass, same process, SINGLE stream (a kernel then has the chip to itself, as in the rocprofv3
+    # profiles): one step with HIP events attached to the dispatch of every hand-written conv / loss kernel (finds the dominant
     # instantiation and sums the step's algorithmic flops), then `analysis_steps` steps with events around the dominant
     # kernel's launches and the loss kernels only, timed as a whole for the single-stream ms/step ----
     discover, ev, cev, single_ms = None, {}, {}, None
@@ -308,9 +308,10 @@ def main():
                     "launches_per_step": v["calls"] / n_an,
                     "note": "kernel instantiation with the largest share of the step; measured in the single-stream analysis pass "
                             f"of this process ({args.analysis_steps} steps after the timed region; launches of different decoders "
-                            "overlap in the headline mode, so a launch's event-to-event time is only that kernel's when single-stream): "
-                            "algorithmic flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed HIP-event time on "
-                            "the launch stream; traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); "
+                            "overlap in the headline mode, so a kernel only has the chip to itself when single-stream): "
+                            "algorithmic flops = 2*B*H*W*Cin*Cout*k*k per launch, summed over its launches / summed time between the two "
+                            "HIP events attached to each kernel's dispatch on its launch stream (uaps_next_launch_events: the kernel's "
+                            "execution time, as rocprofv3's kernel trace reports it); traffic = HBM bytes per launch from profiles/pmc_traffic.json (rocprofv3 --pmc passes); "
                             "peak: fp32 flops per second the kernel's matrix instruction allows at the nominal 2.4 GHz -- 157.3 for the "
                             "fp32 MFMA kernels, 2500 / 3 = 833.3 for the fp16-split kernels (conv_h*: three fp16 partial products per "
                             "fp32 multiply, fp32 accumulation), 2500 / 6 = 416.7 for the bf16-split kernels (conv_s*, six partial "

@@ -362,6 +362,13 @@ typedef struct uaps_call_hints {
     const float* stats_bias;
 } uaps_call_hints;
 int uaps_next_call_hints(const uaps_call_hints* hints);
+/* Measurement aid (bench.py): `start` / `stop` are two hipEvent_t created with timing enabled.  The calling thread's next MAIN
+ * kernel launch -- the convolution kernel of uaps_conv_fwd* / uaps_conv_bwd_data* / uaps_conv_bwd_weight* / uaps_convs_*, the
+ * forward / backward kernel of uaps_pairloss_fwd / _bwd; not their packing, reduce or finalize launches -- attaches them to its
+ * dispatch (hipExtLaunchKernel), so that hipEventElapsedTime(start, stop) is that kernel's execution time as a profiler's kernel
+ * trace reports it.  One-shot; (NULL, NULL) disarms.  Returns 1 when the previously armed pair was consumed by a launch since
+ * the last call, else 0. */
+int uaps_next_launch_events(void* start, void* stop);
 int uaps_conv_get_mode(void);
 /* both packed buffers hold the fp32 layout followed by the bf16-split and the fp16-split layouts; they must be 16-byte aligned */
 int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);

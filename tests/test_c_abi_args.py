@@ -98,6 +98,12 @@ def test_call_hints_are_validated_and_one_shot(L):
     assert L.uaps_next_call_hints(C.byref(h)) == OK
     assert L.uaps_conv_fwd(None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL   # consumes the pending hints
     assert L.uaps_next_call_hints(None) == OK
+    # launch events: disarming with nothing armed reports "not consumed"; an armed pair that no launch used is dropped
+    L.uaps_next_launch_events.restype = C.c_int
+    L.uaps_next_launch_events.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.uaps_next_launch_events(None, None) == 0
+    assert L.uaps_next_launch_events(C.c_void_p(16), C.c_void_p(32)) == 0
+    assert L.uaps_next_launch_events(None, None) == 0
     out = (C.c_float * 1024)()
     assert L.uaps_bn_param_bounds(None, None, None, 1, out, None) == EINVAL
 

@@ -286,3 +286,38 @@ def test_conv_without_bounds_runs_the_bf16_form_in_h16_mode(conv_mode):
     y.backward(torch.ones_like(y))
     names, conv.KERNEL_EVENTS = set(conv.KERNEL_EVENTS), None
     assert names and all(n.startswith("conv_s") for n in names), names
+
+
+def test_launch_timer_reads_the_kernel_dispatch(conv_mode):
+    """_lib.LaunchTimer (uaps_next_launch_events): the events ride on the convolution kernel's dispatch, so the elapsed time
+    is positive, at most what two events bracketing the call on the stream measure, and the results are untouched."""
+    from uaps_amd import _lib, conv
+    from uaps_amd.conv import conv2d
+    dev = torch.device("cuda:0")
+    x = _b(_mk((8, 32, 128, 128), 21).to(dev))
+    w = _mk((32, 32, 3, 3), 22).to(dev)
+    ref = conv2d(x, w)
+    torch.cuda.synchronize()
+    for kind in ("fwd", "bwd_data", "wrw"):
+        conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, None
+        try:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            xr = x.detach().clone().requires_grad_(kind == "bwd_data")
+            xr = _b(xr)
+            wr = w.detach().clone().requires_grad_(kind == "wrw")
+            y = conv2d(xr, wr)
+            dy = _b(torch.ones_like(y))
+            s.record()
+            y.backward(dy) if kind != "fwd" else conv2d(x, w)
+            e.record()
+            torch.cuda.synchronize()
+            recs = {k: v for k, v in conv.KERNEL_EVENTS.items()}
+        finally:
+            conv.KERNEL_EVENTS = None
+        assert torch.equal(y.detach(), ref)
+        inner = sum(a.elapsed_time(b) for v in recs.values() for a, b, *_ in v)
+        assert 0.0 < inner <= s.elapsed_time(e), (kind, inner, s.elapsed_time(e))
+    with _lib.LaunchTimer() as t:           # nothing launched inside: the pair falls back to bracketing the (empty) block
+        pass
+    torch.cuda.synchronize()
+    assert not t.dispatch and t.elapsed_ms() >= 0.0

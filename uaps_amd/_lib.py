@@ -78,6 +78,7 @@ SIGNATURES = {
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
     "uaps_set_step_state": (C.c_int, [_PTR]),
     "uaps_next_call_hints": (C.c_int, [_PTR]),
+    "uaps_next_launch_events": (C.c_int, [_PTR, _PTR]),
     "uaps_bn_param_bounds": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, _PTR]),
     "uaps_get_step_state": (C.c_void_p, []),
     "uaps_convs_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -172,6 +173,30 @@ def hints(bounds=(), out_amax=None, stats=None) -> None:
     if out_amax is not None:
         h.out_amax = out_amax.data_ptr()
     check(lib().uaps_next_call_hints(C.byref(h)), "uaps_next_call_hints")
+
+
+class LaunchTimer:
+    """Times the MAIN kernel launched by the entry point(s) called inside the `with` block: the two events are attached to
+    that kernel's dispatch (uaps_next_launch_events), so `elapsed_ms()` after a synchronize is the kernel's execution time
+    as rocprofv3's kernel trace reports it.  When no main launch consumed them (an entry point without one), they bracket
+    the block on the stream instead (event-to-event: includes the launch gaps)."""
+
+    def __enter__(self):
+        import torch
+        self.start, self.stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.start.record()                 # creates the hipEvent_t; also the start mark of the fall-back
+        self.stop.record()
+        lib().uaps_next_launch_events(self.start.cuda_event, self.stop.cuda_event)
+        return self
+
+    def __exit__(self, *a):
+        self.dispatch = bool(lib().uaps_next_launch_events(None, None))
+        if not self.dispatch:
+            self.stop.record()
+        return False
+
+    def elapsed_ms(self) -> float:
+        return self.start.elapsed_time(self.stop)
 
 
 def check(rc: int, what: str) -> None:

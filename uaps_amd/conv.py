@@ -37,7 +37,7 @@ register_optimizer_step_post_hook(invalidate_packed_weights)
 
 
 # bench.py sets KERNEL_EVENTS to a dict {kernel instantiation name: [(start_event, end_event, flops), ...]}
-# to time individual launches with HIP events on the stream they run on; EVENT_FILTER (a set of names)
+# to time individual launches with HIP events attached to the kernel's dispatch (_lib.LaunchTimer); EVENT_FILTER (a set of names)
 # restricts the recording to those instantiations.  None (the default) records nothing.
 KERNEL_EVENTS: Optional[Dict[str, list]] = None
 EVENT_FILTER: Optional[set] = None
@@ -85,14 +85,13 @@ class _timed:
 
     def __enter__(self):
         if self.on:
-            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.s.record()
+            self.t = _lib.LaunchTimer().__enter__()
         return self
 
     def __exit__(self, *a):
         if self.on:
-            self.e.record()
-            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e, self.flops))
+            self.t.__exit__()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.t.start, self.t.stop, self.flops))
         return False
 
 

@@ -45,14 +45,14 @@ int launch_fwd(ConvFwdArgs a, bool vec, int extra_lds, hipStream_t s) {
     if (a.xf) {                  // BatchNorm + LeakyReLU of the input applied while staging: 16-byte form, 8-channel chunks, no dilation
         if constexpr (DIL == 1 && CK == 8) {
             if (!vec) return UAPS_ERANGE;
-            hipLaunchKernelGGL((conv_fwd_bn_kernel<KS, TH, TW, BN, CK, 4, 1>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+            UAPS_LAUNCH_MAIN((conv_fwd_bn_kernel<KS, TH, TW, BN, CK, 4, 1>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
             return (int)hipGetLastError();
         } else {
             return UAPS_ERANGE;
         }
     }
-    if (vec) hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
-    else hipLaunchKernelGGL((conv_fwd_kernel<KS, TH, TW, BN, CK, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+    if (vec) UAPS_LAUNCH_MAIN((conv_fwd_kernel<KS, TH, TW, BN, CK, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
+    else UAPS_LAUNCH_MAIN((conv_fwd_kernel<KS, TH, TW, BN, CK, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), extra_lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -83,12 +83,12 @@ int launch_sfwd(ConvFwdArgs a, hipStream_t s) {
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     if (a.wscale) {                                   // the fp16 two-piece form (plan: h16)
-        if (a.xf) hipLaunchKernelGGL((conv_hfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-        else hipLaunchKernelGGL((conv_hfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_hfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
         return (int)hipGetLastError();
     }
-    if (a.xf) hipLaunchKernelGGL((conv_sfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_sfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (a.xf) UAPS_LAUNCH_MAIN((conv_sfwd_bn_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else UAPS_LAUNCH_MAIN((conv_sfwd_kernel<KS, TH, TW, BN, CK>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 template <int KS, int TH, int TW>
@@ -112,11 +112,11 @@ int launch_hp16(ConvFwdArgs a, hipStream_t s) {
     const long want = a.Cin <= 16 ? 768 : 512;
     const unsigned grid = (unsigned)(((ntiles < want ? ntiles : want) + 7) / 8 * 8);
     if (a.Cin <= 16) {
-        if (a.xf) hipLaunchKernelGGL((conv_hp16_bn_kernel<2>), dim3(grid), dim3(kConvThreads), 0, s, a);
-        else hipLaunchKernelGGL((conv_hp16_kernel<2>), dim3(grid), dim3(kConvThreads), 0, s, a);
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_hp16_bn_kernel<2>), dim3(grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hp16_kernel<2>), dim3(grid), dim3(kConvThreads), 0, s, a);
     } else {
-        if (a.xf) hipLaunchKernelGGL((conv_hp16_bn_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
-        else hipLaunchKernelGGL((conv_hp16_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_hp16_bn_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hp16_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
     }
     return (int)hipGetLastError();
 }
@@ -128,8 +128,8 @@ int launch_small(ConvFwdArgs a, int kind, hipStream_t s) {
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     (void)kind;
-    if (a.xf) hipLaunchKernelGGL((conv_small_bn_kernel<8, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_small_kernel<8, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (a.xf) UAPS_LAUNCH_MAIN((conv_small_bn_kernel<8, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else UAPS_LAUNCH_MAIN((conv_small_kernel<8, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -141,12 +141,12 @@ int launch_s32(ConvFwdArgs a, hipStream_t s) {
     const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     if (a.wscale) {                                   // the fp16 two-piece form (plan: h16)
-        if (a.xf) hipLaunchKernelGGL((conv_h32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-        else hipLaunchKernelGGL((conv_h32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_h32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_h32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
         return (int)hipGetLastError();
     }
-    if (a.xf) hipLaunchKernelGGL((conv_s32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_s32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (a.xf) UAPS_LAUNCH_MAIN((conv_s32_bn_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else UAPS_LAUNCH_MAIN((conv_s32_kernel<BN>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include "../../include/uaps_hip.h"
 #include "conv_kernels.hpp"
+#include "hints.hpp"
 using namespace uaps;
 
 namespace {
@@ -327,9 +328,9 @@ extern "C" int uaps_convs_fwd(const float* x, const float* wf, float* y, int B, 
     const long grid = (nitems + 3) / 4;
     if (grid > 0x7fffffffL) return UAPS_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    if (nw == 4) hipLaunchKernelGGL((convs_fwd_kernel<4>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
-    else if (nw == 2) hipLaunchKernelGGL((convs_fwd_kernel<2>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
-    else hipLaunchKernelGGL((convs_fwd_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
+    if (nw == 4) UAPS_LAUNCH_MAIN((convs_fwd_kernel<4>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
+    else if (nw == 2) UAPS_LAUNCH_MAIN((convs_fwd_kernel<2>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
+    else UAPS_LAUNCH_MAIN((convs_fwd_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
     return (int)hipGetLastError();
 }
 
@@ -349,9 +350,9 @@ extern "C" int uaps_convs_bwd_data(const float* dy, const float* wb, float* dx, 
     const long grid = (nitems + 3) / 4;
     if (grid > 0x7fffffffL) return UAPS_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    if (nw == 4) hipLaunchKernelGGL((convs_bwd_data_kernel<4>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
-    else if (nw == 2) hipLaunchKernelGGL((convs_bwd_data_kernel<2>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
-    else hipLaunchKernelGGL((convs_bwd_data_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
+    if (nw == 4) UAPS_LAUNCH_MAIN((convs_bwd_data_kernel<4>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
+    else if (nw == 2) UAPS_LAUNCH_MAIN((convs_bwd_data_kernel<2>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
+    else UAPS_LAUNCH_MAIN((convs_bwd_data_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, ncb, nitems);
     return (int)hipGetLastError();
 }
 
@@ -394,14 +395,14 @@ extern "C" int uaps_convs_bwd_weight(const float* dy, const float* x, float* dw,
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(p.nsplit * p.ncob * p.ncib), ks == 7 ? 7 : 1);
     if (ks == 1) {
-        if (stride == 1) hipLaunchKernelGGL((convs_wrw_kernel<1, 1, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((convs_wrw_kernel<1, 1, 2>), grid, dim3(256), 0, s, a);
+        if (stride == 1) UAPS_LAUNCH_MAIN((convs_wrw_kernel<1, 1, 1>), grid, dim3(256), 0, s, a);
+        else UAPS_LAUNCH_MAIN((convs_wrw_kernel<1, 1, 2>), grid, dim3(256), 0, s, a);
     } else if (ks == 3) {
-        if (stride == 1) hipLaunchKernelGGL((convs_wrw_kernel<3, 3, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((convs_wrw_kernel<3, 3, 2>), grid, dim3(256), 0, s, a);
+        if (stride == 1) UAPS_LAUNCH_MAIN((convs_wrw_kernel<3, 3, 1>), grid, dim3(256), 0, s, a);
+        else UAPS_LAUNCH_MAIN((convs_wrw_kernel<3, 3, 2>), grid, dim3(256), 0, s, a);
     } else {
-        if (stride == 1) hipLaunchKernelGGL((convs_wrw_kernel<1, 7, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((convs_wrw_kernel<1, 7, 2>), grid, dim3(256), 0, s, a);
+        if (stride == 1) UAPS_LAUNCH_MAIN((convs_wrw_kernel<1, 7, 1>), grid, dim3(256), 0, s, a);
+        else UAPS_LAUNCH_MAIN((convs_wrw_kernel<1, 7, 2>), grid, dim3(256), 0, s, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -80,17 +80,17 @@ int launch_swrw(const ConvWrwArgs& a, hipStream_t s) {
             if (tall && a.H >= 8) {
                 ConvWrwArgs b = a;
                 b.tiles_y = (a.H + 7) / 8;
-                if (b.xf) hipLaunchKernelGGL((conv_hwrw_bn_kernel<8, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, b);
-                else hipLaunchKernelGGL((conv_hwrw_kernel<8, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, b);
+                if (b.xf) UAPS_LAUNCH_MAIN((conv_hwrw_bn_kernel<8, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, b);
+                else UAPS_LAUNCH_MAIN((conv_hwrw_kernel<8, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, b);
                 return (int)hipGetLastError();
             }
         }
-        if (a.xf) hipLaunchKernelGGL((conv_hwrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-        else hipLaunchKernelGGL((conv_hwrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_hwrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hwrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
         return (int)hipGetLastError();
     }
-    if (a.xf) hipLaunchKernelGGL((conv_swrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_swrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (a.xf) UAPS_LAUNCH_MAIN((conv_swrw_bn_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else UAPS_LAUNCH_MAIN((conv_swrw_kernel<TH, WCO, WCI>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 int dispatch_swrw(const ConvWrwArgs& a, const WrwPlan& p, hipStream_t s) {
@@ -109,14 +109,14 @@ int launch_wrw(const ConvWrwArgs& a, bool vec, hipStream_t s) {
     if (a.xf) {                  // BatchNorm + LeakyReLU of the input recomputed while staging: 16-byte form, no dilation
         if constexpr (DIL == 1) {
             if (!vec) return UAPS_ERANGE;
-            hipLaunchKernelGGL((conv_wrw_bn_kernel<KS, TH, TW, WCO, WCI, 4, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+            UAPS_LAUNCH_MAIN((conv_wrw_bn_kernel<KS, TH, TW, WCO, WCI, 4, 1>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
             return (int)hipGetLastError();
         } else {
             return UAPS_ERANGE;
         }
     }
-    if (vec) hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
-    else hipLaunchKernelGGL((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    if (vec) UAPS_LAUNCH_MAIN((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 4, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else UAPS_LAUNCH_MAIN((conv_wrw_kernel<KS, TH, TW, WCO, WCI, 1, DIL>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -171,8 +171,8 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     if (p.small) {
         if (x2) return UAPS_EINVAL;
         const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
-        if (a.xf) hipLaunchKernelGGL(conv_small_wrw_bn_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
-        else hipLaunchKernelGGL(conv_small_wrw_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
+        if (a.xf) UAPS_LAUNCH_MAIN(conv_small_wrw_bn_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN(conv_small_wrw_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
         return (int)hipGetLastError();
     }
     if (p.split) {

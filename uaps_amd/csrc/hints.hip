@@ -4,6 +4,7 @@
 namespace {
 thread_local uaps_call_hints g_hints;
 thread_local bool g_have = false;
+thread_local uaps::LaunchEvents g_launch;
 }
 
 namespace uaps {
@@ -13,7 +14,16 @@ uaps_call_hints take_hints() {
     else memset(&h, 0, sizeof h);
     return h;
 }
+LaunchEvents& launch_events() { return g_launch; }
 }  // namespace uaps
+
+extern "C" int uaps_next_launch_events(void* start, void* stop) {
+    const int used = g_launch.used ? 1 : 0;
+    g_launch.start = (hipEvent_t)start; g_launch.stop = (hipEvent_t)stop;
+    g_launch.armed = start != nullptr && stop != nullptr;
+    g_launch.used = false;
+    return used;
+}
 
 extern "C" int uaps_next_call_hints(const uaps_call_hints* h) {
     if (!h) { g_have = false; return UAPS_OK; }

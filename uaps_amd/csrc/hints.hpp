@@ -1,12 +1,30 @@
 // One-shot side arguments of the next entry point called on this thread (include/uaps_hip.h, uaps_next_call_hints).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "../../include/uaps_hip.h"
 
 namespace uaps {
 // returns the pending hints (all-null when none) and clears them: every entry point that understands hints calls this
 // first, so that a hint never outlives the call it was meant for
 uaps_call_hints take_hints();
+
+// uaps_next_launch_events (include/uaps_hip.h): a pair of events the calling thread's next MAIN kernel launch (the convolution /
+// loss kernel of an entry point, not its packing, reduce or finalize launches) attaches to its dispatch, so that their
+// elapsed time is that kernel's execution alone -- what rocprofv3's kernel trace reports -- instead of the event-to-event time
+// of two extra packets on the stream.
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; bool armed = false, used = false; };
+LaunchEvents& launch_events();
+#define UAPS_LAUNCH_MAIN(kernel, grid, block, shmem, stream, ...)                                                            \
+    do {                                                                                                                     \
+        uaps::LaunchEvents& le_ = uaps::launch_events();                                                                     \
+        if (le_.armed) {                                                                                                     \
+            le_.armed = false; le_.used = true;                                                                              \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, le_.start, le_.stop, 0, __VA_ARGS__);                  \
+        } else {                                                                                                             \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                             \
+        }                                                                                                                    \
+    } while (0)
 
 // A magnitude bound lives in UAPS_BOUND_SLOTS floats spaced UAPS_BOUND_STRIDE floats apart (include/uaps_hip.h); its value
 // is the maximum over the slots.  Thousands of workgroups raising ONE address serialise at the memory side (measured: ~2.4 ns

@@ -9,18 +9,18 @@ template <int D, int C> static int run_pair_bwd(const PairArgs& a) {
     if (pair_vec_ok(a, 4, true)) {
         const int nb_s = pair_grid(N / 4, pair_cap_s(a.cfg)), nb_u = pair_grid(N / VU, pair_cap_u(a.cfg));
         if (a.amax_out)
-            hipLaunchKernelGGL((pair_bwd_kernel<D, C, 4, VU, true>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
+            UAPS_LAUNCH_MAIN((pair_bwd_kernel<D, C, 4, VU, true>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
                                a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb_s, (const uint32_t*)uaps_get_step_state(), a.amax_out);
         else
-            hipLaunchKernelGGL((pair_bwd_kernel<D, C, 4, VU>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
+            UAPS_LAUNCH_MAIN((pair_bwd_kernel<D, C, 4, VU>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
                                a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb_s, (const uint32_t*)uaps_get_step_state(), a.amax_out);
     } else {
         const int nb_s = pair_grid(N, pair_cap_s(a.cfg)), nb_u = pair_grid(N, pair_cap_u(a.cfg));
         if (a.amax_out)
-            hipLaunchKernelGGL((pair_bwd_kernel<D, C, 1, 1, true>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
+            UAPS_LAUNCH_MAIN((pair_bwd_kernel<D, C, 1, 1, true>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
                                a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb_s, (const uint32_t*)uaps_get_step_state(), a.amax_out);
         else
-            hipLaunchKernelGGL((pair_bwd_kernel<D, C, 1, 1>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
+            UAPS_LAUNCH_MAIN((pair_bwd_kernel<D, C, 1, 1>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, dl, du, (int)HW, N, a.Nloss,
                                a.labels, a.cpseudo, a.sscal, a.uscal, a.ce_coef, a.dice_coef, a.cw1, a.cw2, a.gscale, nb_s, (const uint32_t*)uaps_get_step_state(), a.amax_out);
     }
     return (int)hipGetLastError();

@@ -5,7 +5,7 @@ template <int D, int C, int VS, int VU, bool PFS, bool PFU, int MINW>
 static void launch_variant(const PairArgs& a, long N, int HW, const HeadPtrs<D>& zl, const HeadPtrs<D>& zu, const HeadWeights<D>& w,
                            float* part_s, float* part_u, int& nb_s, int& nb_u) {
     nb_s = pair_grid(N / VS, pair_cap_s(a.cfg)); nb_u = pair_grid(N / VU, pair_cap_u(a.cfg));
-    hipLaunchKernelGGL((pair_fwd_kernel<D, C, VS, VU, PFS, PFU, MINW>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
+    UAPS_LAUNCH_MAIN((pair_fwd_kernel<D, C, VS, VU, PFS, PFU, MINW>), dim3(nb_s + nb_u), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
                        a.pseudo, a.var, part_s, part_u, nb_s, a.w ? (const uint32_t*)nullptr : (const uint32_t*)uaps_get_step_state());
 }
 template <int D, int C, int VS, int VU, int MINW>
@@ -13,7 +13,7 @@ static void launch_both(const PairArgs& a, long N, int HW, const HeadPtrs<D>& zl
                         float* part_s, float* part_u, int& nb_s, int& nb_u) {
     const int cap = (a.cfg & 0xfff) ? (a.cfg & 0xfff) : 512;
     nb_s = nb_u = pair_grid(N / (VS > VU ? VS : VU), cap);
-    hipLaunchKernelGGL((pair_fwd_both_kernel<D, C, VS, VU, MINW>), dim3(nb_s), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
+    UAPS_LAUNCH_MAIN((pair_fwd_both_kernel<D, C, VS, VU, MINW>), dim3(nb_s), dim3(kThreads), 0, a.stream, zl, zu, w, HW, N, a.labels,
                        a.pseudo, a.var, part_s, part_u, a.w ? (const uint32_t*)nullptr : (const uint32_t*)uaps_get_step_state());
 }
 template <int D, int C> static int run_pair_fwd(const PairArgs& a) {

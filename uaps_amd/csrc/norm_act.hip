@@ -101,7 +101,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd(const float2* __restrict
         double s = 0.0, ss = 0.0;
         if (g < G) {
             const float2* pp = partials + ((long)c * B + (long)g * Bg) * nch;
-            for (int i = t; i < nparts; i += kThreads) { const float2 v = pp[i]; s += v.x; ss += v.y; }
+            // 8 independent loads per trip (clamped index, masked add: the order of the additions is that of the plain loop);
+            // the kernel is one short block per channel and all memory latency
+            for (int i0 = t; i0 < nparts; i0 += 8 * kThreads) {
+                float2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + u * kThreads; v[u] = pp[i < nparts ? i : nparts - 1]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * kThreads < nparts) { s += v[u].x; ss += v[u].y; }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }

@@ -36,8 +36,9 @@ def _s_off(D, C):
 
 _ws_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 
-# bench.py sets this to a dict {kernel name: [(start_event, end_event), ...]} to time individual
-# launches with HIP events on the stream they run on; None (the default) records nothing.
+# bench.py sets this to a dict {kernel name: [(start_event, end_event), ...]} to time individual launches with HIP events
+# attached to the main kernel's dispatch (_lib.LaunchTimer: the pair-loss entries time pair_fwd_kernel / pair_bwd_kernel, the
+# separate-branch entries fall back to event-to-event); None (the default) records nothing.
 KERNEL_EVENTS: Optional[Dict[str, list]] = None
 
 
@@ -50,15 +51,14 @@ class _timed:
         self.name = name
 
     def __enter__(self):
-        if KERNEL_EVENTS is not None:
-            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.s.record()
+        self.t = _lib.LaunchTimer().__enter__() if KERNEL_EVENTS is not None else None
         return self
 
     def __exit__(self, *a):
-        if KERNEL_EVENTS is not None:
-            self.e.record()
-            KERNEL_EVENTS.setdefault(self.name, []).append((self.s, self.e))
+        if self.t is not None:
+            self.t.__exit__()
+            if KERNEL_EVENTS is not None:
+                KERNEL_EVENTS.setdefault(self.name, []).append((self.t.start, self.t.stop))
         return False
 
 
