@@ -131,7 +131,8 @@ def test_conv_refuses_cpu_tensors():
         conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3))
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16),
+                                            (4, 32, 32, 256, 256), (4, 16, 64, 252, 256)])          # the last two: persistent slice kernels
 def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
     """conv2d_with_stats: the per-tile (sum, sum of squares) written by the conv epilogue must add up to the
     statistics of y, and bn_act fed with them must equal bn_act running its own statistics pass."""
@@ -158,7 +159,7 @@ def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,C1,C2,Cout,H,W,ks", [(2, 16, 16, 16, 64, 64, 3), (2, 32, 32, 32, 32, 32, 3), (1, 128, 128, 128, 16, 16, 3),
-                                                  (2, 16, 24, 20, 24, 40, 3), (2, 32, 16, 8, 16, 16, 1)])
+                                                  (2, 16, 24, 20, 24, 40, 3), (2, 32, 16, 8, 16, 16, 1), (4, 16, 16, 32, 256, 256, 3)])
 def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
     """conv2d_cat(x1, x2, w) must be conv2d(cat([x1, x2]), w) bit for bit (same kernels, same order of operations),
     and so must its three gradients."""
@@ -203,7 +204,7 @@ def test_dilated_conv_vs_torch_cpu(B, Cin, Cout, H, W, dil):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [(4, 64, 64, 64, 64, 3), (2, 16, 16, 256, 256, 3), (4, 256, 128, 16, 16, 1), (2, 3, 16, 128, 128, 3),
-                                               (2, 128, 128, 32, 32, 3)])
+                                               (2, 128, 128, 32, 32, 3), (4, 32, 32, 256, 256, 3), (4, 16, 64, 256, 256, 3)])
 def test_split_mode_is_as_accurate_as_the_fp32_matrix_instruction(B, Cin, Cout, H, W, ks, conv_mode):
     """The bf16-split kernels claim fp32 accuracy: measured against a float64 reference, their forward / input-gradient
     error must be of the size of the exact fp32 kernels' (both are a few 1e-7 of sum |a*b|), on inputs with a wide
