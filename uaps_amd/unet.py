@@ -16,6 +16,7 @@ everything after the logits are the HIP kernels of this package (csrc/*.hip).
 from __future__ import annotations
 
 import os
+import weakref
 from typing import List, Optional, Sequence
 
 import torch
@@ -35,6 +36,7 @@ _FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
 # One HIP stream per auxiliary decoder (see UNet_UAPS.forward): +5 % images/s on the bench step, opt-in because kernels of
 # different decoders then overlap and per-launch timings (bench.py's roofline, rocprof averages) stop describing one kernel.
 _DECODER_STREAMS = os.environ.get("UAPS_DECODER_STREAMS", "0") != "0"
+_CAPTURE_KEEP = weakref.WeakKeyDictionary()     # model -> tensors that cross streams inside its captured step (UNet_UAPS.forward)
 # BatchNorm partial sums in the conv epilogues are taken about running_mean - conv bias (no variance cancellation for channels
 # with |mean| >> std).  Off: plain sums, as in round 1 -- then forward_pair and two successive forwards agree bit for bit (with
 # the shift the second forward already sees the running mean the first one updated: another rounding of the same statistics)
@@ -284,13 +286,32 @@ class UNet_UAPS(nn.Module):
                 self._streams = [torch.cuda.Stream(device=x.device) for _ in range(self.n_aux)]
             ready = main.record_event()
             outs = [None] * len(decoders)
+            # Memory that crosses streams.  The caching allocator hands a freed block back to the stream it was allocated on at
+            # once: the perturbed feature maps (allocated on the main stream) are read by the side stream's kernels -- in the
+            # forward, and as saved convolution inputs in the backward, where autograd drops them as soon as the node's kernels
+            # are ENQUEUED -- so without a record the main decoder's next allocation could reuse, and overwrite, a map a side
+            # stream's weight-gradient kernel has yet to read (seen as a rare bit mismatch between two runs of the same steps).
+            # Eager: record_stream (the block is reusable only after the other stream has passed the point of the free).
+            # Under capture the same reuse would be baked into the graph with no dependency between the two kernels: the tensors
+            # are simply kept until the next capture (their private-pool addresses are the graph's own anyway).
+            capturing = torch.cuda.is_current_stream_capturing()
+            keep = []
             for d in range(1, len(decoders)):
                 side = self._streams[d - 1]
                 side.wait_event(ready)
+                for t in per_dec[d]:
+                    if capturing:
+                        keep.append(t)
+                    else:
+                        t.record_stream(side)
                 with torch.cuda.stream(side):
                     outs[d] = decoders[d](per_dec[d])
-                if not torch.cuda.is_current_stream_capturing():
+                if capturing:
+                    keep.append(outs[d])
+                else:
                     outs[d].record_stream(main)          # consumed by the loss on the main stream
+            if capturing:
+                _CAPTURE_KEEP[self] = keep              # not an attribute: the model stays deep-copyable
             outs[0] = decoders[0](per_dec[0])
             for side in self._streams:
                 main.wait_stream(side)
