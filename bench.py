@@ -178,8 +178,9 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     # one process: the step is captured as a hipGraph after two eager steps (needs --warmup >= 3 to stay out of the timed region)
-    # and replayed, bit-identical to the eager step; N > 1 steps eagerly (the RCCL bucket exchange is not captured)
-    use_graph = world == 1 and not args.no_graph and args.net == "unet_uaps"
+    # and replayed, bit-identical to the eager step
+    # N > 1: two graphs around the eager RCCL gradient exchange (uaps_amd/graph.py); UAPS_GRAPH_MULTI=0 keeps the eager step there
+    use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or os.environ.get("UAPS_GRAPH_MULTI", "1") != "0")
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
     data = uaps_amd.data.SyntheticBatches(b, 3, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
 
@@ -217,6 +218,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     last_loss = float(trainer.last["loss"])
+    sg = trainer.step_graph
+    graph_used = sg is not None and sg.graph is not None        # False: no capture asked for, too few warm-up steps, or a failed capture
+    graph_split = graph_used and sg.split
 
     # ---- per-kernel analysis pass, same process, SINGLE stream (a kernel then has the chip to itself, as in the rocprofv3
     # profiles): one step with HIP events attached to the dispatch of every hand-written conv / loss kernel (finds the dominant
@@ -343,8 +347,13 @@ def main():
                          "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
         mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (bit-identical to single-stream)"
-        if use_graph:
+        if graph_used and not graph_split:
             mode = "captured hipGraph of the whole step, replayed once per step (bit-identical to the eager step); " + mode
+        elif graph_split:
+            mode = ("two captured hipGraphs per step (forward + loss + backward | Adam + metrics) replayed around the eager RCCL all-reduce of "
+                    "the flat gradient buckets (bit-identical to the eager step); ") + mode
+        elif use_graph:
+            mode = "eager launches (the capture was requested but did not take place); " + mode
         res = {"metric": "training images/sec (labeled+unlabeled) NEU-Seg 256x256 K=3", "value": round(2 * b * world * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -226,7 +226,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool wide = p.tw == 32;
     // a side with <= 4 channels: the exact-N fp32 kernels (no BatchNorm statistics epilogue, one tensor per side)
-    if (p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
+    static const bool no_small = getenv("UAPS_DIAG_NO_SMALL") != nullptr;         // diagnosis only
+    if (!no_small && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
     if (p.split) {
         // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
         a.wp = wp + (size_t)ks * ks * p.CinP * p.CoutP;
@@ -240,7 +241,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[1]; a.in2_mul = hints.mul[1]; }
         }
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
-        if (a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
+        static const bool no_hp16 = getenv("UAPS_DIAG_NO_HP16") != nullptr;      // diagnosis only (tools/diag/dp_repeat.py)
+        if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
         return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);
     }

@@ -29,10 +29,16 @@ LaunchEvents& launch_events();
 // A magnitude bound lives in UAPS_BOUND_SLOTS floats spaced UAPS_BOUND_STRIDE floats apart (include/uaps_hip.h); its value
 // is the maximum over the slots.  Thousands of workgroups raising ONE address serialise at the memory side (measured: ~2.4 ns
 // per atomic, +20 us on a 30 us kernel of 8192 blocks); spread over 16 lines they do not.
+// Agent-scope loads: the slots are raised by memory-side atomics of the producing kernel, and a plain load may be served from a
+// line this XCD's L2 still holds from before them -- the zero fill, or the previous replay's value at the same address (the same
+// hazard as the FeatureDropout maximum in perturb.hip).  A stale bound is still a usable scale, so nothing breaks, but workgroups
+// then scale by different powers of two from run to run and the results differ in the last bits (seen as rare bit mismatches
+// between a replayed and an eager run of the same steps).
 __device__ __forceinline__ float bound_max(const float* p) {
-    float m = p[0];
+    float m = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int i = 1; i < UAPS_BOUND_SLOTS; ++i) m = __builtin_fmaxf(m, p[i * UAPS_BOUND_STRIDE]);
+    for (int i = 1; i < UAPS_BOUND_SLOTS; ++i)
+        m = __builtin_fmaxf(m, __hip_atomic_load(p + i * UAPS_BOUND_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return m;
 }
 

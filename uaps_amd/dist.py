@@ -83,6 +83,7 @@ class GradBuckets:
             for p, o in zip(params, offs):
                 _graddest.register(p, flat, o)
         self._hooks = []
+        self.defer = False
         if self.world > 1 and overlap:
             for bi, params in enumerate(self.buckets):
                 for p in params:
@@ -95,6 +96,8 @@ class GradBuckets:
 
     def _make_hook(self, bi: int):
         def hook(_param):
+            if self.defer:                     # captured backward (graph.StepGraph): the exchange is launched by finish(), after the replay
+                return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
@@ -121,7 +124,7 @@ class GradBuckets:
         """Call after backward(): waits for the collectives and (average=True) divides by the world size."""
         if self.world == 1:
             return
-        if not self.overlap:
+        if not self.overlap or self.defer:
             for bi in range(len(self.buckets)):
                 self._launch(bi)
         else:
@@ -134,6 +137,23 @@ class GradBuckets:
             if self.average:
                 self._flat[bi].mul_(inv)
         self.reset()
+
+    def in_place(self) -> bool:
+        """True when every parameter's .grad is its slice of the flat buffer (what a captured backward must guarantee: a gradient
+        produced elsewhere would need the per-step copy of _launch, which a replay does not run)."""
+        return all(p.grad is not None and p.grad.data_ptr() == self._view(bi, k).data_ptr()
+                   for bi, params in enumerate(self.buckets) for k, p in enumerate(params))
+
+    def exchange_all(self):
+        """All buckets at once, no hooks involved (between the two replays of graph.StepGraph): all-reduce, wait, average."""
+        if self.world == 1:
+            return
+        hs = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self._flat]
+        inv = 1.0 / self.world
+        for flat, h in zip(self._flat, hs):
+            h.wait()
+            if self.average:
+                flat.mul_(inv)
 
     def remove(self):
         from . import _graddest
