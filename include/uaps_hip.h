@@ -369,6 +369,9 @@ int uaps_next_call_hints(const uaps_call_hints* hints);
  * trace reports it.  One-shot; (NULL, NULL) disarms.  Returns 1 when the previously armed pair was consumed by a launch since
  * the last call, else 0. */
 int uaps_next_launch_events(void* start, void* stop);
+/* Zero n floats of bound storage (a multiple of UAPS_BOUND_FLOATS) with agent-scope stores -- the way bounds handed to
+ * uaps_call_hints::out_amax must be cleared (a plain fill may be written back over the atomically raised value). */
+int uaps_zero_bounds(float* bounds, long n, uaps_stream_t stream);
 int uaps_conv_get_mode(void);
 /* both packed buffers hold the fp32 layout followed by the bf16-split and the fp16-split layouts; they must be 16-byte aligned */
 int uaps_conv_pack_floats(int Cout, int Cin, int ks, size_t* fwd_floats_host, size_t* bwd_floats_host);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "uaps_set_step_state": (C.c_int, [_PTR]),
     "uaps_next_call_hints": (C.c_int, [_PTR]),
     "uaps_next_launch_events": (C.c_int, [_PTR, _PTR]),
+    "uaps_zero_bounds": (C.c_int, [_PTR, C.c_long, _PTR]),
     "uaps_bn_param_bounds": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, _PTR]),
     "uaps_get_step_state": (C.c_void_p, []),
     "uaps_convs_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

@@ -59,7 +59,10 @@ def new_amax(dev: torch.device) -> torch.Tensor:
     ent = _pool.get(key)
     if ent is None or ent[1] >= _CHUNK:
         # all views of a chunk are made by one call (a Python-level slice per bound costs more than the kernels' hints)
-        ent = _pool[key] = [torch.zeros((_CHUNK, FLOATS), dtype=torch.float32, device=dev).unbind(0), 0]
+        chunk = torch.empty((_CHUNK, FLOATS), dtype=torch.float32, device=dev)
+        with _lib.device_guard(dev):                # agent-scope zero fill: see uaps_zero_bounds (csrc/hints.hip)
+            _lib.check(_lib.lib().uaps_zero_bounds(chunk.data_ptr(), chunk.numel(), _lib.current_stream(dev)), "uaps_zero_bounds")
+        ent = _pool[key] = [chunk.unbind(0), 0]
     s = ent[0][ent[1]]
     ent[1] += 1
     return s

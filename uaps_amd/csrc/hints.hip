@@ -17,6 +17,22 @@ uaps_call_hints take_hints() {
 LaunchEvents& launch_events() { return g_launch; }
 }  // namespace uaps
 
+// Zero fill of bound slots with agent-scope stores: the slots are then raised by memory-side atomics and read with agent-scope
+// loads (hints.hpp), so every access to them bypasses the per-XCD L2s.  A plain fill leaves its zeros in one XCD's write-back L2;
+// under a hipGraph replay a late write-back of such a line was seen to wipe the raised value (the convolution then scales by a
+// different power of two and the replayed step differs from the eager one in the last bits).
+namespace {
+__global__ void zero_bounds_kernel(float* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) __hip_atomic_store(p + i, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+extern "C" int uaps_zero_bounds(float* p, long n, uaps_stream_t stream) {
+    if (!p || n <= 0) return UAPS_EINVAL;
+    hipLaunchKernelGGL(zero_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, n);
+    return (int)hipGetLastError();
+}
+
 extern "C" int uaps_next_launch_events(void* start, void* stop) {
     const int used = g_launch.used ? 1 : 0;
     g_launch.start = (hipEvent_t)start; g_launch.stop = (hipEvent_t)stop;

@@ -56,7 +56,8 @@ __device__ __forceinline__ void block_amax_to(float* dst, float v, float* smem_1
         float m = smem_16[0];
         for (int i = 1; i < nw; ++i) m = __builtin_fmaxf(m, smem_16[i]);
         unsigned* slot = reinterpret_cast<unsigned*>(dst) + ((blockIdx.x + blockIdx.y * 5u) % UAPS_BOUND_SLOTS) * UAPS_BOUND_STRIDE;
-        if (m == m && m > __builtin_bit_cast(float, __atomic_load_n(slot, __ATOMIC_RELAXED))) atomicMax(slot, __builtin_bit_cast(unsigned, m));
+        if (m == m && m > __builtin_bit_cast(float, __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(slot, __builtin_bit_cast(unsigned, m));
     }
 }
 }  // namespace uaps

@@ -577,7 +577,10 @@ __global__ __launch_bounds__(64) void bn_param_bounds_kernel(BoundBatch bb, floa
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     // a bound is UAPS_BOUND_SLOTS strided floats whose maximum counts (include/uaps_hip.h): slot 0 = m, the others 0
-    if (threadIdx.x < UAPS_BOUND_SLOTS) out[(long)i * UAPS_BOUND_FLOATS + threadIdx.x * UAPS_BOUND_STRIDE] = threadIdx.x == 0 ? m : 0.f;
+    // agent-scope stores: bounds are read with agent-scope loads (hints.hpp bound_max), every access to bound storage bypasses the XCD L2s
+    if (threadIdx.x < UAPS_BOUND_SLOTS)
+        __hip_atomic_store(out + (long)i * UAPS_BOUND_FLOATS + threadIdx.x * UAPS_BOUND_STRIDE, threadIdx.x == 0 ? m : 0.f, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
 

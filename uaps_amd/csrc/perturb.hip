@@ -12,9 +12,11 @@ namespace {
 // Zero-fill as a kernel of this library.  hipMemsetAsync in front of the atomics that accumulate into the same words is ordered
 // with them in a stream, but under hipGraph replay the FeatureDropout maxima were observed to differ from the eager step from
 // the third replay on (tools/diag/graph_val_debug.py): memset nodes and kernel nodes are different engines' work.
+// Agent-scope stores: the words are then updated by memory-side atomics; a plain store may sit in one XCD's write-back L2 and be
+// written back over them later (the same hazard as the magnitude bounds, uaps_zero_bounds in hints.hip).
 __global__ void zero_words_kernel(uint32_t* __restrict__ p, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0u;
+    if (i < n) __hip_atomic_store(p + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
 
