@@ -186,6 +186,8 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // channels and lose on 1x1 convolutions (HBM-bound, the split only adds staging work) and on the <= 8-channel layers
     // (a chunk of 8 channels fills 9 of 12 k-groups); cfg bits 29-30 != 0 force a split form regardless
     p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || ((cfg >> 29) & 3));
+    static const bool diag_no_split_fwd = getenv("UAPS_DIAG_NO_SPLIT_FWD") != nullptr;      // diagnosis only (tools/diag/share_repeat.py)
+    if (diag_no_split_fwd) p->split = false;
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
     p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);
     p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 512) ? 32 : 16;

@@ -21,6 +21,8 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     const bool force_exact = (cfg >> 28) & 1, force_split = (cfg >> 29) & 1;
     cfg &= 0xffffff;
     p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() >= 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
+    static const bool diag_no_split_wrw = getenv("UAPS_DIAG_NO_SPLIT_WRW") != nullptr;      // diagnosis only (tools/diag/share_repeat.py)
+    if (diag_no_split_wrw) p.split = false;
     // <= 4 output channels x 16 input channels on a wide map: the exact-N VALU kernel (conv_small.hpp), slabs [tap][4][16]
     p.small = ks == 3 && p.dil == 1 && W % 4 == 0 && W >= 64 && Cout <= 4 && Cin == 16 && !force_exact && !force_split;
     if (p.small) {
