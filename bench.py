@@ -346,12 +346,12 @@ def main():
                          "step_hbm_GBps": round(step_bytes / ms_per_step / 1e6, 1) if step_bytes else None,
                          "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
-        mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (bit-identical to single-stream)"
+        mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (same kernels as single-stream)"
         if graph_used and not graph_split:
-            mode = "captured hipGraph of the whole step, replayed once per step (bit-identical to the eager step); " + mode
+            mode = "captured hipGraph of the whole step, replayed once per step (the eager step's kernels and arithmetic; DESIGN.md section 4 on bit reproducibility); " + mode
         elif graph_split:
             mode = ("two captured hipGraphs per step (forward + loss + backward | Adam + metrics) replayed around the eager RCCL all-reduce of "
-                    "the flat gradient buckets (bit-identical to the eager step); ") + mode
+                    "the flat gradient buckets (the eager step's kernels and arithmetic); ") + mode
         elif use_graph:
             mode = "eager launches (the capture was requested but did not take place); " + mode
         res = {"metric": "training images/sec (labeled+unlabeled) NEU-Seg 256x256 K=3", "value": round(2 * b * world * args.steps / dt, 2),
