@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
                     help="time the headline steps with all launches on one HIP stream (default: one stream per auxiliary decoder, "
-                         "bit-identical results, launches of different decoders overlap)")
+                         "same kernels and results, launches of different decoders overlap)")
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1 only: run the timed steps eagerly instead of replaying the captured hipGraph of the step (uaps_amd/graph.py)")
     ap.add_argument("--exact-steps", type=int, default=5,
@@ -178,7 +178,7 @@ def main():
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
     # one process: the step is captured as a hipGraph after two eager steps (needs --warmup >= 3 to stay out of the timed region)
-    # and replayed, bit-identical to the eager step
+    # and replayed (the eager step's kernels and arithmetic)
     # N > 1: two graphs around the eager RCCL gradient exchange (uaps_amd/graph.py); UAPS_GRAPH_MULTI=0 keeps the eager step there
     use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or os.environ.get("UAPS_GRAPH_MULTI", "1") != "0")
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
@@ -195,7 +195,7 @@ def main():
                          "work": float(sum(r[2] for r in recs if len(r) > 2))}
         return out
 
-    # ---- headline: W warm-up steps, then exactly K timed steps, in the fastest bit-identical launch mode ----
+    # ---- headline: W warm-up steps, then exactly K timed steps, in the fastest launch mode of the same kernels ----
     for i in range(args.warmup):
         trainer.train_step(*data.next())
     torch.cuda.synchronize()
