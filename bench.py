@@ -179,8 +179,10 @@ def main():
         os.close(saved_stdout)
     # one process: the step is captured as a hipGraph after two eager steps (needs --warmup >= 3 to stay out of the timed region)
     # and replayed (the eager step's kernels and arithmetic)
-    # N > 1: two graphs around the eager RCCL gradient exchange (uaps_amd/graph.py); UAPS_GRAPH_MULTI=0 keeps the eager step there
-    use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or os.environ.get("UAPS_GRAPH_MULTI", "1") != "0")
+    # N > 1 steps eagerly (decoder streams, bucket all-reduces overlapped with the backward).  UAPS_GRAPH_MULTI=1 selects the two-graph
+    # form of uaps_amd/graph.py instead (two gloo ranks on one card: bit-equal to the eager step; over RCCL only ever run with one
+    # rank here, where tools/diag/rccl_split_graph.py once aborted behind other process groups of the same process -- so not the default)
+    use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or os.environ.get("UAPS_GRAPH_MULTI", "0") == "1")
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
     data = uaps_amd.data.SyntheticBatches(b, 3, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
 
