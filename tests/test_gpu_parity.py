@@ -460,50 +460,13 @@ def test_grad_buckets_over_rccl_single_rank(streams):
     """The N > 1 exchange step (uaps_amd.dist.GradBuckets: per-module flat buckets, asynchronous all-reduce launched from
     post-accumulate hooks during backward, gradients re-pointed at the reduced buffers) exercised over the real RCCL
     backend with one rank: with the bucket's divisor forced to 2 every gradient must come out exactly halved.  (The
-    multi-rank logic is covered on CPU by tests/test_ddp_gloo.py; this checks the nccl call path, streams and views.)"""
-    import torch.distributed as dist
-    import uaps_amd
-    import uaps_amd.unet as unet_mod
-    from uaps_amd import dist as udist, perturb
-    if dist.is_initialized():
-        pytest.skip("a process group already exists in this process")
-    # with decoder streams the bucket hooks fire on the auxiliary decoders' side streams: the all-reduce must order itself
-    # behind the stream that produced the bucket's gradients and the main stream behind the all-reduce
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29653 + int(streams)}", rank=0, world_size=1, device_id=torch.device(DEV))
-    unet_mod._DECODER_STREAMS = streams
-    try:
-        def grads(with_buckets):
-            torch.manual_seed(9); np.random.seed(9); perturb.manual_seed(9)
-            model = uaps_amd.net_factory("unet_uaps", 3, 4).to(DEV)
-            data = uaps_amd.data.SyntheticBatches(2, 3, 4, 32, 32, n_batches=1, seed=9, device=DEV)
-            x_l, y_l, x_u = data.next()
-            buckets = None
-            if with_buckets:
-                buckets = udist.GradBuckets(model)
-                buckets.world = 2                                   # divisor of the average; one rank contributes the sum
-                for bi, params in enumerate(buckets.buckets):       # register the hooks the world > 1 constructor would
-                    for p in params:
-                        buckets._hooks.append(p.register_post_accumulate_grad_hook(buckets._make_hook(bi)))
-                buckets.reset()
-            both = model.forward_pair(x_l, x_u)
-            out = uaps_amd.uaps_pair_loss(both, y_l, np.full(4, 0.25), 0.1, 0.1)
-            out.loss.backward()
-            if buckets is not None:
-                buckets.finish()
-                for bi, params in enumerate(buckets.buckets):       # the kernels wrote into the flat buffers, RCCL reduced in place
-                    for k, p in enumerate(params):
-                        assert p.grad.data_ptr() == buckets._view(bi, k).data_ptr()
-            torch.cuda.synchronize()
-            out = [p.grad.clone() for p in model.parameters()]
-            if buckets is not None:
-                buckets.remove()
-            return out
-
-        ref, got = grads(False), grads(True)
-        assert len(ref) == len(got) == 208
-        for a, b in zip(ref, got):
-            assert torch.equal(b, a * 0.5)
-    finally:
-        unet_mod._DECODER_STREAMS = False
-        dist.destroy_process_group()
-
+    multi-rank logic is covered on CPU by tests/test_ddp_gloo.py and on the GPU by tests/test_gpu_two_ranks.py; this checks the
+    nccl call path, streams and views.)  Runs in a child process (tests/rccl_single_rank_check.py): a process group, its
+    watchdog thread and its teardown stay out of the test runner, which was twice seen to abort from a non-Python thread
+    somewhere behind these checks."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_single_rank_check.py"), str(int(streams))],
+                       capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "RCCL_CHECK_OK" in r.stdout
