@@ -348,9 +348,12 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above; process-wide, not 
  *                     longer cancels for channels with |mean| >> std (fp32 partial sums).  The call that CONSUMES those
  *                     partials (uaps_bn_act_fwd_train_partials, uaps_bn_finalize_train) must be given the same two
  *                     pointers in its own hints; it reads them before it updates running_mean.
- *   out_amax          a bound (UAPS_BOUND_FLOATS floats, zero-initialised by the caller) whose slots the producing kernel raises
- *                     atomically so that value(out_amax) = maximum |element| of its output tensor: the bound of a later
- *                     convolution's operand. */
+ *   out_amax          a bound (UAPS_BOUND_FLOATS floats, zero-initialised by the caller WITH uaps_zero_bounds) whose slots the
+ *                     producing kernel raises atomically so that value(out_amax) = maximum |element| of its output tensor: the
+ *                     bound of a later convolution's operand.
+ * Bound storage is read by the kernels with agent-scope loads and raised by memory-side atomics; whoever else writes it must
+ * write past the per-XCD L2s too (uaps_zero_bounds, uaps_bn_param_bounds do; a plain fill or copy of the same kernel stream is
+ * coherent only after that kernel has ended -- under a hipGraph replay not even then). */
 #define UAPS_BOUND_SLOTS 16
 #define UAPS_BOUND_STRIDE 64
 #define UAPS_BOUND_FLOATS (UAPS_BOUND_SLOTS * UAPS_BOUND_STRIDE)
