@@ -234,3 +234,80 @@ def test_graph_replay_tracks_the_eager_step_in_the_default_mode(streams, monkeyp
     for (n, pa), pb in zip(m0.named_parameters(), m1.parameters()):
         scale = float(pa.abs().max()) + 1e-12
         assert float((pa - pb).abs().max()) <= 1e-4 * scale, n
+
+
+def test_graph_trainer_takes_a_ragged_batch_and_a_caller_supplied_mix():
+    """A trainer built with use_graph=True whose step cannot go through the state-mode body (x_l.shape != x_u.shape: a ragged
+    last batch; or caller-supplied mixing weights) runs the plain eager step for that call -- Adam's scalars by value -- and
+    replays again afterwards with the right Adam step count."""
+    import uaps_amd
+    m0 = _model(6)
+    m1 = copy.deepcopy(m0)
+    m0.to(DEV), m1.to(DEV)
+    plain = uaps_amd.UAPSTrainer(m0, base_lr=1e-3, seed=3)
+    graph = uaps_amd.UAPSTrainer(m1, base_lr=1e-3, seed=3, use_graph=True)
+    same = _batches(5, 2, 64, 64, seed=21)
+    (xl, y, _), = _batches(1, 2, 64, 64, seed=22)
+    (_, _, xu3), = _batches(1, 3, 64, 64, seed=23)
+    seq = same[:3] + [(xl, y, xu3)] + same[3:]
+    for i, (a, b, c) in enumerate(seq):
+        r = graph.train_step(a, b, c)
+        assert np.isfinite(float(r["loss"])), i
+    assert graph.step_graph.graph is not None and graph.iter_num == 6
+    steps = {float(st["step"]) for st in graph.optimizer.state.values()}
+    assert steps == {6.0}
+    # explicit mixing weights: eager route as well
+    w = np.full(4, 0.25)
+    r = graph.train_step(*same[0], w=w)
+    assert np.isfinite(float(r["loss"])) and np.array_equal(r["w"], w)
+    del plain
+
+
+def test_returned_scalars_are_not_aliases_of_the_graph_outputs():
+    import uaps_amd
+    m = _model(8).to(DEV)
+    tr = uaps_amd.UAPSTrainer(m, base_lr=1e-2, seed=2, use_graph=True)
+    kept = [tr.train_step(*b)["loss"] for b in _batches(6, 2, 64, 64, seed=31)]
+    vals = [float(v) for v in kept]
+    assert tr.step_graph.graph is not None and len(set(vals[2:])) == 4, vals      # replayed steps keep their own values
+
+
+def test_checkpoint_load_drops_the_capture(tmp_path):
+    """load_checkpoint replaces Adam's moment tensors: a captured step would keep updating the old buffers through its frozen
+    pointers.  After a load the step warms up and captures again, and continues exactly like an eager state-mode trainer that
+    loaded the same checkpoint."""
+    import os
+    import uaps_amd
+    from uaps_amd import conv
+    prev = conv.get_mode()
+    conv.set_mode("exact")
+    try:
+        m0 = _model(9)
+        m1, m2 = copy.deepcopy(m0), copy.deepcopy(m0)
+        m0.to(DEV), m1.to(DEV), m2.to(DEV)
+        bs = _batches(10, 2, 64, 64, seed=41)
+        src = uaps_amd.UAPSTrainer(m0, base_lr=1e-3, seed=4, use_graph=True)
+        for b in bs[:4]:
+            src.train_step(*b)
+        path = os.path.join(tmp_path, "ck.pth")
+        src.save_checkpoint(path, 1, 0.5)
+        assert "step_key" in torch.load(path, weights_only=False)
+        g = uaps_amd.UAPSTrainer(m1, base_lr=1e-3, seed=4, use_graph=True)
+        e = uaps_amd.UAPSTrainer(m2, base_lr=1e-3, seed=4, step_state=True)
+        for b in bs[4:7]:                            # train a little first, so that a capture exists when the checkpoint arrives
+            g.train_step(*b)
+        assert g.step_graph.graph is not None
+        g.load_checkpoint(path); e.load_checkpoint(path)
+        assert g.step_graph.graph is None and g.step_graph.state.key == src.step_graph.state.key == e.step_graph.state.key
+        for i, b in enumerate(bs[4:]):
+            uaps_amd.perturb.manual_seed(4, 0); np.random.seed(4)
+            le = float(e.train_step(*b)["loss"])
+            uaps_amd.perturb.manual_seed(4, 0); np.random.seed(4)
+            lg = float(g.train_step(*b)["loss"])
+            assert le == lg, (i, le, lg)
+        assert g.step_graph.graph is not None
+        for (n, pa), pb in zip(m1.named_parameters(), m2.parameters()):
+            assert torch.equal(pa, pb), n
+        assert {float(st["step"]) for st in g.optimizer.state.values()} == {10.0}
+    finally:
+        conv.set_mode(prev)

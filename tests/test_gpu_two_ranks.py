@@ -38,7 +38,14 @@ def _batch(rank, step):
             torch.randn(2, 3, 64, 64, generator=g).to("cuda:0"))
 
 
-def _worker(rank, world, port, out_dir, gathered, streams, steps):
+def _ragged_batch(rank, step):
+    """A last batch of a finite loader: 2 labelled but 3 unlabelled images (neither the reference nor this build sets drop_last)."""
+    x_l, y_l, _ = _batch(rank, step)
+    g = torch.Generator().manual_seed(7000 + 10 * step + rank)
+    return x_l, y_l, torch.randn(3, 3, 64, 64, generator=g).to("cuda:0")
+
+
+def _worker(rank, world, port, out_dir, gathered, streams, steps, pair=True, ragged=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -48,11 +55,11 @@ def _worker(rank, world, port, out_dir, gathered, streams, steps):
     unet._DECODER_STREAMS = streams
     model = _make_model(seed=rank)                 # different init per rank: the broadcast must fix it
     uaps_amd.dist.broadcast_model(model)
-    tr = uaps_amd.UAPSTrainer(model, seed=SEED, gathered_loss=gathered)
+    tr = uaps_amd.UAPSTrainer(model, seed=SEED, gathered_loss=gathered, pair_forward=pair)
     assert tr.world == world and tr.buckets is not None
     rec = []
     for s in range(steps):
-        res = tr.train_step(*_batch(rank, s))
+        res = tr.train_step(*(_ragged_batch if ragged else _batch)(rank, s))
         rec.append({"w": res["w"], "loss": float(res["loss"]),
                     "grads": {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}})
     torch.cuda.synchronize()
@@ -62,9 +69,9 @@ def _worker(rank, world, port, out_dir, gathered, streams, steps):
     dist.destroy_process_group()
 
 
-def _run(tmp_path, gathered, streams, steps):
+def _run(tmp_path, gathered, streams, steps, pair=True, ragged=False):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), gathered, streams, steps), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), gathered, streams, steps, pair, ragged), nprocs=2, join=True)
     return [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(2)]
 
 
@@ -102,6 +109,36 @@ def test_two_ranks_average_gradients(tmp_path, streams):
     for n, g in r0["steps"][0]["grads"].items():
         want = (own[0][n] + own[1][n]) * 0.5
         assert torch.equal(g, want), (n, float((g - want).abs().max()))
+
+
+@pytest.mark.parametrize("case", ["two_forwards", "ragged_batch"])
+def test_two_ranks_two_forward_route_adds_both_gradients(tmp_path, case):
+    """The route with TWO forwards of one model per step (pair_forward=False, or a ragged last batch whose halves cannot be
+    concatenated): every parameter then has two gradient-producing nodes in one backward.  Its bucket slice must be handed out
+    once -- handed out twice, the second node overwrites the first and the exchanged gradient is 2 g_unlabelled instead of
+    g_labelled + g_unlabelled.  Checked against the two shards' own single-process gradients."""
+    ragged = case == "ragged_batch"
+    r0, r1 = _run(tmp_path, gathered=False, streams=False, steps=1, pair=not ragged, ragged=ragged)
+    import uaps_amd
+    from uaps_amd import conv, perturb
+    prev_mode = conv.get_mode()
+    conv.set_mode(MODE)
+    own = []
+    try:
+        for rank in range(2):
+            model = _make_model(seed=0)
+            tr = uaps_amd.UAPSTrainer(model, seed=SEED, pair_forward=not ragged)
+            np.random.seed(SEED + rank)
+            perturb.manual_seed(SEED, rank)
+            tr.train_step(*(_ragged_batch if ragged else _batch)(rank, 0))
+            own.append({n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+    finally:
+        conv.set_mode(prev_mode)
+    for n, g in r0["steps"][0]["grads"].items():
+        assert torch.equal(g, r1["steps"][0]["grads"][n]), n
+        want = (own[0][n] + own[1][n]) * 0.5
+        scale = float(want.abs().max()) + 1e-30
+        assert float((g - want).abs().max()) <= 2e-6 * scale, (n, float((g - want).abs().max()), scale)
 
 
 def test_two_ranks_gathered_loss(tmp_path):

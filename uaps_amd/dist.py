@@ -91,8 +91,10 @@ class GradBuckets:
         self.reset()
 
     def reset(self):
+        from . import _graddest
         self._pending = [len(b) for b in self.buckets]
         self._handles = []
+        _graddest.new_backward()
 
     def _make_hook(self, bi: int):
         def hook(_param):
@@ -143,6 +145,18 @@ class GradBuckets:
         produced elsewhere would need the per-step copy of _launch, which a replay does not run)."""
         return all(p.grad is not None and p.grad.data_ptr() == self._view(bi, k).data_ptr()
                    for bi, params in enumerate(self.buckets) for k, p in enumerate(params))
+
+    def gather_in(self):
+        """Copy every gradient that was produced outside its slice into the flat buffers and re-point .grad (what _launch does
+        per bucket)."""
+        for bi, params in enumerate(self.buckets):
+            for k, p in enumerate(params):
+                v = self._view(bi, k)
+                if p.grad is None:
+                    raise RuntimeError(f"bucket {self.names[bi]}: a parameter got no gradient this step")
+                if p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
 
     def exchange_all(self):
         """All buckets at once, no hooks involved (between the two replays of graph.StepGraph): all-reduce, wait, average."""

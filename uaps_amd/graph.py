@@ -93,18 +93,26 @@ class StepGraph:
         self.calls = 0
         self.static = None
         self._side = torch.cuda.Stream(device=trainer.device) if capture else None
-        self._adam_t = None
+        # data parallel + capture: every step of every rank, warm-up and fallback steps included, launches the bucket
+        # all-reduces in ONE fixed order after the backward (exchange_all), never from the backward hooks -- a rank whose
+        # capture failed, or that steps eagerly for another reason, still pairs the same buckets as the ranks that replay
+        self.fixed_order = self.split and capture
         trainer.optimizer.from_step_state = True
+
+    def invalidate(self) -> None:
+        """Forget the capture (checkpoint load, anything that replaced tensors the graph addresses): the next steps warm up
+        eagerly and the step is recorded again."""
+        self.graph = self.graph_tail = self.static = None
+        self.calls = 0
 
     # ---- host side of one step: what the reference's loop computes on the host (UAPS_train.py:251, 279-280, 292) ----
     def _refresh(self):
         tr = self.tr
         opt = tr.optimizer
-        if self._adam_t is None:
-            st = [opt.state[p].get("step") for g in opt.param_groups for p in g["params"] if p in opt.state]
-            self._adam_t = int(st[0]) if st else 0
-        self._adam_t += 1
-        ss, isb = opt.step_scalars(self._adam_t)
+        # Adam's step count is read from the optimizer state every step (host tensors: no device sync), so that an eager
+        # fallback step or a loaded checkpoint in between cannot leave a cached count behind
+        st = next((opt.state[p]["step"] for g in opt.param_groups for p in g["params"] if p in opt.state and "step" in opt.state[p]), None)
+        ss, isb = opt.step_scalars((int(st) if st is not None else 0) + 1)
         w = tr.mix_rng.dirichlet(np.ones(tr.n_heads), size=1)[0]
         cw1, cw2 = tr.consistency_weights()
         self.state.fill(w, cw1, cw2, ss, isb)
@@ -127,6 +135,17 @@ class StepGraph:
 
     def _body(self, x_l, y_l, x_u):
         """The device work of one step, eagerly (state mode, warm-up steps)."""
+        if self.fixed_order:
+            self.tr.buckets.defer = True
+            try:
+                out, both = self._head(x_l, y_l, x_u)
+            finally:
+                self.tr.buckets.defer = False
+            if not self.tr.buckets.in_place():
+                self.tr.buckets.gather_in()
+            self.tr.buckets.exchange_all()
+            self.tr.buckets.reset()
+            return out, self._tail(both, x_l, y_l)
         out, both = self._head(x_l, y_l, x_u)
         if self.split:
             self.tr.buckets.finish()                 # overlapped with the backward by the bucket hooks
@@ -187,7 +206,10 @@ class StepGraph:
         if cm is not None:
             tr._cms.append(cm.clone() if self.graph is not None else cm)
         tr.iter_num += 1
-        tr.last = {"loss": out.loss.detach(), "sup": out.sup.detach(), "unsup": out.unsup.detach(), "cw1": cw1, "cw2": cw2, "w": w}
+        # a replay overwrites the graph's static output tensors: hand out copies (as for the confusion matrix above), so that
+        # scalars a caller collects over an epoch keep their own step's values
+        sc = (lambda t: t.detach().clone()) if self.graph is not None else (lambda t: t.detach())
+        tr.last = {"loss": sc(out.loss), "sup": sc(out.sup), "unsup": sc(out.unsup), "cw1": cw1, "cw2": cw2, "w": w}
         return tr.last
 
     # ---- capture / replay ----

@@ -71,6 +71,17 @@ class UAPSTrainer:
         """Returns device scalars (loss, sup, unsup); nothing here synchronises with the host."""
         if self.step_graph is not None and w is None and x_l.shape == x_u.shape:
             return self.step_graph.step(x_l, y_l, x_u)
+        if self.step_graph is not None:
+            # a step the state-mode body does not cover (caller-supplied mixing weights, a ragged last batch): the plain eager
+            # step, with Adam's scalars passed by value for this one step (no step state is active here)
+            prev, self.optimizer.from_step_state = self.optimizer.from_step_state, False
+            try:
+                return self._eager_step(x_l, y_l, x_u, w)
+            finally:
+                self.optimizer.from_step_state = prev
+        return self._eager_step(x_l, y_l, x_u, w)
+
+    def _eager_step(self, x_l, y_l, x_u, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:                      # model.train() walks ~2600 modules: only when the mode changes
             self.model.train()
         cw1, cw2 = self.consistency_weights()
@@ -147,14 +158,71 @@ class UAPSTrainer:
         m["loss"] = float(sum(0.5 * ((1 - p["mdice"]) + c) for p, c in zip(per, ce)) / n)                  # :386, 394
         return m
 
+    # -- the epoch loop (UAPS_train.py:127-159, 316-329, 367-402, 427-450) --
+    def fit(self, train_batches, unlabeled_batches, val_batches, epochs: int = 800, iter_per_epoch: int = 60,
+            checkpoint_path: Optional[str] = None, start_epoch: int = 1, best_dice: float = 0.0,
+            log: Optional[Callable[[Dict], None]] = None):
+        """The reference's `Network.run()` around `train_step`, with its off-by-one conventions kept:
+
+        * `for epoch in range(1, epochs)` (:127) -- epochs - 1 epochs; `start_epoch` resumes a run (pass the checkpoint's
+          `epoch + 1` and `best_dice_1`, after `load_checkpoint`);
+        * every epoch draws `iter_per_epoch - 1` steps (`range(1, iter_per_epoch)`, :159) from a FRESH
+          `zip(cycle(train), cycle(unlabeled))` -- the over-sampling form of DAGM-Dataset-codes/UAPS_train.py:143; the NEU
+          script's plain `zip` (:157) raises StopIteration as soon as the labelled loader is shorter than an epoch;
+        * the logged training means divide the running sums by `iter_per_epoch`, not by the number of steps (:316-321);
+        * the consistency ramp runs on `iter_num // 80` across epochs (:279-280; `ramp_divisor`);
+        * validation on the main head (:367-399), `scheduler.step(val mDice)` (:402), and the checkpoint is written only when
+          the validation mDice is STRICTLY greater than the best so far (:427-450; the reference's initial best is False == 0).
+
+        `train_batches` / `unlabeled_batches` / `val_batches`: re-iterables (lists, DataLoaders) of (x, y) pairs, the
+        unlabelled labels are ignored (:166).  Nothing inside an epoch synchronises with the host; the epoch's scalars are
+        fetched with one copy at its end.  Returns the per-epoch records (also handed to `log`)."""
+        import itertools
+        history = []
+        patience = 0
+        for epoch in range(int(start_epoch), int(epochs)):
+            semi = iter(zip(itertools.cycle(train_batches), itertools.cycle(unlabeled_batches)))
+            kept = []
+            for _ in range(1, int(iter_per_epoch)):
+                (x_l, y_l), u = next(semi)
+                x_u = u[0] if isinstance(u, (tuple, list)) else u
+                res = self.train_step(x_l.to(self.device), y_l.to(self.device), x_u.to(self.device))
+                kept.append(torch.stack([res["loss"].float(), res["sup"].float(), res["unsup"].float()]))
+            rec: Dict = {"epoch": epoch, "iter_num": self.iter_num, "lr": float(self.optimizer.param_groups[0]["lr"])}
+            if kept:
+                sums = torch.stack(kept).sum(0).double().cpu().numpy()
+                rec.update(loss=float(sums[0]) / iter_per_epoch, sup=float(sums[1]) / iter_per_epoch,
+                           unsup=float(sums[2]) / iter_per_epoch)
+                tm = self.epoch_metrics()                       # mean over the epoch's batches
+                n = len(kept)
+                rec.update(train_miou=tm["miou"] * n / iter_per_epoch, train_mdice=tm["mdice"] * n / iter_per_epoch)
+            rec["cw1"], rec["cw2"] = self.consistency_weights()
+            val = self.validate(val_batches)
+            rec.update({"val_" + k: v for k, v in val.items()})
+            self.scheduler.step(val["mdice"])                                                              # :402
+            if best_dice < val["mdice"]:                                                                   # :427-433
+                best_dice, patience, rec["saved"] = val["mdice"], 0, True
+                if checkpoint_path is not None:
+                    self.save_checkpoint(checkpoint_path, epoch, best_dice)                                # :440-450
+            else:
+                patience, rec["saved"] = patience + 1, False
+            rec["best_dice"], rec["patience"] = best_dice, patience
+            history.append(rec)
+            if log is not None:
+                log(rec)
+        return history
+
     # -- checkpoint (UAPS_train.py:437-450) --
     def state_for_checkpoint(self, epoch: int, best_dice: float, dataparallel_prefix: bool = True) -> Dict:
         sd = self.model.state_dict()
         if dataparallel_prefix and not any(k.startswith("module.") for k in sd):
             sd = {"module." + k: v for k, v in sd.items()}     # the reference saves nn.DataParallel(model).state_dict()
         # the reference's four keys (UAPS_train.py:443-448) + what a resume needs (its loaders ignore unknown keys)
-        return {"epoch": epoch, "best_dice_1": best_dice, "state_dict": sd, "optimizer": self.optimizer.state_dict(),
-                "iter_num": self.iter_num, "scheduler": self.scheduler.state_dict()}
+        ck = {"epoch": epoch, "best_dice_1": best_dice, "state_dict": sd, "optimizer": self.optimizer.state_dict(),
+              "iter_num": self.iter_num, "scheduler": self.scheduler.state_dict(), "mix_rng": self.mix_rng.get_state()}
+        if self.step_graph is not None:
+            ck["step_key"] = int(self.step_graph.state.key)      # the Philox key of the state-mode perturbation streams
+        return ck
 
     def save_checkpoint(self, path: str, epoch: int, best_dice: float):
         if self.rank == 0:
@@ -175,6 +243,14 @@ class UAPSTrainer:
                 self.iter_num = int(ck["iter_num"])
             if "scheduler" in ck:
                 self.scheduler.load_state_dict(ck["scheduler"])
+            if "mix_rng" in ck:
+                self.mix_rng.set_state(ck["mix_rng"])
+        if self.step_graph is not None:
+            # a captured step holds the OLD Adam moment buffers through frozen pointers (load_state_dict replaced them):
+            # drop the capture, it is re-recorded after the warm-up steps; the Adam step count is re-read from the loaded state
+            self.step_graph.invalidate()
+            if "step_key" in ck:
+                self.step_graph.state.key = int(ck["step_key"])
         return ck
 
 
