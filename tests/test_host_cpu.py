@@ -161,7 +161,7 @@ def test_checkpoint_layout_round_trip(tmp_path):
     tr.save_checkpoint(path, epoch=7, best_dice=0.5)
     ck = torch.load(path, weights_only=False)
     # the reference's four keys (UAPS_train.py:443-448) + the resume extras its loaders ignore
-    assert {"epoch", "best_dice_1", "state_dict", "optimizer"} <= set(ck) <= {"epoch", "best_dice_1", "state_dict", "optimizer", "iter_num", "scheduler"}
+    assert {"epoch", "best_dice_1", "state_dict", "optimizer"} <= set(ck) <= {"epoch", "best_dice_1", "state_dict", "optimizer", "iter_num", "scheduler", "mix_rng", "step_key"}
     assert all(k.startswith("module.") for k in ck["state_dict"]) and len(ck["state_dict"]) == 334
     assert "module.encoder.in_conv.conv_conv.0.weight" in ck["state_dict"]
     # the reference's way of consuming it: DataParallel(model).load_state_dict(ckpt['state_dict'])
