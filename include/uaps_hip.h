@@ -9,8 +9,15 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all memory;
  *   - tensors are dense fp32 NCHW exactly as the reference's decoders produce them; labels and
  *     pseudo-labels are int64 [B,H,W] as torch.argmax / the reference's data loader produce them;
- *   - `stream` is a hipStream_t (0 = the null stream); calls only enqueue work, never synchronise,
- *     never allocate, keep no global state and are re-entrant per stream (safe under hipGraph capture);
+ *   - `stream` is a hipStream_t (0 = the null stream); calls only enqueue work, never synchronise, never allocate, read no
+ *     environment variable and are safe under hipGraph capture.  The library keeps exactly this state, all of it set by the
+ *     caller through the entry points named here and none of it stream-ordered (change it between steps):
+ *       process-wide   the convolution arithmetic (uaps_conv_set_mode) and planner switches (uaps_conv_set_tuning), the pointer
+ *                      to the device-resident step state (uaps_set_step_state: NULL outside a state-mode step; two trainers in
+ *                      one process each bracket their steps with set / clear, see uaps_amd/graph.py) and the pointer to the
+ *                      sticky device error word (uaps_set_error_word);
+ *       per thread     the one-shot side arguments of the NEXT call (uaps_next_call_hints, uaps_next_launch_events), consumed
+ *                      and cleared by that call;
  *   - return value: 0 on success, a negative UAPS_E* code for bad arguments, a positive hipError_t
  *     if a launch failed.  Nothing throws.
  *   - number of heads D in [1,8] (main + auxiliary decoders), classes C in [2,8].
@@ -327,7 +334,26 @@ int uaps_bn_param_bounds(const float* const* gamma_host, const float* const* bet
  * Bits 24-27 of `cfg` are functional: the dilation of a 3x3 kernel, 0/1 (none), 2 or 4, with padding = dilation
  * (the dilated stages of utilities/resnet.py:8-10, 201-203); pass the same value to all three directions.
  * ------------------------------------------------------------------------------------------- */
-int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above; process-wide, not stream-ordered: set it between steps */
+int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above (default 2); process-wide, not stream-ordered: set it between steps */
+/* Planner switches for ablation runs and diagnosis (tools/ablation.sh, tools/diag); 0 = the shipped plan. */
+#define UAPS_TUNE_NO_SPLIT_FWD 1u      /* forward / input gradient on the fp32 matrix instruction whatever the mode */
+#define UAPS_TUNE_NO_SPLIT_WRW 2u      /* weight gradient likewise */
+#define UAPS_TUNE_NO_SMALL 4u          /* no exact-N class kernels (csrc/conv_small.hpp) */
+#define UAPS_TUNE_NO_HP16 8u           /* no persistent 16-output-channel kernels (csrc/conv_split_n16.hpp) */
+#define UAPS_TUNE_WRW_ROW_MAJOR 16u    /* split weight gradient: row-major instead of column-strip tile order */
+#define UAPS_TUNE_WRW_SHORT_TILES 32u  /* split weight gradient: 4-row tiles also on the 16-output-channel layers */
+int uaps_conv_set_tuning(unsigned flags);
+unsigned uaps_conv_get_tuning(void);
+
+/* Sticky device error word.  The fp16-split convolutions (mode 2) trust the magnitude bounds they are handed: a bound that
+ * is too small by more than the 2x headroom lets a scaled operand overflow fp16, and every output it touches comes back
+ * NaN.  Those kernels check what they store and OR a UAPS_ERR_* bit into *device_word (4-byte aligned device memory owned
+ * and zeroed by the caller; NULL = no reporting) when a stored value is not finite -- so a violated bound, or non-finite data
+ * entering a convolution, is reported instead of training on.  Read the word whenever the host synchronises anyway
+ * (UAPSTrainer.epoch_metrics / validate / check_errors do). */
+#define UAPS_ERR_CONV_NONFINITE 1u     /* an fp16-split forward / input-gradient convolution stored a non-finite value */
+#define UAPS_ERR_WRW_NONFINITE 2u      /* an fp16-split weight-gradient convolution produced a non-finite partial sum */
+int uaps_set_error_word(unsigned* device_word);
 
 /* One-shot side arguments for the NEXT kernel entry point called on this thread; that call consumes and clears them
  * (every convolution entry point, uaps_bn_act_fwd_train_partials, uaps_bn_finalize_train, uaps_bn_act_bwd*,

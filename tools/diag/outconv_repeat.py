@@ -52,8 +52,14 @@ bad_xf = torch.zeros((), dtype=torch.int64, device=dev); bad_z = torch.zeros((),
 nbad_elems = torch.zeros((), dtype=torch.int64, device=dev)
 maxd = torch.zeros((), device=dev)
 t0 = time.time()
+events = []
 for i in range(reps):
     xf, z = pair()
+    if len(events) < 6 and i % 50 == 49:          # (cheap) look for a deviation every 50 launches and keep its geometry
+        d = (z.view(torch.int32) != z0.view(torch.int32))
+        if bool(d.any()):
+            idx = d.nonzero()
+            events.append((i, idx.cpu(), (z - z0)[d].cpu(), z[d].cpu(), z0[d].cpu()))
     bad_xf += (xf.view(torch.int32) != xf0.view(torch.int32)).any()
     ne = z.view(torch.int32) != z0.view(torch.int32)
     bad_z += ne.any(); nbad_elems += ne.sum()
@@ -61,3 +67,7 @@ for i in range(reps):
 torch.cuda.synchronize()
 print(f"pid {os.getpid()} ctx {ctx} mode {CV.get_mode()}: {reps} pairs: xf differed {int(bad_xf)} times, z differed {int(bad_z)} times "
       f"({int(nbad_elems)} elements, max |diff| {float(maxd):.3e}) in {time.time() - t0:.0f}s", flush=True)
+for i, idx, dv, zv, z0v in events:
+    print(f"launch {i}: {idx.shape[0]} elements differ; (b, c, y, x) -> got / want:")
+    for r in range(min(idx.shape[0], 80)):
+        print("   ", idx[r].tolist(), f"{float(zv[r]):+.5f} / {float(z0v[r]):+.5f}")

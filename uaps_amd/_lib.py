@@ -57,6 +57,9 @@ SIGNATURES = {
     "uaps_up_cat_bwd": (C.c_int, [_PTR] * 3 + [C.c_int] * 5 + [_PTR]),
     "uaps_conv_set_mode": (C.c_int, [C.c_int]),
     "uaps_conv_get_mode": (C.c_int, []),
+    "uaps_conv_set_tuning": (C.c_int, [C.c_uint]),
+    "uaps_conv_get_tuning": (C.c_uint, []),
+    "uaps_set_error_word": (C.c_int, [_PTR]),
     "uaps_conv_pack_floats": (C.c_int, [C.c_int] * 3 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "uaps_conv_pack_weights": (C.c_int, [_PTR] + [C.c_int] * 3 + [_PTR, _PTR, _PTR]),
     "uaps_conv_pack_weights_batch": (C.c_int, [_PTR] * 6 + [C.c_int, _PTR]),
@@ -144,8 +147,29 @@ def lib() -> C.CDLL:
                 except AttributeError as e:
                     raise UapsHipError(f"libuaps_hip.so does not export {name}; rebuild it") from e
                 fn.restype, fn.argtypes = res, args
+            _configure_from_environment(l)
             _lib = l
     return _lib
+
+
+# planner switches of uaps_conv_set_tuning (include/uaps_hip.h: UAPS_TUNE_*) <- the environment variables the ablation and
+# diagnosis scripts set; the library itself reads no environment
+_TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, None), ("UAPS_DIAG_NO_SMALL", 4, None),
+             ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"))
+
+
+def _configure_from_environment(l) -> None:
+    mode = os.environ.get("UAPS_CONV_MODE")
+    if mode:                                    # "0" / "exact" / "f32";  "1" / "bf16" / "split";  "2" / "h16"
+        m = 0 if mode[0] in "0ef" else (1 if mode[0] in "1bs" else 2)
+        if l.uaps_conv_set_mode(m) != 0:
+            raise UapsHipError(f"UAPS_CONV_MODE={mode}: uaps_conv_set_mode failed")
+    flags = 0
+    for name, bit, on_value in _TUNE_ENV:
+        v = os.environ.get(name)
+        if v is not None and (on_value is None or v == on_value):
+            flags |= bit
+    l.uaps_conv_set_tuning(flags)
 
 
 class CallHints(C.Structure):

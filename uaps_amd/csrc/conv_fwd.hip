@@ -13,20 +13,18 @@ using namespace uaps;
 // 0 = exact fp32 matrix instructions (v_mfma_f32_16x16x4_f32), 1 = exact 3-way bf16 split on the bf16 matrix pipe,
 // 2 (default) = 1, and the two-piece fp16 split for operands with a known magnitude bound (conv_split.hpp).
 // Initialised from UAPS_CONV_MODE, switchable with uaps_conv_set_mode.
-static int g_conv_mode = -1;
-static int conv_mode() {
-    if (g_conv_mode < 0) {
-        const char* e = getenv("UAPS_CONV_MODE");
-        g_conv_mode = !e ? 2 : ((e[0] == '0' || e[0] == 'e' || e[0] == 'f') ? 0 : ((e[0] == '1' || e[0] == 'b' || e[0] == 's') ? 1 : 2));
-    }                                                                // "0" / "exact" / "f32";  "1" / "bf16" / "split";  "2" / "h16"
-    return g_conv_mode;
-}
+// Set with uaps_conv_set_mode (the Python layer forwards UAPS_CONV_MODE once at load); the library itself reads no environment.
+static int g_conv_mode = 2;
+static unsigned g_conv_tuning = 0;      // UAPS_TUNE_* bits (uaps_conv_set_tuning): ablation / diagnosis switches of the planners
+static int conv_mode() { return g_conv_mode; }
 extern "C" int uaps_conv_set_mode(int mode) {
     if (mode != 0 && mode != 1 && mode != 2) return UAPS_EINVAL;
     g_conv_mode = mode;
     return UAPS_OK;
 }
 extern "C" int uaps_conv_get_mode(void) { return conv_mode(); }
+extern "C" int uaps_conv_set_tuning(unsigned flags) { g_conv_tuning = flags; return UAPS_OK; }
+extern "C" unsigned uaps_conv_get_tuning(void) { return g_conv_tuning; }
 
 namespace {
 
@@ -176,7 +174,7 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     p->bn = bn;
     p->small = 0;
     if (ks == 3 && p->dil == 1 && W % 4 == 0 && W >= 64 && H >= 8 && !(cfg & 0x70ffffff)) {
-        if (Cout <= 4 && Cin % 8 == 0 && Cin <= 64) p->small = 1;
+        if (Cout <= 4 && Cin % 8 == 0 && Cin <= 32) p->small = 1;      // conv_small_body: KMAX
         // (the mirror case, <= 4 contraction channels -> 16 outputs, measured 52 us against 47 us of the fp32 MFMA kernel at
         // 4 -> 16 @ 256 x 256, B = 32: not used)
     }
@@ -186,8 +184,7 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // channels and lose on 1x1 convolutions (HBM-bound, the split only adds staging work) and on the <= 8-channel layers
     // (a chunk of 8 channels fills 9 of 12 k-groups); cfg bits 29-30 != 0 force a split form regardless
     p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || ((cfg >> 29) & 3));
-    static const bool diag_no_split_fwd = getenv("UAPS_DIAG_NO_SPLIT_FWD") != nullptr;      // diagnosis only (tools/diag/share_repeat.py)
-    if (diag_no_split_fwd) p->split = false;
+    if (g_conv_tuning & UAPS_TUNE_NO_SPLIT_FWD) p->split = false;
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
     p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);
     p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 512) ? 32 : 16;
@@ -228,7 +225,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool wide = p.tw == 32;
     // a side with <= 4 channels: the exact-N fp32 kernels (no BatchNorm statistics epilogue, one tensor per side)
-    static const bool no_small = getenv("UAPS_DIAG_NO_SMALL") != nullptr;         // diagnosis only
+    const bool no_small = (g_conv_tuning & UAPS_TUNE_NO_SMALL) != 0;
     if (!no_small && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
     if (p.split) {
         // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
@@ -241,9 +238,10 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             a.wp = a.wp + 3 * piece + kH16Header;
             a.in_bound = hints.bound[0]; a.in_mul = hints.mul[0];
             if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[1]; a.in2_mul = hints.mul[1]; }
+            a.err = uaps::error_word();
         }
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
-        static const bool no_hp16 = getenv("UAPS_DIAG_NO_HP16") != nullptr;      // diagnosis only (tools/diag/dp_repeat.py)
+        const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
         if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
         return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);

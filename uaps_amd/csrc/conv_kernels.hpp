@@ -26,12 +26,28 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/uaps_hip.h"
 
 namespace uaps {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// {w, w} for a packed fp32 instruction, with w pinned to the LOW register of an aligned pair: the consumer then broadcasts
+// with `op_sel_hi:[..0..]` (high half from the low register) and never with the low-half-from-the-high-register form that
+// misbehaves beside 16x16x32 matrix instructions on MI355X (the packed-operand rule of conv_small.hpp).  The empty asm hides
+// where w came from; the pair's high register is left undefined.  Costs at most one v_mov_b32.
+__device__ __forceinline__ f32x2 bcast_lo(float w) {
+    f32x2 t;
+    t.x = w;
+    t.y = __builtin_nondeterministic_value(w);
+    asm("" : "+v"(t));
+    return f32x2{t.x, t.x};
+}
+// A packed fp32 operand held as the two halves of ONE aligned register pair in natural order (no op_sel can be folded into
+// its consumer); at most two v_mov_b32.
+__device__ __forceinline__ f32x2 natural_pair(f32x2 v) { asm("" : "+v"(v)); return v; }
 
 constexpr int kConvThreads = 256;
 #ifndef UAPS_XF_S0
@@ -146,7 +162,23 @@ struct ConvFwdArgs {
     // each times a host factor, and the packed weights' header {scale, 1 / scale}
     const float* in_bound; const float* in2_bound; const float* wscale;
     float in_mul, in2_mul;
+    unsigned* err;      // fp16-split kernels: sticky device error word (uaps_set_error_word) or nullptr
 };
+
+// A magnitude bound that was too small lets a scaled operand overflow fp16: the pieces become +-inf and every output they
+// touch NaN (inf - inf in the second piece) -- never a plausible wrong number.  The fp16-split kernels therefore check what
+// they store: v * 0 is 0 for a finite v and NaN otherwise (one fma per element in the epilogue), and a wave that saw a
+// non-finite output ORs UAPS_ERR_* into the caller's sticky error word.  Non-finite INPUTS raise the same flag; the reader
+// (UAPSTrainer.check_errors) says so.
+__device__ __forceinline__ void note_nonfinite(float& chk, const f32x4& v) {
+    chk = __builtin_fmaf(v.x, 0.f, chk); chk = __builtin_fmaf(v.y, 0.f, chk);
+    chk = __builtin_fmaf(v.z, 0.f, chk); chk = __builtin_fmaf(v.w, 0.f, chk);
+}
+__device__ __forceinline__ void report_nonfinite(unsigned* err, float chk, unsigned code) {
+    if (err == nullptr) return;
+    const unsigned long long bad = __builtin_amdgcn_ballot_w64(!(chk == 0.f));
+    if (bad != 0ull && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bad)) atomicOr(err, code);
+}
 
 __device__ __forceinline__ float stats_shift(const ConvFwdArgs& a, int co, bool co_ok) {
     if (!co_ok || a.stats == nullptr) return 0.f;
@@ -406,6 +438,7 @@ struct ConvWrwArgs {
     const float2* xf;
     float xf_slope;
     int xf_Bg;
+    unsigned* err;      // fp16-split kernels: sticky device error word (uaps_set_error_word) or nullptr
 };
 constexpr int kWrwMaxGroups = 8;     // statistics groups a conv_wrw_bn_kernel keeps coefficients for (norm_act.hip kMaxGroups)
 

@@ -294,6 +294,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
 
     // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every tile (same C/D map as 16x16x4) ----
     float st_s[NW], st_q[NW];
+    float chk = 0.f;
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         st_s[n] = 0.f; st_q[n] = 0.f;
@@ -313,6 +314,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
             v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             const bool ok = co_ok && gy < a.H && gx < a.W;      // W % 4 == 0: the 4 pixels are all inside or all outside
             if (ok) {
+                if constexpr (H16) note_nonfinite(chk, v);
                 *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
                 const f32x4 d = v - sh;
                 st_s[n] += (d.x + d.y) + (d.z + d.w);
@@ -320,6 +322,7 @@ __device__ __forceinline__ void conv_sfwd_body(const ConvFwdArgs& a) {
             }
         }
     }
+    if constexpr (H16) report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
     if (a.stats != nullptr) {                    // per-tile BatchNorm partial sums, fixed order (see conv_fwd_body)
         float* red = reinterpret_cast<float*>(sIn);
 #pragma unroll
@@ -560,6 +563,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 
     // ---- epilogue.  C/D of 32x32: lane (n = r, h) register i holds pixel 8 (i >> 2) + 4 h + (i & 3) of channel n ----
     float st_s[NT], st_q[NT];
+    float chk = 0.f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         st_s[n] = 0.f; st_q[n] = 0.f;
@@ -580,6 +584,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
                 if constexpr (H16) { v *= out_scale_a; v *= out_scale_w; }      // exact: powers of two
                 v += bv;
                 if (co_ok && gy < a.H && gx < a.W) {
+                    if constexpr (H16) note_nonfinite(chk, v);
                     *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
                     const f32x4 d = v - sh;
                     st_s[n] += (d.x + d.y) + (d.z + d.w);
@@ -588,6 +593,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             }
         }
     }
+    if constexpr (H16) report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
     if (a.stats != nullptr) {                    // per-tile BatchNorm partial sums: 8 partials (4 waves x 2 halves) per channel, fixed order
         float* red = reinterpret_cast<float*>(sIn);
 #pragma unroll

@@ -181,7 +181,7 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
         // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every M tile ----
         int b, y0, x0, part;
         tile_of(t, b, y0, x0, part);
-        float st_s = 0.f, st_q = 0.f;
+        float st_s = 0.f, st_q = 0.f, chk = 0.f;
         float* out_c = a.out + ((size_t)b * a.Cout + (co_ok ? co : 0)) * HW;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
@@ -191,12 +191,14 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
             v *= out_scale_a; v *= out_scale_w;       // exact: powers of two
             v.x += bv; v.y += bv; v.z += bv; v.w += bv;
             if (co_ok && gy < a.H && gx < a.W) {      // W % 4 == 0: the 4 pixels are all inside or all outside
+                note_nonfinite(chk, v);
                 *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
                 const f32x4 d = v - sh;
                 st_s += (d.x + d.y) + (d.z + d.w);
                 st_q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
+        report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
         if (a.stats != nullptr) {
             sRed[((wave * 4 + kq) * 16 + j) * 2 + 0] = st_s;
             sRed[((wave * 4 + kq) * 16 + j) * 2 + 1] = st_q;

@@ -311,13 +311,17 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     if (wr != 0) return;
     // lane (j, kq), register r: co = co0 + wco*16 + kq*4 + r, ci = ci0 + wci*16 + j
     float* slab = a.slab + (size_t)split * 9 * a.CoutS * a.CinS;
+    float chk = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) {
+        if constexpr (H16) note_nonfinite(chk, acc[t]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + wco * 16 + kq * 4 + r, ci = ci0 + wci * 16 + j;
             slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = H16 ? (acc[t][r] * inv_d) * inv_x : acc[t][r];      // exact: powers of two
         }
+    }
+    if constexpr (H16) report_nonfinite(a.err, chk, UAPS_ERR_WRW_NONFINITE);
     if (want_bias && wci == 0 && j == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = H16 ? accb[r] * inv_d : accb[r];

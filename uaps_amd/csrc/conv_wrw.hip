@@ -8,6 +8,7 @@
 using namespace uaps;
 
 extern "C" int uaps_conv_get_mode(void);
+extern "C" unsigned uaps_conv_get_tuning(void);
 
 namespace {
 
@@ -21,8 +22,7 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     const bool force_exact = (cfg >> 28) & 1, force_split = (cfg >> 29) & 1;
     cfg &= 0xffffff;
     p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() >= 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
-    static const bool diag_no_split_wrw = getenv("UAPS_DIAG_NO_SPLIT_WRW") != nullptr;      // diagnosis only (tools/diag/share_repeat.py)
-    if (diag_no_split_wrw) p.split = false;
+    if (uaps_conv_get_tuning() & UAPS_TUNE_NO_SPLIT_WRW) p.split = false;
     // <= 4 output channels x 16 input channels on a wide map: the exact-N VALU kernel (conv_small.hpp), slabs [tap][4][16]
     p.small = ks == 3 && p.dil == 1 && W % 4 == 0 && W >= 64 && Cout <= 4 && Cin == 16 && !force_exact && !force_split;
     if (p.small) {
@@ -78,7 +78,7 @@ int launch_swrw(const ConvWrwArgs& a, hipStream_t s) {
         if constexpr (WCO == 1 && TH == 4) {          // 16 output channels (the 256 x 256 level): 8-row tiles, halo rows 10/8 instead of 6/4 and
             // half the barriers -- measured 161 -> 150 us (32 -> 16 channels) and 103 -> 90 us (16 -> 16 with the staging-time
             // BatchNorm) at B = 32; the 32 x 16 channel block of the 128 x 128 level loses 10 % and keeps 4 rows
-            static const int tall = getenv("UAPS_WRW_TALL") ? atoi(getenv("UAPS_WRW_TALL")) : 1;
+            const bool tall = !(uaps_conv_get_tuning() & UAPS_TUNE_WRW_SHORT_TILES);
             if (tall && a.H >= 8) {
                 ConvWrwArgs b = a;
                 b.tiles_y = (a.H + 7) / 8;
@@ -164,7 +164,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     ConvWrwArgs a{};
     a.dout = dy; a.in = x; a.in2 = x2; a.Csplit = Csplit; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
-    { static const char* e = getenv("UAPS_SWRW_COLMAJOR"); a.col_major = e ? atoi(e) : 1; }      // measured: 2.3x -> 1.07x of the algorithmic bytes at 32 -> 16 @ 256^2
+    a.col_major = (uaps_conv_get_tuning() & UAPS_TUNE_WRW_ROW_MAJOR) ? 0 : 1;      // column strips measured: 2.3x -> 1.07x of the algorithmic bytes at 32 -> 16 @ 256^2
     a.ncob = p.ncob; a.ncib = p.ncib; a.nsplit = p.nsplit;
     a.bslab = want_bias ? a.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
@@ -183,6 +183,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
             a.dy_bound = hints.bound[0]; a.dy_mul = hints.mul[0];
             a.in_bound = hints.bound[1]; a.in_mul = hints.mul[1];
             if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
+            a.err = uaps::error_word();
         }
         return dispatch_swrw(a, p, s);
     }

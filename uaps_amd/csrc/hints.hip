@@ -5,6 +5,7 @@ namespace {
 thread_local uaps_call_hints g_hints;
 thread_local bool g_have = false;
 thread_local uaps::LaunchEvents g_launch;
+unsigned* g_error_word = nullptr;      // process-wide, like the convolution mode
 }
 
 namespace uaps {
@@ -15,7 +16,14 @@ uaps_call_hints take_hints() {
     return h;
 }
 LaunchEvents& launch_events() { return g_launch; }
+unsigned* error_word() { return g_error_word; }
 }  // namespace uaps
+
+extern "C" int uaps_set_error_word(unsigned* device_word) {
+    if ((uintptr_t)device_word % 4) return UAPS_EINVAL;
+    g_error_word = device_word;
+    return UAPS_OK;
+}
 
 // Zero fill of bound slots with agent-scope stores: the slots are then raised by memory-side atomics and read with agent-scope
 // loads (hints.hpp), so every access to them bypasses the per-XCD L2s.  A plain fill leaves its zeros in one XCD's write-back L2;

@@ -13,6 +13,8 @@ uaps_call_hints take_hints();
 // loss kernel of an entry point, not its packing, reduce or finalize launches) attaches to its dispatch, so that their
 // elapsed time is that kernel's execution alone -- what rocprofv3's kernel trace reports -- instead of the event-to-event time
 // of two extra packets on the stream.
+// uaps_set_error_word: the sticky device error word the fp16-split kernels OR UAPS_ERR_* into, or nullptr
+unsigned* error_word();
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; bool armed = false, used = false; };
 LaunchEvents& launch_events();
 #define UAPS_LAUNCH_MAIN(kernel, grid, block, shmem, stream, ...)                                                            \

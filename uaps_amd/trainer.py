@@ -14,6 +14,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
+from . import _lib
 from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
@@ -55,12 +56,40 @@ class UAPSTrainer:
         self.buckets = udist.GradBuckets(model, overlap=overlap_comm, average=not self.gathered_loss) if self.world > 1 else None
         self._cms = []                                        # one on-device C x C confusion matrix per training step
         self.last: Dict[str, torch.Tensor] = {}
+        # sticky device error word (include/uaps_hip.h, uaps_set_error_word): the fp16-split convolutions flag non-finite
+        # outputs there -- a violated magnitude bound, or non-finite data -- and check_errors() raises on it
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.device) if on_gpu else None
+        self._bind_error_word()
         # step_state: per-step scalars and the RNG key travel through the device-resident step state instead of kernel
         # arguments (uaps_amd.graph); use_graph: that step is captured as a hipGraph after two warm-up steps and replayed
         self.step_graph = None
         if (step_state or use_graph) and on_gpu:
             from .graph import StepGraph
             self.step_graph = StepGraph(self, capture=bool(use_graph))
+
+    # -- device-side error reporting --
+    def _bind_error_word(self) -> None:
+        if self._err is not None:
+            _lib.check(_lib.lib().uaps_set_error_word(self._err.data_ptr()), "uaps_set_error_word")
+
+    def check_errors(self, flags: Optional[int] = None) -> None:
+        """Raise if a kernel reported an error since the last check (one device->host copy unless `flags` is given)."""
+        if self._err is None:
+            return
+        if flags is None:
+            flags = int(self._err.item())
+        if flags:
+            self._err.zero_()
+            what = []
+            if flags & 1:
+                what.append("a forward / input-gradient convolution in the fp16-split form stored non-finite values")
+            if flags & 2:
+                what.append("a weight-gradient convolution in the fp16-split form produced non-finite sums")
+            raise _lib.UapsHipError(
+                "uaps_amd: " + "; ".join(what) + f" (error word {flags:#x}): either non-finite data reached the convolution or a "
+                "magnitude bound (tensor attribute _uaps_bound) was smaller than the tensor it describes -- in-place edits of a "
+                "bounded tensor, BatchNorm parameters changed between bounds.refresh and the forward, a custom op that kept "
+                "the attribute.  conv.set_mode('split') runs without bounds.")
 
     # -- schedule (UAPS_train.py:279-280) --
     def consistency_weights(self):
@@ -69,6 +98,7 @@ class UAPSTrainer:
 
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u: torch.Tensor, w=None) -> Dict[str, torch.Tensor]:
         """Returns device scalars (loss, sup, unsup); nothing here synchronises with the host."""
+        self._bind_error_word()                          # process-wide registration: the trainer that steps owns it
         if self.step_graph is not None and w is None and x_l.shape == x_u.shape:
             return self.step_graph.step(x_l, y_l, x_u)
         if self.step_graph is not None:
@@ -121,8 +151,15 @@ class UAPSTrainer:
         device; this is the one device->host copy.  `pooled=True` instead scores the summed confusion matrix (not what the
         reference logs: the two differ whenever a class is absent from some batches)."""
         if not self._cms:
+            self.check_errors()
             return {"miou": float("nan"), "mdice": float("nan"), "acc": float("nan")}
-        cms = torch.stack(self._cms).cpu().numpy()
+        if self._err is not None:                    # the error word rides in the same device->host copy
+            both = torch.cat([torch.stack(self._cms).flatten(), self._err.to(torch.int64)]).cpu().numpy()
+            c = self._cms[0].shape[0]
+            cms = both[:-1].reshape(len(self._cms), c, c)
+            self.check_errors(int(both[-1]))
+        else:
+            cms = torch.stack(self._cms).cpu().numpy()
         if reset:
             self._cms = []
         return metrics.metrics_from_confusion(cms.sum(0)) if pooled else metrics.mean_batch_metrics(cms)
@@ -133,6 +170,7 @@ class UAPSTrainer:
         mDice, each averaged over the batches -- the mDice returned here is what the reference feeds to
         ReduceLROnPlateau.step (:402) and to the best-checkpoint test (:427).  One device->host copy at the end.
         `pooled=True`: metrics of the summed confusion matrix instead (a different number, see epoch_metrics)."""
+        self._bind_error_word()
         self.model.eval()
         cms, ces = [], []
         for x, y in batches:
@@ -144,6 +182,7 @@ class UAPSTrainer:
             return {"miou": float("nan"), "mdice": float("nan"), "acc": float("nan"), "ce": float("nan"), "loss": float("nan")}
         cm = torch.stack(cms).cpu().numpy()
         ce = torch.stack(ces).double().cpu().numpy()
+        self.check_errors()
         if pooled:
             m = metrics.metrics_from_confusion(cm.sum(0))
             m["ce"] = float(ce.mean())
