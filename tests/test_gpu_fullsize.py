@@ -223,3 +223,71 @@ def test_real_width_step_256_vs_cpu_oracle(pair, monkeypatch):
             np.testing.assert_allclose(v.cpu().numpy(), sd_cpu[k].detach().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
         elif k.endswith("num_batches_tracked"):
             assert int(v) == int(sd_cpu[k]) == 2, k
+
+
+@pytest.mark.parametrize("mode", ["h16", "split", "exact"])
+def test_real_width_step_256_vs_float64_oracle(mode):
+    """The whole step at the real width against the oracle in FLOAT64 (UAPS_unet.py:224-233 + UAPS_train.py:186-292 restated by
+    oracle.uaps_oracle, run in double so that its own rounding is out of the comparison): logits of both batches, loss, and all
+    208 gradients within 5e-4 of their scale, in each of the three convolution arithmetics -- the composed error of 23 layers of
+    22-bit operand pieces (mode h16), of the exact three-piece split and of the fp32 matrix instruction, forward and backward.
+    4 + 4 images of 256 x 256 (UAPS_TEST_F64_BATCH): the unfused float64 step of 16 + 16 needs ~60 GB of host memory."""
+    import os
+    import uaps_amd
+    from oracle import uaps_oracle as O
+    from uaps_amd import conv, losses, unet
+    torch.manual_seed(21)
+    rng = np.random.default_rng(21)
+    B, H, W, C = int(os.environ.get("UAPS_TEST_F64_BATCH", "4")), 256, 256, 4
+    model = unet.UNet_UAPS(3, C, n_aux=3, dropout=[0.0] * 5)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.7, 1.3); m.bias.uniform_(-0.2, 0.2)
+    sd64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
+    for k in sd64:
+        if sd64[k].is_floating_point() and (k.endswith(".weight") or k.endswith(".bias")):
+            sd64[k].requires_grad_(True)
+    xl = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+    xu = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32))
+    yl = torch.tensor(uaps_amd.data.synthetic_masks(rng, B, C, H, W))
+    w = rng.dirichlet(np.ones(4), size=1)[0]
+    fshapes = [(c, H >> i, W >> i) for i, c in enumerate(unet.FEATURE_CHANNELS)]
+    rec = {tag: {"noise": [torch.tensor(rng.uniform(-0.3, 0.3, s).astype(np.float32)) for s in fshapes],
+                 "mask": [torch.tensor((rng.random((B,) + s) < 0.5).astype(np.float32)) for s in fshapes],
+                 "u": [float(rng.uniform(0.7, 0.9)) for _ in fshapes]} for tag in ("l", "u")}
+    cw1, cw2 = 0.07, 0.05
+    rec64 = {t: {"noise": [n.double() for n in d["noise"]], "mask": [m.double() for m in d["mask"]], "u": d["u"]} for t, d in rec.items()}
+    lab_c = O.uaps_forward(xl.double(), sd64, True, rec64["l"], dropout=[0.0] * 5)
+    un_c = O.uaps_forward(xu.double(), sd64, True, rec64["u"], dropout=[0.0] * 5)
+    r = O.step_loss(un_c, lab_c, yl, w, cw1, cw2)
+    r["loss"].backward()
+
+    prev = conv.get_mode()
+    conv.set_mode(mode)
+    try:
+        model.to(DEV).train()
+        draws = lambda tag: ([t.to(DEV) for t in rec[tag]["noise"]], [t.to(DEV) for t in rec[tag]["mask"]], rec[tag]["u"])
+        both = model.forward_pair(xl.to(DEV), xu.to(DEV), perturbations=injected_pair(draws("l"), draws("u")))
+        out = losses.uaps_pair_loss(both, yl.to(DEV), w, cw1, cw2)
+        out.loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        conv.set_mode(prev)
+    worst_logit = 0.0
+    for k in range(4):
+        for got, ref in ((both[k][:B], lab_c[k]), (both[k][B:], un_c[k])):
+            worst_logit = max(worst_logit, float((got.detach().cpu().double() - ref.detach()).abs().max()))
+    assert worst_logit <= 1e-4, worst_logit                  # north_star: maps within 1e-4
+    np.testing.assert_allclose(float(out.loss), float(r["loss"]), rtol=2e-5)
+    worst = (0.0, "")
+    for n, p in model.named_parameters():
+        ref = sd64[n].grad
+        scale = float(ref.abs().max())
+        err = float((p.grad.cpu().double() - ref).abs().max())
+        if scale < 1e-9:                                      # conv biases in front of a train-mode BatchNorm: exactly zero
+            assert err < 1e-6, n
+            continue
+        worst = max(worst, (err / scale, n))
+        assert err <= max(5e-4 * scale, 2e-6), f"[{mode}] {n}: max err {err:.3e} vs scale {scale:.3e}"
+    print(f"[{mode}] worst logit error {worst_logit:.2e}; worst relative gradient error {worst[0]:.2e} ({worst[1]})")
