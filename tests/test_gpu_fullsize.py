@@ -225,29 +225,26 @@ def test_real_width_step_256_vs_cpu_oracle(pair, monkeypatch):
             assert int(v) == int(sd_cpu[k]) == 2, k
 
 
-@pytest.mark.parametrize("mode", ["h16", "split", "exact"])
-def test_real_width_step_256_vs_float64_oracle(mode):
-    """The whole step at the real width against the oracle in FLOAT64 (UAPS_unet.py:224-233 + UAPS_train.py:186-292 restated by
-    oracle.uaps_oracle, run in double so that its own rounding is out of the comparison): logits of both batches, loss, and all
-    208 gradients within 5e-4 of their scale, in each of the three convolution arithmetics -- the composed error of 23 layers of
-    22-bit operand pieces (mode h16), of the exact three-piece split and of the fp32 matrix instruction, forward and backward.
-    4 + 4 images of 256 x 256 (UAPS_TEST_F64_BATCH): the unfused float64 step of 16 + 16 needs ~60 GB of host memory."""
-    import os
+_F64_CACHE = {}
+
+
+def _float64_and_float32_oracle_step(B, H, W, C):
+    """One whole step of the real-width net by the oracle in float64 AND in float32 (the reference's own arithmetic) on the
+    same inputs and draws; FeatureDropout keep masks recorded from the float64 run and replayed in the float32 one."""
     import uaps_amd
     from oracle import uaps_oracle as O
-    from uaps_amd import conv, losses, unet
+    from uaps_amd import unet
+    key = (B, H, W, C)
+    if key in _F64_CACHE:
+        return _F64_CACHE[key]
     torch.manual_seed(21)
     rng = np.random.default_rng(21)
-    B, H, W, C = int(os.environ.get("UAPS_TEST_F64_BATCH", "4")), 256, 256, 4
     model = unet.UNet_UAPS(3, C, n_aux=3, dropout=[0.0] * 5)
     with torch.no_grad():
         for m in model.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.weight.uniform_(0.7, 1.3); m.bias.uniform_(-0.2, 0.2)
-    sd64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.detach().clone()) for k, v in model.state_dict().items()}
-    for k in sd64:
-        if sd64[k].is_floating_point() and (k.endswith(".weight") or k.endswith(".bias")):
-            sd64[k].requires_grad_(True)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     xl = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32))
     xu = torch.tensor(rng.standard_normal((B, 3, H, W)).astype(np.float32))
     yl = torch.tensor(uaps_amd.data.synthetic_masks(rng, B, C, H, W))
@@ -257,37 +254,103 @@ def test_real_width_step_256_vs_float64_oracle(mode):
                  "mask": [torch.tensor((rng.random((B,) + s) < 0.5).astype(np.float32)) for s in fshapes],
                  "u": [float(rng.uniform(0.7, 0.9)) for _ in fshapes]} for tag in ("l", "u")}
     cw1, cw2 = 0.07, 0.05
-    rec64 = {t: {"noise": [n.double() for n in d["noise"]], "mask": [m.double() for m in d["mask"]], "u": d["u"]} for t, d in rec.items()}
-    lab_c = O.uaps_forward(xl.double(), sd64, True, rec64["l"], dropout=[0.0] * 5)
-    un_c = O.uaps_forward(xu.double(), sd64, True, rec64["u"], dropout=[0.0] * 5)
-    r = O.step_loss(un_c, lab_c, yl, w, cw1, cw2)
-    r["loss"].backward()
+    keeps = {"l": [], "u": []}
+    real_fd = O.feature_dropout
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        sd = {k: (v.detach().clone().to(dt) if v.is_floating_point() else v.detach().clone()) for k, v in sd0.items()}
+        for k in sd:
+            if sd[k].is_floating_point() and (k.endswith(".weight") or k.endswith(".bias")):
+                sd[k].requires_grad_(True)
+        rr = {t: {"noise": [n.to(dt) for n in d["noise"]], "mask": [m.to(dt) for m in d["mask"]], "u": d["u"]} for t, d in rec.items()}
 
+        def fd_for(tag):
+            if dt == torch.float64:                 # record the keep masks ...
+                def fd(x, u):
+                    att = x.mean(dim=1, keepdim=True)
+                    thr = (att.reshape(x.shape[0], -1).max(dim=1, keepdim=True)[0] * float(u)).view(-1, 1, 1, 1)
+                    keeps[tag].append((att < thr))
+                    return x * keeps[tag][-1].to(x.dtype)
+                return fd
+            it = iter(keeps[tag])                   # ... and replay them
+            return lambda x, u: x * next(it).to(x.dtype)
+        try:
+            O.feature_dropout = fd_for("l")
+            lab = O.uaps_forward(xl.to(dt), sd, True, rr["l"], dropout=[0.0] * 5)
+            O.feature_dropout = fd_for("u")
+            un = O.uaps_forward(xu.to(dt), sd, True, rr["u"], dropout=[0.0] * 5)
+        finally:
+            O.feature_dropout = real_fd
+        r = O.step_loss(un, lab, yl, w, cw1, cw2)
+        r["loss"].backward()
+        res[dt] = {"lab": [t.detach() for t in lab], "un": [t.detach() for t in un], "loss": float(r["loss"].detach()),
+                   "grads": {k: sd[k].grad.detach().double() for k in sd if sd[k].is_floating_point() and sd[k].grad is not None}}
+    out = (sd0, xl, xu, yl, w, rec, keeps, cw1, cw2, res)
+    _F64_CACHE[key] = out
+    return out
+
+
+def _grad_errors(got, ref):
+    """[(relative max error, name)] over the parameters whose reference gradient is not identically zero."""
+    errs = []
+    for n, g in ref.items():
+        scale = float(g.abs().max())
+        if scale < 1e-9:
+            continue
+        errs.append((float((got[n] - g).abs().max()) / scale, n))
+    return sorted(errs, reverse=True)
+
+
+@pytest.mark.parametrize("mode", ["h16", "split", "exact"])
+def test_real_width_step_256_vs_float64_oracle(mode):
+    """The whole step at the real width against the oracle in FLOAT64 (UAPS_unet.py:224-233 + UAPS_train.py:186-292 restated by
+    oracle.uaps_oracle, run in double so that its own rounding is out of the comparison), in each of the three convolution
+    arithmetics: logits of both batches within 1e-4 (north_star), loss to 2e-5, and the 208 gradients AS CLOSE TO FLOAT64 AS THE
+    REFERENCE'S OWN ARITHMETIC IS.  The gradient of this net is not a smooth function of its inputs -- 2 x 2 max-pool arg-max
+    ties and LeakyReLU arguments within rounding of zero flip between any two roundings -- so plain PyTorch-CPU float32 (what
+    the reference trains in) already differs from float64 by up to ~1e-2 of a gradient's scale on a few parameters (median
+    2e-4; measured here by running the oracle in float32 too).  The bar: the HIP path's median relative error <= 1.5 x and its
+    worst <= 3 x the float32 oracle's, over all parameters -- a composed error of 23 layers of 22-bit operand pieces (mode
+    h16) that exceeded fp32's would show here.  FeatureDropout's keep mask is a step function of the features
+    (UAPS_unet.py:161-169), so the masks the float64 oracle drew are replayed everywhere (the threshold logic itself is pinned
+    bit for bit by fixture g3).  4 + 4 images of 256 x 256 by default (UAPS_TEST_F64_BATCH)."""
+    import os
+    from uaps_amd import conv, losses, perturb, unet
+    B, H, W, C = int(os.environ.get("UAPS_TEST_F64_BATCH", "4")), 256, 256, 4
+    sd0, xl, xu, yl, w, rec, keeps, cw1, cw2, res = _float64_and_float32_oracle_step(B, H, W, C)
+    r64, r32 = res[torch.float64], res[torch.float32]
+    model = unet.UNet_UAPS(3, C, n_aux=3, dropout=[0.0] * 5)
+    model.load_state_dict(sd0)
     prev = conv.get_mode()
     conv.set_mode(mode)
     try:
         model.to(DEV).train()
         draws = lambda tag: ([t.to(DEV) for t in rec[tag]["noise"]], [t.to(DEV) for t in rec[tag]["mask"]], rec[tag]["u"])
-        both = model.forward_pair(xl.to(DEV), xu.to(DEV), perturbations=injected_pair(draws("l"), draws("u")))
+        pert = injected_pair(draws("l"), draws("u"))
+        kl = [k.float().expand(B, c, *k.shape[2:]).contiguous().to(DEV) for k, c in zip(keeps["l"], unet.FEATURE_CHANNELS)]
+        ku = [k.float().expand(B, c, *k.shape[2:]).contiguous().to(DEV) for k, c in zip(keeps["u"], unet.FEATURE_CHANNELS)]
+        pert[2] = lambda fs: [torch.cat([perturb.dropout_with(f[:B].contiguous(), a, 0.0), perturb.dropout_with(f[B:].contiguous(), b, 0.0)])
+                              for f, a, b in zip(fs, kl, ku)]
+        both = model.forward_pair(xl.to(DEV), xu.to(DEV), perturbations=pert)
         out = losses.uaps_pair_loss(both, yl.to(DEV), w, cw1, cw2)
         out.loss.backward()
         torch.cuda.synchronize()
     finally:
         conv.set_mode(prev)
-    worst_logit = 0.0
+    worst_logit = worst_logit32 = 0.0
     for k in range(4):
-        for got, ref in ((both[k][:B], lab_c[k]), (both[k][B:], un_c[k])):
-            worst_logit = max(worst_logit, float((got.detach().cpu().double() - ref.detach()).abs().max()))
-    assert worst_logit <= 1e-4, worst_logit                  # north_star: maps within 1e-4
-    np.testing.assert_allclose(float(out.loss), float(r["loss"]), rtol=2e-5)
-    worst = (0.0, "")
-    for n, p in model.named_parameters():
-        ref = sd64[n].grad
-        scale = float(ref.abs().max())
-        err = float((p.grad.cpu().double() - ref).abs().max())
-        if scale < 1e-9:                                      # conv biases in front of a train-mode BatchNorm: exactly zero
-            assert err < 1e-6, n
-            continue
-        worst = max(worst, (err / scale, n))
-        assert err <= max(5e-4 * scale, 2e-6), f"[{mode}] {n}: max err {err:.3e} vs scale {scale:.3e}"
-    print(f"[{mode}] worst logit error {worst_logit:.2e}; worst relative gradient error {worst[0]:.2e} ({worst[1]})")
+        for got, ref, r32t in ((both[k][:B], r64["lab"][k], r32["lab"][k]), (both[k][B:], r64["un"][k], r32["un"][k])):
+            worst_logit = max(worst_logit, float((got.detach().cpu().double() - ref).abs().max()))
+            worst_logit32 = max(worst_logit32, float((r32t.double() - ref).abs().max()))
+    assert worst_logit <= 1e-4, (worst_logit, worst_logit32)                  # north_star: maps within 1e-4
+    np.testing.assert_allclose(float(out.loss.detach()), r64["loss"], rtol=2e-5)
+    got = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters()}
+    for n, g in r64["grads"].items():
+        if float(g.abs().max()) < 1e-9:                      # conv biases in front of a train-mode BatchNorm: exactly zero
+            assert float(got[n].abs().max()) < 1e-6, n
+    e_hip, e_f32 = _grad_errors(got, r64["grads"]), _grad_errors(r32["grads"], r64["grads"])
+    med = lambda e: float(np.median([v for v, _ in e]))
+    print(f"[{mode}] logits: HIP {worst_logit:.2e}, float32 oracle {worst_logit32:.2e} from float64; gradients (relative to scale): "
+          f"HIP median {med(e_hip):.2e} worst {e_hip[0][0]:.2e} ({e_hip[0][1]}); float32 oracle median {med(e_f32):.2e} worst {e_f32[0][0]:.2e} ({e_f32[0][1]})")
+    assert med(e_hip) <= 1.5 * med(e_f32) + 2e-5, (med(e_hip), med(e_f32))
+    assert e_hip[0][0] <= 3.0 * e_f32[0][0] + 1e-4, (e_hip[:3], e_f32[:3])
