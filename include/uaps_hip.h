@@ -357,7 +357,7 @@ int uaps_set_error_word(unsigned* device_word);
 
 /* One-shot side arguments for the NEXT kernel entry point called on this thread; that call consumes and clears them
  * (every convolution entry point, uaps_bn_act_fwd_train_partials, uaps_bn_finalize_train, uaps_bn_act_bwd*,
- * uaps_pairloss_bwd and uaps_up_cat_fwd do; NULL clears).
+ * uaps_pairloss_bwd, uaps_up_cat_fwd and uaps_add_relu do; NULL clears).
  *   bound[i], mul[i]  device bound b and host factor m > 0 with |operand i| <= value(b) * m for every element; NULL = unknown.
  *                     A bound is UAPS_BOUND_FLOATS floats (16-byte aligned): value(b) = max over the UAPS_BOUND_SLOTS
  *                     floats b[k * UAPS_BOUND_STRIDE], the rest is padding -- the producing kernels raise the slots with

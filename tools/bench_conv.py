@@ -61,7 +61,7 @@ def main():
     tot = {k: 0.0 for k in ("fwd", "bwd", "wrw", "mfwd", "mbwd", "mwrw")}
     print(f"{'layer':28s} {'GF':>6s} | {'fwd us':>8s} {'TF/s':>6s} {'miopen':>8s} | {'bwdD us':>8s} {'TF/s':>6s} {'miopen':>8s} | {'wrw us':>8s} {'TF/s':>6s} {'miopen':>8s}")
     for name, Cin, Cout, HW, ks, calls in LAYERS:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         x = torch.randn(B, Cin, HW, HW, device=dev)
         w = torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05

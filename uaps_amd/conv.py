@@ -555,4 +555,4 @@ class _MaxPool3x3s2(torch.autograd.Function):
 
 def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     """nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (utilities/resnet.py:124)."""
-    return _MaxPool3x3s2.apply(x)
+    return bounds.carry(x, _MaxPool3x3s2.apply(x))

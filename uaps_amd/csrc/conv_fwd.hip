@@ -183,7 +183,11 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // measured (tools/bench_modes.py, B = 32): the split forms win 1.2-1.7x on every 3x3 layer with more than 8 contraction
     // channels and lose on 1x1 convolutions (HBM-bound, the split only adds staging work) and on the <= 8-channel layers
     // (a chunk of 8 channels fills 9 of 12 k-groups); cfg bits 29-30 != 0 force a split form regardless
-    p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || ((cfg >> 29) & 3));
+    // 1x1 convolutions: the U-Net's (<= 256 -> 128 channels on <= 32 x 32 maps, or narrower) are HBM-bound and stay on the fp32
+    // instruction; the bottleneck projections of the ResNet encoders (64 ... 2048 channels, utilities/resnet.py:55-95) are
+    // compute-bound and take the split form
+    const bool big_1x1 = ks == 1 && Cin >= 64 && (long)Cin * Cout >= 16384 && (long)H * W >= 1024;
+    p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || big_1x1 || ((cfg >> 29) & 3));
     if (g_conv_tuning & UAPS_TUNE_NO_SPLIT_FWD) p->split = false;
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
     p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/uaps_hip.h"
+#include "hints.hpp"
 
 namespace {
 constexpr int kThreads = 256;
@@ -269,14 +270,20 @@ extern "C" int uaps_entropy_map(const float* p, int B, int C, int H, int W, floa
 // ---- residual join of the ResNet blocks (utilities/resnet.py:47-50, 88-91): out = relu(a + b), and its backward
 // da = db = dout * (out > 0), each one 16-byte-per-lane streaming pass -------------------------------------------------
 namespace {
+// amax: optional bound (uaps_call_hints::out_amax) raised to max(out) -- the join's output feeds the next block's convolutions
 __global__ __launch_bounds__(kThreads) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                            float* __restrict__ out, long n4, long n) {
+                                                            float* __restrict__ out, long n4, long n, float* __restrict__ amax) {
+    __shared__ float s16[16];
+    float m = 0.f;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kThreads) {
         const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
-        reinterpret_cast<float4*>(out)[i] = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+        const float4 r = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+        reinterpret_cast<float4*>(out)[i] = r;
+        m = fmaxf(m, fmaxf(fmaxf(r.x, r.y), fmaxf(r.z, r.w)));
     }
     if (blockIdx.x == 0)
-        for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) out[i] = fmaxf(a[i] + b[i], 0.f);
+        for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) { const float r = fmaxf(a[i] + b[i], 0.f); out[i] = r; m = fmaxf(m, r); }
+    if (amax != nullptr) uaps::block_amax_to(amax, m, s16);
 }
 __global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                             float* __restrict__ dx, long n4, long n) {
@@ -291,9 +298,10 @@ inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 }  // namespace
 
 extern "C" int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
+    float* amax = uaps::take_hints().out_amax;
     if (!a || !b || !out || n <= 0) return UAPS_EINVAL;
     const long n4 = (al16p(a) && al16p(b) && al16p(out)) ? n / 4 : 0;
-    hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, a, b, out, n4, n);
+    hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, a, b, out, n4, n, amax);
     return (int)hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, conv, fused, perturb
+from . import _lib, bounds, conv, fused, perturb
 from .unet import ConvBlock, UpBlock, _PERTURBATIONS
 
 
@@ -30,11 +30,13 @@ from .unet import ConvBlock, UpBlock, _PERTURBATIONS
 
 class _AddRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, am=None):
         _lib.require_device(a, "add_relu")
         a, b = a.contiguous(), b.contiguous()
         out = torch.empty_like(a)
         with _lib.device_guard(a.device):
+            if am is not None:
+                _lib.hints((), am)
             rc = _lib.lib().uaps_add_relu(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
         _lib.check(rc, "uaps_add_relu")
         ctx.save_for_backward(out)
@@ -48,11 +50,15 @@ class _AddRelu(torch.autograd.Function):
         with _lib.device_guard(g.device):
             rc = _lib.lib().uaps_relu_bwd(g.data_ptr(), out.data_ptr(), dx.data_ptr(), g.numel(), _lib.current_stream(g.device))
         _lib.check(rc, "uaps_relu_bwd")
-        return dx, dx
+        bounds.carry(g, dx)                       # a mask: |dx| <= |g|
+        return dx, dx, None
 
 
 def add_relu(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    return _AddRelu.apply(a, b) if a.is_cuda else F.relu(a + b)
+    if not a.is_cuda:
+        return F.relu(a + b)
+    am = bounds.new_amax(a.device) if bounds.enabled() else None      # max(out), raised by the kernel: the join feeds the next block's convolutions
+    return bounds.put(_AddRelu.apply(a, b, am), am)
 
 
 def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, training: bool) -> torch.Tensor:
@@ -288,6 +294,10 @@ class ResUAPS(nn.Module):
             if self._conv_weights is None:
                 self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d) and m.kernel_size[0] in (1, 3)]
             conv.pack_all(self._conv_weights)
+            if self.training:                        # Samuelson bounds of the train-mode BatchNorm outputs (conv mode 'h16')
+                if getattr(self, "_bns", None) is None:
+                    self._bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+                bounds.refresh(self._bns)
         feats = self.encoder.base_forward(x)
         kinds = [_PERTURBATIONS[i % 3] for i in range(self.n_aux)]
         if x.is_cuda and self.n_aux > 0:
