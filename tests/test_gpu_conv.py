@@ -44,6 +44,12 @@ SHAPES = [
     (2, 32, 16, 64, 64, 1),
     (1, 20, 40, 18, 18, 3),     # channel counts that are not multiples of the tile sizes
     (1, 24, 24, 10, 10, 1),
+    # wide 1x1 projections of the ResNet bottlenecks (utilities/resnet.py:55-95): the GEMM-tiled kernels of csrc/conv_gemm1x1.hpp
+    (2, 256, 64, 40, 40, 1),    # 1600 pixels: a partial 128-pixel tile; 64-channel output blocks
+    (2, 64, 256, 32, 32, 1),    # 128-channel output blocks, one chunk pair
+    (1, 512, 128, 32, 48, 1),
+    (2, 200, 136, 32, 32, 1),   # channel counts that are no multiples of the block sizes (stays on the 3x3-style tiling: CoutP % 64)
+    (1, 1024, 256, 40, 40, 1),
 ]
 
 

@@ -7,6 +7,7 @@
 #include "conv_split.hpp"
 #include "conv_split_n16.hpp"
 #include "conv_small.hpp"
+#include "conv_gemm1x1.hpp"
 #include "hints.hpp"
 using namespace uaps;
 
@@ -119,6 +120,22 @@ int launch_hp16(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+int launch_g1(ConvFwdArgs a, int bn, hipStream_t s) {
+    a.tiles_x = (a.H * a.W + 127) / 128;
+    a.tiles_y = 1;
+    a.nblk = a.CoutP / bn;
+    const long grid = ((long)a.B * a.tiles_x * a.nblk + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.wscale) {
+        if (bn == 128) UAPS_LAUNCH_MAIN((conv_g1h_kernel<128>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_g1h_kernel<64>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    } else {
+        if (bn == 128) UAPS_LAUNCH_MAIN((conv_g1s_kernel<128>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_g1s_kernel<64>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
 int launch_small(ConvFwdArgs a, int kind, hipStream_t s) {
     a.tiles_x = (a.W + 63) / 64;
     a.tiles_y = (a.H + 15) / 16;
@@ -150,7 +167,8 @@ int launch_s32(ConvFwdArgs a, hipStream_t s) {
 
 // split: one of the bf16-split kernels runs; s32: the 32x32x16 form (3x3, 8x32 tiles, >= 32 output channels)
 // small: 1 = the exact-N VALU kernel for <= 4 output channels (conv_small.hpp)
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; };
+// g1: the GEMM-tiled 1x1 kernels of conv_gemm1x1.hpp (128 consecutive pixels x 128 / 64 output channels per workgroup)
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; bool g1; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
@@ -189,6 +207,7 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     const bool big_1x1 = ks == 1 && Cin >= 64 && (long)Cin * Cout >= 16384 && (long)H * W >= 1024;
     p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || big_1x1 || ((cfg >> 29) & 3));
     if (g_conv_tuning & UAPS_TUNE_NO_SPLIT_FWD) p->split = false;
+    p->g1 = p->split && big_1x1 && p->vec && p->CoutP % 64 == 0 && !(cfg & 0x7fffffff);
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
     p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);
     p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 512) ? 32 : 16;
@@ -243,6 +262,13 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             a.in_bound = hints.bound[0]; a.in_mul = hints.mul[0];
             if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[1]; a.in2_mul = hints.mul[1]; }
             a.err = uaps::error_word();
+        }
+        if (p.g1) {
+            if (x2 || y2 || xf) {                     // no two-tensor / BatchNorm-in-staging form of the GEMM-tiled kernels: the 3x3-style tiling
+                if (stats) return UAPS_ERANGE;        // (its statistics parts would not match uaps_conv_fwd_stats_parts)
+            } else {
+                return launch_g1(a, p.CoutP % 128 == 0 ? 128 : 64, s);
+            }
         }
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
@@ -344,7 +370,7 @@ extern "C" int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W,
     const int rc = plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
     if (!parts_per_image) return UAPS_EINVAL;
-    *parts_per_image = ((H + p.th - 1) / p.th) * ((W + p.tw - 1) / p.tw);
+    *parts_per_image = p.g1 ? (H * W + 127) / 128 : ((H + p.th - 1) / p.th) * ((W + p.tw - 1) / p.tw);
     return UAPS_OK;
 }
 
@@ -377,6 +403,7 @@ extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int
     if (rc) return rc;
     if (!buf || buflen < 64) return UAPS_EINVAL;
     if (p.small) snprintf(buf, buflen, "conv_small_kernel<8, 4>");
+    else if (p.g1) snprintf(buf, buflen, "conv_g1s_kernel<%d>", p.CoutP % 128 == 0 ? 128 : 64);
     else if (p.s32) snprintf(buf, buflen, "conv_s32_kernel<%d>", p.sbn);
     else if (p.split) snprintf(buf, buflen, "conv_sfwd_kernel<%d, %d, %d, %d, %d>", ks, p.th, p.tw, p.sbn, p.sck);
     else snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);

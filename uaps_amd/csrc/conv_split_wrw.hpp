@@ -41,12 +41,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& p0, u32x4& p1
     }
 }
 
-// 8 consecutive floats (already scaled) -> two 16-byte rows of packed fp16 pieces
+// 8 consecutive floats times the power-of-two scale sc -> two 16-byte rows of packed fp16 pieces.  The scale is pinned to the
+// low register of a pair (bcast_lo): the packed multiply then broadcasts from the low half, never `op_sel` low-from-high
+// (the packed-operand rule of conv_small.hpp; an SGPR-pair broadcast would be the first-source form, unproven either way).
 __device__ __forceinline__ void split8h(const float (&v)[8], float sc, u32x4& p0, u32x4& p1) {
+    const f32x2 sc2 = bcast_lo(sc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        const f32x2 t = f32x2{v[2 * i], v[2 * i + 1]} * sc2;
         unsigned a, b;
-        conv_split2h(v[2 * i] * sc, v[2 * i + 1] * sc, a, b);
+        conv_split2h(t.x, t.y, a, b);
         p0[i] = a; p1[i] = b;
     }
 }
@@ -191,7 +195,8 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                 split8h(v8, sc_x, p0, p1);
                 sX[u] = p0; sX[BCI * XPLU + u] = p1;
                 unsigned e0, e1;                 // (right neighbour, left neighbour) -> low / high half of the edge dword
-                conv_split2h(rx[n][9] * sc_x, rx[n][8] * sc_x, e0, e1);
+                const f32x2 ev = f32x2{rx[n][9], rx[n][8]} * bcast_lo(sc_x);
+                conv_split2h(ev.x, ev.y, e0, e1);
                 sE[eu] = e0; sE[BCI * EPL + eu] = e1;
             } else {
                 u32x4 p0, p1, p2;
@@ -312,19 +317,28 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     // lane (j, kq), register r: co = co0 + wco*16 + kq*4 + r, ci = ci0 + wci*16 + j
     float* slab = a.slab + (size_t)split * 9 * a.CoutS * a.CinS;
     float chk = 0.f;
+    const f32x2 id2 = bcast_lo(inv_d), ix2 = bcast_lo(inv_x);      // (packed-operand rule of conv_small.hpp: broadcasts from low registers)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if constexpr (H16) note_nonfinite(chk, acc[t]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; r += 2) {
+            f32x2 v = f32x2{acc[t][r], acc[t][r + 1]};
+            if constexpr (H16) v = (v * id2) * ix2;                  // exact: powers of two
             const int co = co0 + wco * 16 + kq * 4 + r, ci = ci0 + wci * 16 + j;
-            slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = H16 ? (acc[t][r] * inv_d) * inv_x : acc[t][r];      // exact: powers of two
+            slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = v.x;
+            slab[((size_t)t * a.CoutS + co + 1) * a.CinS + ci] = v.y;
         }
     }
     if constexpr (H16) report_nonfinite(a.err, chk, UAPS_ERR_WRW_NONFINITE);
     if (want_bias && wci == 0 && j == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = H16 ? accb[r] * inv_d : accb[r];
+        for (int r = 0; r < 4; r += 2) {
+            f32x2 v = f32x2{accb[r], accb[r + 1]};
+            if constexpr (H16) v = v * id2;
+            a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r] = v.x;
+            a.bslab[(size_t)split * a.CoutS + co0 + wco * 16 + kq * 4 + r + 1] = v.y;
+        }
     }
 }
 

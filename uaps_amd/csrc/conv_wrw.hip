@@ -4,6 +4,7 @@
 #include "conv_kernels.hpp"
 #include "conv_split_wrw.hpp"
 #include "conv_small.hpp"
+#include "conv_gemm1x1.hpp"
 #include "hints.hpp"
 using namespace uaps;
 
@@ -14,7 +15,8 @@ namespace {
 
 // wave arrangement: (WCO, WCI) 16-channel blocks per workgroup, the remaining factor of 4 splits the tile rows
 // split: the bf16-split kernels of conv_split_wrw.hpp (3x3, no dilation, 16-byte rows, >= 16 input channels)
-struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; bool split, small; };
+// g1: the GEMM-tiled 1x1 kernel of conv_gemm1x1.hpp (128 x 128 channel blocks, 32-pixel chunks)
+struct WrwPlan { int TH, TW, wco, wci, ncob, ncib, nsplit, CoutS, CinS, dil; long tiles; bool split, small, g1; };
 
 WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     WrwPlan p{};
@@ -25,6 +27,21 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     if (uaps_conv_get_tuning() & UAPS_TUNE_NO_SPLIT_WRW) p.split = false;
     // <= 4 output channels x 16 input channels on a wide map: the exact-N VALU kernel (conv_small.hpp), slabs [tap][4][16]
     p.small = ks == 3 && p.dil == 1 && W % 4 == 0 && W >= 64 && Cout <= 4 && Cin == 16 && !force_exact && !force_split;
+    // wide 1x1 projections (ResNet bottlenecks): the same rule as plan_fwd's big_1x1
+    p.g1 = ks == 1 && uaps_conv_get_mode() >= 1 && !force_exact && !(uaps_conv_get_tuning() & UAPS_TUNE_NO_SPLIT_WRW) && cfg == 0 &&
+           Cin >= 64 && (long)Cin * Cout >= 16384 && (long)H * W >= 1024 && ((long)H * W) % 32 == 0 && W % 4 == 0;
+    if (p.g1) {
+        p.split = p.small = false;
+        p.wco = p.wci = 8; p.TH = 1; p.TW = 32;
+        p.ncob = (Cout + 127) / 128; p.ncib = (Cin + 127) / 128;
+        p.CoutS = p.ncob * 128; p.CinS = p.ncib * 128;
+        p.tiles = (long)B * (((long)H * W) / 32);
+        const long blocks = (long)p.ncob * p.ncib;
+        long want = blocks >= 1024 ? 1 : (1024 + blocks - 1) / blocks;      // ~4 workgroups per CU in all
+        if (want > p.tiles) want = p.tiles;
+        p.nsplit = (int)(want < 1 ? 1 : want);
+        return p;
+    }
     if (p.small) {
         p.split = false;
         p.wco = p.wci = 1; p.TH = 8; p.TW = 64; p.ncob = p.ncib = 1; p.CoutS = 4; p.CinS = 16;
@@ -170,6 +187,21 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
+    if (p.g1) {
+        if (x2 || xf || !vec16) return UAPS_ERANGE;
+        a.tiles_x = (H * W) / 32; a.tiles_y = 1;
+        const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;
+        if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+        if (uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1]) {
+            a.dy_bound = hints.bound[0]; a.dy_mul = hints.mul[0];
+            a.in_bound = hints.bound[1]; a.in_mul = hints.mul[1];
+            a.err = uaps::error_word();
+            UAPS_LAUNCH_MAIN(conv_gw1h_kernel, dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        } else {
+            UAPS_LAUNCH_MAIN(conv_gw1s_kernel, dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        }
+        return (int)hipGetLastError();
+    }
     if (p.small) {
         if (x2) return UAPS_EINVAL;
         const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
@@ -245,6 +277,7 @@ extern "C" int uaps_conv_wrw_variant(int B, int Cin, int Cout, int H, int W, int
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ks != 1 && ks != 3) || !buf || buflen < 64) return UAPS_EINVAL;
     const WrwPlan p = plan_wrw(B, Cin, Cout, H, W, cfg, ks);
     if (p.small) snprintf(buf, buflen, "conv_small_wrw_kernel");
+    else if (p.g1) snprintf(buf, buflen, "conv_gw1s_kernel");
     else if (p.split) snprintf(buf, buflen, "conv_swrw_kernel<%d, %d, %d>", p.TH, p.wco, p.wci);
     else snprintf(buf, buflen, "conv_wrw_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.TH, p.TW, p.wco, p.wci, (W % 4 == 0) ? 4 : 1, p.dil);
     return UAPS_OK;
