@@ -111,6 +111,44 @@ def cpu_baseline(batch, H, W, budget_s=25.0):
             "runs": runs, "host": info}
 
 
+def other_configs(steps, dev):
+    """BASELINE.json configs[3] (K = 5 decoders, DAGM-shaped 1 x 512 x 512, 2 classes, 8 + 8 images) and the per-GPU shape of
+    configs[4] (ResNet-50 encoder, K = 3, 640 x 640, 2 classes, 8 + 8 images): `steps` eager training steps each after two
+    warm-up steps, HIP events around the timed steps."""
+    import gc
+    import torch
+    import uaps_amd
+    out = []
+    for name, net, in_chns, classes, aux, batch, size in (
+            ("configs[3]: UAPS K=5 decoders, DAGM-shaped 1x512x512 2-class, batch 8+8", "unet_uaps", 1, 2, 5, 8, 512),
+            ("configs[4] per-GPU shape: UAPS ResNet-50 encoder K=3, KoSDD2-shaped 3x640x640 2-class, batch 8+8", "resnet50_uaps", 3, 2, 3, 8, 640)):
+        try:
+            torch.manual_seed(1337)
+            model = uaps_amd.net_factory(net, in_chns, classes, n_aux=aux)
+            trainer = uaps_amd.UAPSTrainer(model, seed=1337)
+            data = uaps_amd.data.SyntheticBatches(batch, in_chns, classes, size, size, n_batches=2, seed=1337, device=dev)
+            for _ in range(2):
+                trainer.train_step(*data.next())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                trainer.train_step(*data.next())
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            loss = float(trainer.last["loss"])
+            trainer.check_errors()
+            out.append({"workload": name, "images_per_s": round(2 * batch / ms * 1e3, 1), "ms_per_step": round(ms, 2), "steps": steps,
+                        "final_loss": round(loss, 5), "launch_mode": "eager, one HIP stream per auxiliary decoder"})
+            del trainer, model, data
+        except Exception as e:                               # never lose the headline line to a side measurement
+            out.append({"workload": name, "error": f"{type(e).__name__}: {e}"[:300]})
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,6 +168,8 @@ def main():
     ap.add_argument("--exact-steps", type=int, default=5,
                     help="steps timed with every convolution on the fp32 matrix instruction after the headline (0 = skip)")
     ap.add_argument("--analysis-steps", type=int, default=6, help="single-stream steps after the timed region for the per-kernel figures")
+    ap.add_argument("--other-configs", type=int, default=4,
+                    help="N = 1 only: steps timed of each of BASELINE.json configs[3] and the per-GPU shape of configs[4] after everything else (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -449,6 +489,10 @@ def main():
             res["comm"] = comm
         if args.net != "unet_uaps":
             res["config"]["workload"] = f"{args.net} K={args.aux}, {H}x{W} {C}-class, batch {b}+{b} per GPU (not the BASELINE metric config)"
+        if world == 1 and args.other_configs > 0 and args.net == "unet_uaps" and (b, H, C, args.aux) == (16, 256, 4, 3):
+            # the other single-GPU shapes of BASELINE.json, a few eager steps each (decoder streams as in the headline): not the
+            # metric, but a number the driver sees for them
+            res["other_configs"] = other_configs(args.other_configs, dev)
         if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
             res["cpu_baseline"] = cpu_baseline(b, H, W)
         print(json.dumps(res), flush=True)

@@ -295,3 +295,35 @@ def test_checkpoint_load_drops_the_capture(tmp_path):
         for (n, pa), pb in zip(m1.named_parameters(), m2.parameters()):
             assert torch.equal(pa, pb), n
         assert {float(st["step"]) for st in g.optimizer.state.values()} == {10.0}
+
+
+def test_two_trainers_interleave_their_step_states():
+    """The step-state pointer is process-wide (include/uaps_hip.h): every state-mode step brackets its launches with
+    uaps_set_step_state(own) ... (NULL), so two trainers of one process (the two-model methods of the reference's siblings, CPS)
+    can step alternately -- each ends exactly where it ends when it runs alone, one of them replaying a captured graph."""
+    import uaps_amd
+    data = _batches(6, 2, 64, 64, seed=51)
+
+    def run(models, kws, seeds):
+        trs = [uaps_amd.UAPSTrainer(m, base_lr=1e-3, seed=s, **kw) for m, kw, s in zip(models, kws, seeds)]
+        for i in range(6):
+            for tr, s in zip(trs, seeds):
+                uaps_amd.perturb.manual_seed(s, 0); np.random.seed(s)
+                tr.train_step(*data[(i + s) % 6])
+        torch.cuda.synchronize()
+        return trs
+
+    base = [_model(13), _model(14)]
+    solo = []
+    for k, (kw, seed) in enumerate((({"use_graph": True}, 3), ({"step_state": True}, 4))):
+        m = copy.deepcopy(base[k]).to(DEV)
+        run([m], [kw], [seed])
+        solo.append(m)
+    both = [copy.deepcopy(base[0]).to(DEV), copy.deepcopy(base[1]).to(DEV)]
+    trs = run(both, [{"use_graph": True}, {"step_state": True}], [3, 4])
+    assert trs[0].step_graph.graph is not None
+    for k in range(2):
+        for (n, pa), pb in zip(solo[k].named_parameters(), both[k].parameters()):
+            assert torch.equal(pa, pb), (k, n)
+        for (n, ba), bb in zip(solo[k].named_buffers(), both[k].buffers()):
+            assert torch.equal(ba, bb), (k, n)
