@@ -206,7 +206,8 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
 }
 
 template <int BN>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_g1h_kernel(ConvFwdArgs a) { conv_g1_body<BN, true>(a); }
+__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 registers (the compiler's free choice was 170)
+void conv_g1h_kernel(ConvFwdArgs a) { conv_g1_body<BN, true>(a); }
 template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_g1s_kernel(ConvFwdArgs a) { conv_g1_body<BN, false>(a); }
 

@@ -217,7 +217,10 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
 
 template <int NCG>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_hp16_kernel(ConvFwdArgs a) { conv_hp16_body<NCG, false>(a); }
+// NCG = 2: three workgroups per CU, as launch_hp16 sizes the grid (the BatchNorm coefficients would otherwise push the kernel
+// two registers past the 168 that three waves per SIMD allow -- a third of the grid then waited for a second round)
 template <int NCG>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_hp16_bn_kernel(ConvFwdArgs a) { conv_hp16_body<NCG, true>(a); }
+__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(NCG == 2 ? 3 : 2, NCG == 2 ? 3 : 2)))
+void conv_hp16_bn_kernel(ConvFwdArgs a) { conv_hp16_body<NCG, true>(a); }
 
 }  // namespace uaps
