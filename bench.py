@@ -217,7 +217,7 @@ def main():
         if world > 1 and hasattr(os, "sched_setaffinity"):  # every rank its own slice of the usable cores: 8 launching processes + RCCL threads share the host
             cpus = sorted(os.sched_getaffinity(0))
             per = len(cpus) // world
-            if per >= 1:
+            if per >= 4:                                    # fewer than 4 cores per rank (launch + autograd + RCCL threads): leave the scheduler alone
                 affinity = cpus[local_rank * per:(local_rank + 1) * per]
                 try:
                     os.sched_setaffinity(0, affinity)
