@@ -180,6 +180,8 @@ def main():
 
     import uaps_amd.unet as _unet
     _unet._DECODER_STREAMS = not args.single_stream
+    if os.environ.get("UAPS_BENCH_CPUS"):                   # experiment hook: this process on its first n usable cores (what one of 8 ranks gets)
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:int(os.environ["UAPS_BENCH_CPUS"])])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
