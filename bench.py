@@ -27,7 +27,7 @@ def mfma_peak_for(kernel_name):
     """Peak in ALGORITHMIC (fp32) TFLOP/s of the matrix pipe a conv kernel runs on: the fp16-split kernels (conv_h*) evaluate every
     fp32 multiply as three fp16 partial products, the bf16-split kernels (conv_s*) as six bf16 ones: their ceilings are the
     dense 16-bit matrix peak / 3 and / 6."""
-    if kernel_name.startswith("conv_h"):
+    if kernel_name.startswith("conv_h") or kernel_name.startswith("conv_g1h") or kernel_name.startswith("conv_gw1h"):
         return MFMA_BF16_PEAK_TF / 3.0
     return MFMA_BF16_PEAK_TF / 6.0 if kernel_name.startswith("conv_s") else MFMA_F32_PEAK_TF
 
