@@ -188,10 +188,12 @@ def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
     np.testing.assert_allclose(st[..., 0].double().sum((1, 2)).cpu().numpy(), y.detach().double().sum((0, 2, 3)).cpu().numpy(), rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,dil", [(2, 32, 32, 40, 40, 2), (1, 64, 48, 32, 32, 4), (2, 16, 128, 20, 36, 2), (1, 256, 256, 16, 16, 4)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,dil", [(2, 32, 32, 40, 40, 2), (1, 64, 48, 32, 32, 4), (2, 16, 128, 20, 36, 2), (1, 256, 256, 16, 16, 4),
+                                                (1, 128, 128, 80, 80, 2), (1, 256, 256, 80, 80, 4), (2, 64, 96, 12, 44, 4), (1, 8, 32, 24, 24, 2)])
 def test_dilated_conv_vs_torch_cpu(B, Cin, Cout, H, W, dil):
     """3x3 convolutions with dilation 2 / 4 and padding = dilation (the stride-replaced-by-dilation stages of the
-    reference's ResNet-50, utilities/resnet.py:8-10, 201-203): forward, input and weight gradient vs PyTorch CPU."""
+    reference's ResNet-50, utilities/resnet.py:8-10, 201-203): forward, input and weight gradient vs PyTorch CPU.  With
+    >= 32 output channels forward and input gradient run the dilated split kernels (csrc/conv_split.hpp, DIL = 2 / 4)."""
     from uaps_amd.conv import conv2d
     x = _mk((B, Cin, H, W), 31)
     w = _mk((Cout, Cin, 3, 3), 32) / np.sqrt(Cin * 9)
@@ -201,8 +203,8 @@ def test_dilated_conv_vs_torch_cpu(B, Cin, Cout, H, W, dil):
     yr.backward(dy)
     dev = torch.device("cuda:0")
     xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
-    y = conv2d(xg, wg, None, dilation=dil)
-    y.backward(dy.to(dev))
+    y = conv2d(_b(xg), wg, None, dilation=dil)
+    y.backward(_b(dy.to(dev)))
     for got, ref, what in ((y.detach(), yr.detach(), "y"), (xg.grad, xr.grad, "dx"), (wg.grad, wr.grad, "dw")):
         scale = float(ref.abs().max()) + 1e-12
         err = float((got.cpu() - ref).abs().max())

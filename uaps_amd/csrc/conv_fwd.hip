@@ -205,7 +205,9 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // instruction; the bottleneck projections of the ResNet encoders (64 ... 2048 channels, utilities/resnet.py:55-95) are
     // compute-bound and take the split form
     const bool big_1x1 = ks == 1 && Cin >= 64 && (long)Cin * Cout >= 16384 && (long)H * W >= 1024;
-    p->split = conv_mode() >= 1 && p->dil == 1 && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || big_1x1 || ((cfg >> 29) & 3));
+    // dilated 3x3 (ResNet stages): the 32x32x16 split form only (>= 32 output channels, no forced settings)
+    const bool dil_ok = p->dil == 1 || (ks == 3 && Cin > 8 && p->CoutP % 32 == 0 && !(cfg & 0x70ffffff));
+    p->split = conv_mode() >= 1 && dil_ok && (W % 4 == 0) && !(cfg & 0x10ffff00) && ((ks == 3 && Cin > 8) || big_1x1 || ((cfg >> 29) & 3));
     if (g_conv_tuning & UAPS_TUNE_NO_SPLIT_FWD) p->split = false;
     p->g1 = p->split && big_1x1 && p->vec && p->CoutP % 64 == 0 && !(cfg & 0x7fffffff);
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
@@ -221,6 +223,23 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
         p->sbn = bn_req;
     }
     return UAPS_OK;
+}
+
+template <int BN>
+int launch_s32d(ConvFwdArgs a, int dil, hipStream_t s) {
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 7) / 8;
+    a.nblk = a.CoutP / BN;
+    const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL || (dil != 2 && dil != 4)) return UAPS_EINVAL;
+    if (a.wscale) {
+        if (dil == 2) UAPS_LAUNCH_MAIN((conv_h32d_kernel<BN, 2>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_h32d_kernel<BN, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    } else {
+        if (dil == 2) UAPS_LAUNCH_MAIN((conv_s32d_kernel<BN, 2>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_s32d_kernel<BN, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    }
+    return (int)hipGetLastError();
 }
 
 // x [B,Cin,H,W] * packed weights [taps][CinP][CoutP] -> y [B,Cout,H,W]
@@ -240,6 +259,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     if (rc) return rc;
     if ((x2 && (uintptr_t)x2 % 16) || (y2 && (uintptr_t)y2 % 16)) p.vec = false;
     if (!p.vec || (Csplit < Cin && Csplit % p.sck)) p.split = false;      // unaligned tensors / odd concat split: exact kernels
+    if (p.dil > 1 && (!p.s32 || x2 || y2 || xf)) p.split = false;        // the dilated split form: one tensor per side, no staging BatchNorm
     ConvFwdArgs a{};
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats;
@@ -270,6 +290,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
                 return launch_g1(a, p.CoutP % 128 == 0 ? 128 : 64, s);
             }
         }
+        if (p.dil > 1) return p.sbn == 64 ? launch_s32d<64>(a, p.dil, s) : launch_s32d<32>(a, p.dil, s);
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
         if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
@@ -404,6 +425,7 @@ extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int
     if (!buf || buflen < 64) return UAPS_EINVAL;
     if (p.small) snprintf(buf, buflen, "conv_small_kernel<8, 4>");
     else if (p.g1) snprintf(buf, buflen, "conv_g1s_kernel<%d>", p.CoutP % 128 == 0 ? 128 : 64);
+    else if (p.s32 && p.dil > 1) snprintf(buf, buflen, "conv_s32d_kernel<%d, %d>", p.sbn, p.dil);
     else if (p.s32) snprintf(buf, buflen, "conv_s32_kernel<%d>", p.sbn);
     else if (p.split) snprintf(buf, buflen, "conv_sfwd_kernel<%d, %d, %d, %d, %d>", ks, p.th, p.tw, p.sbn, p.sck);
     else snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);

@@ -371,15 +371,18 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_hfwd_bn_kernel(ConvFwdAr
 // -------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int BN, bool XF, bool H16 = false>
+// DIL = dilation of the 3x3 kernel with padding = DIL (the dilated stages of utilities/resnet.py:8-10, 201-203; round 3): the
+// halo is DIL rows and DIL <= 4 columns inside the 4-float margin, a tap is DIL pixels away.
+template <int BN, bool XF, bool H16 = false, int DIL = 1>
 __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     constexpr int NP = H16 ? 2 : 3;                   // pieces per operand: three bf16 (six products) or two fp16 (three products)
-    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 8, PLANE = IH * IW, XS = 3;     // rows start 4 floats left of the tile
+    constexpr int TH = 8, TW = 32, IH = TH + 2 * DIL, IW = TW + 8, PLANE = IH * IW, XS = 4 - DIL;     // rows start 4 floats left of the tile
     constexpr int NQ = 9, NKS = 5, NQP = 2 * NKS;
     constexpr int NT = BN / 32;                       // 32-channel N tiles per wave (every wave covers all BN channels)
     constexpr int NHU = IH * (IW / 2);                // staging half-units: 2 consecutive pixels x 8 channels
+    constexpr int NHT = (NHU + kConvThreads - 1) / kConvThreads;      // half-units per thread: 1 (2 for dilation 4)
     constexpr int NWU = NP * NQ * BN, NWT = (NWU + kConvThreads - 1) / kConvThreads;
-    static_assert(NHU <= kConvThreads, "one half-unit per thread");
+    static_assert(DIL >= 1 && DIL <= 4, "dilation 1..4");
 
     __shared__ __attribute__((aligned(16))) u32x4 sIn[NP * PLANE];
     __shared__ __attribute__((aligned(16))) u32x4 sW[NP * NQP * BN];
@@ -405,12 +408,19 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     }
 
     // ---- staging plan ----
-    const bool has_unit = tid < NHU;
-    const int ur = tid / (IW / 2), uc = tid % (IW / 2);
-    const int ugy = y0 - 1 + ur, ugx = x0 - 4 + uc * 2;
-    const bool uin = has_unit && (unsigned)ugy < (unsigned)a.H && (unsigned)ugx < (unsigned)a.W;      // W % 4 == 0: both pixels in or out
-    const uint32_t ugoff = (uint32_t)(ugy * a.W + ugx) * 4u;
-    const int uloff = ur * IW + uc * 2;
+    bool has_unit[NHT], uin[NHT];
+    uint32_t ugoff[NHT];
+    int uloff[NHT];
+#pragma unroll
+    for (int t = 0; t < NHT; ++t) {
+        const int u = tid + t * kConvThreads;
+        has_unit[t] = u < NHU;
+        const int ur = u / (IW / 2), uc = u % (IW / 2);
+        const int ugy = y0 - DIL + ur, ugx = x0 - 4 + uc * 2;
+        uin[t] = has_unit[t] && (unsigned)ugy < (unsigned)a.H && (unsigned)ugx < (unsigned)a.W;      // W % 4 == 0: both pixels in or out
+        ugoff[t] = (uint32_t)(ugy * a.W + ugx) * 4u;
+        uloff[t] = ur * IW + uc * 2;
+    }
     const int CGP = a.CinP;
     uint32_t wgoff[NWT];
     int wloff[NWT];
@@ -430,10 +440,10 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     const __amdgpu_buffer_rsrc_t rs_xf = XF ? make_rsrc(a.xf + (size_t)(b / (XF ? a.xf_Bg : 1)) * a.Cin, (uint32_t)a.Cin * 8u)
                                             : make_rsrc(a.wp, 0);
 
-    f32x2 rin[8];
+    f32x2 rin[NHT][8];
     u32x4 rw[NWT];
     f32x2 rxf[XF ? 8 : 1];
-    u32x4 pk[NP][2];
+    u32x4 pk[NHT][NP][2];
 
     auto load_chunk = [&](int ci0) {
         const bool second = ci0 >= a.Csplit;        // the chunk lies in one source (Csplit % 8 == 0)
@@ -441,22 +451,25 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             ? make_rsrc(in2_b + (size_t)(ci0 - a.Csplit) * HW, (uint32_t)(a.Cin - ci0) * HW4)
             : make_rsrc(in_b + (size_t)ci0 * HW, (uint32_t)(a.Csplit - ci0) * HW4);
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            rin[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, uin ? (int)(ugoff + (uint32_t)c * HW4) : (int)kOob, 0, 0));
-        if constexpr (XF) {
+        for (int t = 0; t < NHT; ++t)
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                rin[t][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, uin[t] ? (int)(ugoff[t] + (uint32_t)c * HW4) : (int)kOob, 0, 0));
+        if constexpr (XF) {                           // (staging-time BatchNorm: one half-unit per thread, i.e. no dilation 4)
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                    rs_xf, uin ? (int)((uint32_t)(ci0 + c) * 8u) : (int)kOob, 0, 0));
+                    rs_xf, uin[0] ? (int)((uint32_t)(ci0 + c) * 8u) : (int)kOob, 0, 0));
         }
         const uint32_t wbase = (uint32_t)(ci0 / 8) * a.CoutP * 16u;
 #pragma unroll
         for (int n = 0; n < NWT; ++n)
             rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wgoff[n] == kOob ? kOob : wgoff[n] + wbase), 0, 0));
     };
-    auto split_pair = [&](int idx) {                 // channel pair c2 of pixel p
+    static_assert(!XF || NHT == 1, "the staging-time BatchNorm form keeps one half-unit per thread");
+    auto split_pair_t = [&](int t, int idx) {        // channel pair c2 of pixel p of this thread's half-unit t
         const int p = idx / 4, c2 = idx % 4;
-        float v0 = rin[2 * c2][p], v1 = rin[2 * c2 + 1][p];
+        float v0 = rin[t][2 * c2][p], v1 = rin[t][2 * c2 + 1][p];
         if constexpr (XF) {
             const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
             v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
@@ -464,19 +477,29 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         if constexpr (H16) {
             unsigned q0, q1;
             conv_split2h(v0 * in_scale, v1 * in_scale, q0, q1);
-            pk[0][p][c2] = q0; pk[1][p][c2] = q1;
+            pk[t][0][p][c2] = q0; pk[t][1][p][c2] = q1;
         } else {
             unsigned q0, q1, q2;
             conv_split3(v0, v1, q0, q1, q2);
-            pk[0][p][c2] = q0; pk[1][p][c2] = q1; pk[2][p][c2] = q2;
+            pk[t][0][p][c2] = q0; pk[t][1][p][c2] = q1; pk[t][2][p][c2] = q2;
         }
     };
+    auto split_pair = [&](int idx) { split_pair_t(0, idx); };
     auto store_chunk = [&]() {
-        if (has_unit) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+        for (int t = 0; t < NHT; ++t) {
+            if constexpr (NHT > 1) {                  // (the second half-unit is split here, between the barriers)
+                if (t > 0) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) sIn[q * PLANE + uloff + p] = pk[q][p];
+                    for (int i = 0; i < 8; ++i) split_pair_t(t, i);
+                }
+            }
+            if (has_unit[t]) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) sIn[q * PLANE + uloff[t] + p] = pk[t][q][p];
+                }
             }
         }
 #pragma unroll
@@ -500,7 +523,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         const int q = 2 * ks + h;
-        kstep[ks] = q < NQ ? (q / 3) * IW + (q % 3) : 0;
+        kstep[ks] = q < NQ ? (q / 3) * DIL * IW + (q % 3) * DIL : 0;
     }
     const int boff = h * BN + r;
 
@@ -620,6 +643,11 @@ template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_h32_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, true>(a); }
 template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_h32_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true, true>(a); }
+// dilated 3x3 (dilation 2 / 4, padding = dilation), no staging-time BatchNorm
+template <int BN, int DIL>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_s32d_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, false, DIL>(a); }
+template <int BN, int DIL>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_h32d_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, true, DIL>(a); }
 
 // -------------------------------------------------------------------------------------------------
 // Split weight packing: w [Cout][Cin][KS][KS] fp32 ->

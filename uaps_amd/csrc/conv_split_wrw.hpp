@@ -20,14 +20,15 @@
 
 namespace uaps {
 
-template <int TH, int WCO, int WCI> struct SWrwCfg {
+template <int TH, int WCO, int WCI, int DIL = 1> struct SWrwCfg {
     static constexpr int TW = 32, WR = 4 / (WCO * WCI), RPW = TH / WR;          // rows of the tile per wave
     static constexpr int BCO = 16 * WCO, BCI = 16 * WCI;
+    static constexpr int XG = DIL > 1 ? 6 : 4;                                   // 8-pixel groups per staged input row (dilated: one halo group either side)
     static constexpr int DPLU = TH * 4 + 2;                                      // dy plane stride in 16-byte units (== 2 mod 4)
-    static constexpr int XPLU = (TH + 2) * 4 + 2;                                // input plane stride in 16-byte units
+    static constexpr int XPLU = (TH + 2) * XG + 2;                               // input plane stride in 16-byte units
     static constexpr int EPL = (TH + 2) * 4 + 1;                                 // edge dwords per input channel (odd stride)
     static constexpr int ND = (BCO * TH * 4 + kConvThreads - 1) / kConvThreads;  // dy staging units per thread (8 pixels each)
-    static constexpr int NX = (BCI * (TH + 2) * 4 + kConvThreads - 1) / kConvThreads;
+    static constexpr int NX = (BCI * (TH + 2) * XG + kConvThreads - 1) / kConvThreads;
     static_assert(WCO * WCI * WR == 4 && TH % WR == 0, "wave arrangement");
 };
 
@@ -57,10 +58,17 @@ __device__ __forceinline__ void split8h(const float (&v)[8], float sc, u32x4& p0
 
 // H16: the two-piece fp16 form (three partial products); dy and the input are scaled by powers of two derived from the
 // callers' bounds (ConvWrwArgs::dy_bound / in_bound / in2_bound), the slabs receive the unscaled partial sums
-template <int TH, int WCO, int WCI, bool XF, bool H16 = false>
+//
+// DIL = 2 / 4 (the dilated 3x3 layers of utilities/resnet.py:8-10, 201-203; fp16 form only): a tile is TH rows DIL apart
+// (tile row index = DIL * block + row phase), so that the three row taps still meet TH + 2 staged rows; the column taps are
+// DIL pixels = DIL / 2 dwords of packed pieces away: the staged rows carry one 8-pixel halo group on either side and the two
+// shifted fragments are register selections of the aligned fragment and its neighbours' dwords (no alignbit, no edge dwords).
+template <int TH, int WCO, int WCI, bool XF, bool H16 = false, int DIL = 1>
 __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
-    using Cfg = SWrwCfg<TH, WCO, WCI>;
+    using Cfg = SWrwCfg<TH, WCO, WCI, DIL>;
+    static_assert(DIL == 1 || ((DIL == 2 || DIL == 4) && H16 && !XF), "dilated form: fp16 pieces, no staging-time BatchNorm");
     constexpr int NP = H16 ? 2 : 3;
+    constexpr int XG = Cfg::XG, XH = DIL > 1 ? 1 : 0;      // groups per staged row, halo groups on the left
     constexpr int TW = 32, WR = Cfg::WR, RPW = Cfg::RPW, BCO = Cfg::BCO, BCI = Cfg::BCI;
     constexpr int DPLU = Cfg::DPLU, XPLU = Cfg::XPLU, EPL = Cfg::EPL, ND = Cfg::ND, NX = Cfg::NX;
     constexpr int RED_FLOATS = WR > 1 ? (WR / 2) * WCO * WCI * 10 * 256 : 0;
@@ -68,7 +76,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     constexpr int LDS_UNITS = STAGE_UNITS > RED_FLOATS / 4 ? STAGE_UNITS : RED_FLOATS / 4;
 
     __shared__ __attribute__((aligned(16))) u32x4 smem[LDS_UNITS];
-    __shared__ unsigned sE[NP * BCI * EPL];
+    __shared__ unsigned sE[DIL == 1 ? NP * BCI * EPL : 1];
     __shared__ f32x2 sXf[XF ? kWrwMaxGroups * BCI + 1 : 1];
     u32x4* sD = smem;                        // [piece][co][row][4 groups] (+ 2 pad units per plane)
     u32x4* sX = smem + NP * BCO * DPLU;      // [piece][ci][row][4 groups] (+ 2 pad units per plane)
@@ -108,7 +116,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
     for (int n = 0; n < NX; ++n) {
         const int u = tid + n * kConvThreads;
-        xC[n] = u < BCI * (TH + 2) * 4 ? u / ((TH + 2) * 4) : -1; xR[n] = (u / 4) % (TH + 2); xG[n] = u % 4;
+        xC[n] = u < BCI * (TH + 2) * XG ? u / ((TH + 2) * XG) : -1; xR[n] = (u / XG) % (TH + 2); xG[n] = u % XG;
     }
     if constexpr (XF) {
         const int G = a.B / a.xf_Bg;
@@ -122,15 +130,16 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     }
 
     float rd[ND][8];
-    float rx[NX][10];                        // 8 pixels, then the pixel left of the group and the pixel right of it
+    float rx[NX][DIL == 1 ? 10 : 8];         // 8 pixels, then (DIL 1) the pixel left of the group and the pixel right of it
     int xf_idx[XF ? NX : 1];
 
     auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
-        const int y0 = (a.col_major ? tt % a.tiles_y : tt / a.tiles_x) * TH, x0 = (a.col_major ? tt / a.tiles_y : tt % a.tiles_x) * TW;
+        const int ry = a.col_major ? tt % a.tiles_y : tt / a.tiles_x, x0 = (a.col_major ? tt / a.tiles_y : tt % a.tiles_x) * TW;
+        const int y0 = DIL == 1 ? ry * TH : ry % DIL + (ry / DIL) * (TH * DIL);      // dilated: rows y0 + DIL * r
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
-            const int c = co0 + dC[n], gy = y0 + dR[n], gx = x0 + dG[n] * 8;
+            const int c = co0 + dC[n], gy = y0 + dR[n] * DIL, gx = x0 + dG[n] * 8;
             const bool ok = dC[n] >= 0 && c < a.Cout && gy < a.H && gx < a.W;             // W % 4 == 0: float4 pieces are all in or all out
             const float* p = a.dout + ((size_t)b * a.Cout + (ok ? c : 0)) * HW + (ok ? gy * a.W + gx : 0);
             const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -140,18 +149,20 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
         }
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
-            const int c = ci0 + xC[n], gy = y0 - 1 + xR[n], gx = x0 + xG[n] * 8;
+            const int c = ci0 + xC[n], gy = y0 + (xR[n] - 1) * DIL, gx = x0 + (xG[n] - XH) * 8;
             const bool second = c >= a.Csplit;
             const float* src = second ? a.in2 + ((size_t)b * (a.Cin - a.Csplit) + (c - a.Csplit)) * HW : a.in + ((size_t)b * a.Csplit + c) * HW;
             const bool okc = xC[n] >= 0 && c < a.Cin && gy >= 0 && gy < a.H;
-            const bool ok = okc && gx < a.W;
+            const bool ok = okc && gx >= 0 && gx < a.W;
             const float* p = src + (okc ? gy * a.W : 0) + (ok ? gx : 0);
             const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
             const f32x4 v1 = (ok && gx + 4 < a.W) ? *reinterpret_cast<const f32x4*>(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) { rx[n][k] = v0[k]; rx[n][4 + k] = v1[k]; }
-            rx[n][8] = (okc && gx - 1 >= 0 && gx - 1 < a.W) ? src[gy * a.W + gx - 1] : 0.f;
-            rx[n][9] = (okc && gx + 8 < a.W) ? src[gy * a.W + gx + 8] : 0.f;
+            if constexpr (DIL == 1) {
+                rx[n][8] = (okc && gx - 1 >= 0 && gx - 1 < a.W) ? src[gy * a.W + gx - 1] : 0.f;
+                rx[n][9] = (okc && gx + 8 < a.W) ? src[gy * a.W + gx + 8] : 0.f;
+            }
             if constexpr (XF) xf_idx[n] = okc ? (b / a.xf_Bg) * BCI + xC[n] : XF_ZERO;     // padding rows / channels stay zero
         }
     };
@@ -188,9 +199,13 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             float v8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v8[k] = rx[n][k];
-            const int u = xC[n] * XPLU + xR[n] * 4 + xG[n];
+            const int u = xC[n] * XPLU + xR[n] * XG + xG[n];
             const int eu = xC[n] * EPL + xR[n] * 4 + xG[n];
-            if constexpr (H16) {
+            if constexpr (DIL > 1) {
+                u32x4 p0, p1;
+                split8h(v8, sc_x, p0, p1);
+                sX[u] = p0; sX[BCI * XPLU + u] = p1;
+            } else if constexpr (H16) {
                 u32x4 p0, p1;
                 split8h(v8, sc_x, p0, p1);
                 sX[u] = p0; sX[BCI * XPLU + u] = p1;
@@ -218,7 +233,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     const int aoff = (wco * 16 + j) * DPLU + kq;         // + row * 4 (+ piece plane)
-    const int boff = (wci * 16 + j) * XPLU + kq;
+    const int boff = (wci * 16 + j) * XPLU + kq + XH;    // + row * XG
     const int eoff = (wci * 16 + j) * EPL + kq;
 
     if (t_begin < t_end) { load_tile(t_begin); }
@@ -235,7 +250,20 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             bf16x8 bf[3][NP];                             // [shift kx][piece]
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const u32x4 c = sX[p * BCI * XPLU + boff + r * 4];
+                const u32x4 c = sX[p * BCI * XPLU + boff + r * XG];
+                if constexpr (DIL > 1) {                  // neighbours' dwords: pixels x - DIL .. x - 1 and x + 8 .. x + 7 + DIL
+                    const unsigned* cl = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLU + boff + r * XG - 1]);
+                    const unsigned* cr = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLU + boff + r * XG + 1]);
+                    if constexpr (DIL == 2) {
+                        bf[0][p] = __builtin_bit_cast(bf16x8, u32x4{cl[3], c[0], c[1], c[2]});
+                        bf[2][p] = __builtin_bit_cast(bf16x8, u32x4{c[1], c[2], c[3], cr[0]});
+                    } else {
+                        bf[0][p] = __builtin_bit_cast(bf16x8, u32x4{cl[2], cl[3], c[0], c[1]});
+                        bf[2][p] = __builtin_bit_cast(bf16x8, u32x4{c[2], c[3], cr[0], cr[1]});
+                    }
+                    bf[1][p] = __builtin_bit_cast(bf16x8, c);
+                    continue;
+                }
                 const unsigned e = sE[p * BCI * EPL + eoff + r * 4];
                 const unsigned t01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), t12 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
                 const unsigned t23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
@@ -350,5 +378,7 @@ template <int TH, int WCO, int WCI>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_hwrw_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, false, true>(a); }
 template <int TH, int WCO, int WCI>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_hwrw_bn_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, true, true>(a); }
+template <int TH, int WCO, int WCI, int DIL>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_hwrw_d_kernel(ConvWrwArgs a) { conv_swrw_body<TH, WCO, WCI, false, true, DIL>(a); }
 
 }  // namespace uaps

@@ -209,6 +209,20 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         else UAPS_LAUNCH_MAIN(conv_small_wrw_kernel, dim3(grid), dim3(kConvThreads), 0, s, a);
         return (int)hipGetLastError();
     }
+    // dilated 3x3 with both operands bounded: the dilated fp16 form (conv_hwrw_d_kernel); same 32 x 32 channel blocks, 4-row
+    // tiles and slabs as the fp32 kernel the plan describes, so workspace size and reduction are unchanged
+    if (p.dil > 1 && ks == 3 && !xf && !x2 && vec16 && W >= 32 && Cin >= 16 && !((cfg >> 28) & 1) && uaps_conv_get_mode() == 2 &&
+        !(uaps_conv_get_tuning() & UAPS_TUNE_NO_SPLIT_WRW) && hints.bound[0] && hints.bound[1] && p.wco == 2 && p.wci == 2 && p.TH == 4) {
+        a.dy_bound = hints.bound[0]; a.dy_mul = hints.mul[0];
+        a.in_bound = hints.bound[1]; a.in_mul = hints.mul[1];
+        a.err = uaps::error_word();
+        a.tiles_y = p.dil * (((H + p.dil - 1) / p.dil + 3) / 4);      // per row phase: ceil(ceil(H / dil) / 4) tiles
+        const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;
+        if (grid <= 0 || grid > 0x7fffffffL || (long)a.B * a.tiles_x * a.tiles_y > 0x7fffffffL) return UAPS_EINVAL;
+        if (p.dil == 2) UAPS_LAUNCH_MAIN((conv_hwrw_d_kernel<4, 2, 2, 2>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hwrw_d_kernel<4, 2, 2, 4>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
     if (p.split) {
         // mode 2 and every tensor operand bounded (uaps_next_call_hints: 0 = dy, 1 = x, 2 = x2): the two-piece fp16 form
         if (uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1] && (!x2 || Csplit >= Cin || hints.bound[2])) {
