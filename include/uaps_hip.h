@@ -146,6 +146,11 @@ int uaps_convs_bwd_weight(const float* dy, const float* x, float* dw, int B, int
  * (first maximum wins, NaN propagates: torch.nn.MaxPool2d(3, 2, 1)) */
 int uaps_maxpool3x3s2_fwd(const float* x, float* y, void* idx, long planes, int H, int W, uaps_stream_t stream);
 int uaps_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, long planes, int H, int W, uaps_stream_t stream);
+/* y [planes, OH, OW] = x[:, ::2, ::2] (OH = (H - 1) / 2 + 1) and its adjoint (dx [planes, H, W]: dy at the even positions, zero
+ * elsewhere): the sampling of a 1x1 / stride 2 convolution (utilities/resnet.py:13-14, 157-161), which then runs as a
+ * stride-1 uaps_conv_fwd on the sampled tensor */
+int uaps_subsample2_fwd(const float* x, float* y, long planes, int H, int W, uaps_stream_t stream);
+int uaps_subsample2_bwd(const float* dy, float* dx, long planes, int H, int W, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The whole loss block of one training step -- UAPS_train.py:194-218 on the labelled logits and :186-189, 223-282 on the

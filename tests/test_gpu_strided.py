@@ -68,6 +68,22 @@ def test_maxpool3x3s2_vs_torch_cpu(B, C, H, W):
     assert torch.equal(xg.grad.cpu(), xr.grad)       # ties resolved like torch: the first maximum of the window
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 48, 64), (1, 3, 7, 9), (2, 5, 33, 20), (2, 256, 160, 160), (1, 4, 8, 12)])
+def test_subsample2_and_its_adjoint(B, C, H, W):
+    """x[:, :, ::2, ::2] (the sampling of the 1x1 / stride-2 shortcut, utilities/resnet.py:157-161) and its adjoint: bit-exact
+    copies; both the 16-byte and the scalar form."""
+    from uaps_amd.conv import subsample2
+    x = _mk((B, C, H, W), 15).to(DEV).requires_grad_(True)
+    y = subsample2(x)
+    ref = x.detach()[:, :, ::2, ::2]
+    assert y.shape == ref.shape and torch.equal(y.detach(), ref)
+    dy = _mk(tuple(y.shape), 16).to(DEV)
+    y.backward(dy)
+    want = torch.zeros_like(x.detach())
+    want[:, :, ::2, ::2] = dy
+    assert torch.equal(x.grad, want)
+
+
 def test_no_library_convolution_or_pooling_on_the_resnet_path():
     """The ResNet-50 encoder on the GPU must not call F.conv2d / max-pool: run its forward + backward under a profiler-free
     check -- torch's convolution and pooling entry points are patched to raise."""

@@ -63,6 +63,52 @@ def test_resnet50_hip_path_vs_reference_fixture():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layer,idx,cin,hw", [("layer2", 0, 256, 64), ("layer3", 0, 512, 32), ("layer3", 1, 1024, 32), ("layer4", 0, 1024, 32),
+                                              ("layer4", 1, 2048, 32)])
+@pytest.mark.parametrize("mode", ["h16", "split", "exact"])
+def test_bottleneck_block_forward_backward_vs_cpu_module_math(layer, idx, cin, hw, mode):
+    """One Bottleneck (utilities/resnet.py:55-95) in train mode, forward and every gradient, against the plain-PyTorch module
+    math of the same class on the CPU: layer2.0 holds the two strided convolutions and the sampled shortcut projection,
+    layer3 / layer4 the dilated (2 / 4) 3x3 convolutions.  Inputs are ReLU outputs with a magnitude bound, as inside the net."""
+    from uaps_amd import bounds, conv
+    dev = torch.device("cuda:0")
+    cpu = _backbone().train()
+    gpu = _backbone().to(dev).train()
+    blk_c, blk_g = getattr(cpu, layer)[idx], getattr(gpu, layer)[idx]
+    g = torch.Generator().manual_seed(cin + idx)
+    x = torch.relu(torch.randn(2, cin, hw, hw, generator=g))
+    xc = x.clone().requires_grad_(True)
+    yc = blk_c(xc)
+    dy = torch.randn(yc.shape, generator=g)
+    yc.backward(dy)
+    prev = conv.get_mode()
+    conv.set_mode(mode)
+    try:
+        gpu._bns = [m for m in gpu.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        conv.pack_all([m.weight for m in gpu.modules() if isinstance(m, torch.nn.Conv2d) and m.kernel_size[0] in (1, 3)])
+        bounds.refresh(gpu._bns)
+        xg = x.to(dev).requires_grad_(True)
+        yg = blk_g(bounds.put(xg, bounds.from_value(xg.detach().abs().max()), 1.0))
+        dyg = dy.to(dev)
+        yg.backward(bounds.put(dyg, bounds.from_value(dyg.abs().max()), 1.0))
+    finally:
+        conv.set_mode(prev)
+
+    # Forward: rounding only.  Gradients: BatchNorm outputs that sit within rounding of zero flip their ReLU mask between any
+    # two fp32 evaluations (PyTorch-CPU fp32 against float64 differs by 1e-4 ... 4e-3 in relative L2 norm on these blocks,
+    # tools/diag/blk_err.py); each operator's own gradient is pinned tightly in test_gpu_conv / test_gpu_strided / test_gpu_fused,
+    # this test pins the wiring (a wrong operand, layout or missing term is an O(1) error).
+    def close(a, b, what, tol):
+        err = float((a.cpu() - b).norm() / (b.norm() + 1e-20))
+        assert err <= tol, f"{layer}[{idx}] {what}: relative L2 error {err:.3e}"
+
+    close(yg.detach(), yc.detach(), "y", 1e-4)
+    close(xg.grad, xc.grad, "dx", 4e-2)
+    for (n, pc), (_, pg) in zip(blk_c.named_parameters(), blk_g.named_parameters()):
+        close(pg.grad, pc.grad, n, 4e-2)
+
+
+@pytest.mark.gpu
 def test_res_uaps_training_steps():
     """Whole UAPS steps on the ResNet-50 encoder variant through the product path (forward_pair, grouped BatchNorm,
     pair loss, HIP Adam): finite, decreasing loss and a finite gradient for every parameter."""

@@ -108,6 +108,7 @@ def set_mode(mode) -> None:
     m = {"h16": 2, "split": 1, "bf16": 1, "exact": 0, "f32": 0}.get(mode, mode)
     _lib.check(_lib.lib().uaps_conv_set_mode(int(m)), "uaps_conv_set_mode")
     _variant_cache.clear()
+    _parts_cache.clear()          # the plan (and with it the statistics layout of the GEMM-tiled 1x1 kernels) depends on the mode
     _mode_name = None
 
 
@@ -525,6 +526,38 @@ class _ConvStrided(torch.autograd.Function):
 def conv2d_strided(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
     """Bias-free F.conv2d(x, weight, None, stride, padding), odd kernel sizes <= 7 (1, 3, 7 for the weight gradient), stride 1 or 2."""
     return _ConvStrided.apply(x, weight, int(stride), int(padding))
+
+
+class _Subsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_device(x, "subsample2")
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+        with _lib.device_guard(x.device):
+            rc = _lib.lib().uaps_subsample2_fwd(x.data_ptr(), y.data_ptr(), B * Cc, H, W, _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_subsample2_fwd")
+        ctx.shape = (B, Cc, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cc, H, W = ctx.shape
+        dyb = bounds.get(dy)
+        dy = dy.contiguous()
+        dx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=dy.device)
+        with _lib.device_guard(dy.device):
+            rc = _lib.lib().uaps_subsample2_bwd(dy.data_ptr(), dx.data_ptr(), B * Cc, H, W, _lib.current_stream(dy.device))
+        _lib.check(rc, "uaps_subsample2_bwd")
+        if dyb is not None:
+            bounds.put(dx, *dyb)
+        return dx
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    """x[:, :, ::2, ::2] (contiguous): what a 1x1 convolution with stride 2 samples (utilities/resnet.py:13-14)."""
+    return bounds.carry(x, _Subsample2.apply(x))
 
 
 class _MaxPool3x3s2(torch.autograd.Function):

@@ -417,6 +417,77 @@ extern "C" int uaps_convs_bwd_weight(const float* dy, const float* x, float* dw,
     return (int)hipGetLastError();
 }
 
+// Every second row and column of `planes` planes (the sampling a 1x1 / stride 2 convolution performs, utilities/resnet.py:13-14,
+// 157-161: layer2's shortcut projection): y [planes, OH, OW] = x[:, ::2, ::2], and its adjoint dx = zeros with dy at the even
+// positions.  The 1x1 convolution itself then runs at stride 1 on the GEMM-tiled kernels (conv_gemm1x1.hpp).
+namespace {
+__global__ __launch_bounds__(256) void subsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long planes, int H, int W,
+                                                             int OH, int OW, int vec) {
+    if (vec) {              // OW % 4 == 0 (so W % 8 == 0 or W == 2 * OW - 1 is excluded by the caller): 8 floats in, 4 out
+        const int q = OW / 4;
+        const long n = planes * OH * q;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+            const int g = (int)(e % q), oy = (int)((e / q) % OH);
+            const long pl = e / ((long)q * OH);
+            const f32x4* src = reinterpret_cast<const f32x4*>(x + (pl * H + 2 * oy) * W + 8 * g);
+            const f32x4 a = src[0], b = src[1];
+            *reinterpret_cast<f32x4*>(y + (pl * OH + oy) * OW + 4 * g) = f32x4{a.x, a.z, b.x, b.z};
+        }
+        return;
+    }
+    const long n = planes * OH * OW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int ox = (int)(e % OW), oy = (int)((e / OW) % OH);
+        const long pl = e / ((long)OW * OH);
+        y[e] = x[(pl * H + 2 * oy) * W + 2 * ox];
+    }
+}
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long planes, int H, int W,
+                                                             int OH, int OW, int vec) {
+    if (vec) {              // W % 8 == 0: 4 floats in, 8 out; odd rows are zero
+        const int q = W / 8;
+        const long n = planes * H * q;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+            const int g = (int)(e % q), iy = (int)((e / q) % H);
+            const long pl = e / ((long)q * H);
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+            if (!(iy & 1)) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (pl * OH + iy / 2) * OW + 4 * g);
+                a = f32x4{v.x, 0.f, v.y, 0.f}; b = f32x4{v.z, 0.f, v.w, 0.f};
+            }
+            f32x4* dst = reinterpret_cast<f32x4*>(dx + (pl * H + iy) * W + 8 * g);
+            dst[0] = a; dst[1] = b;
+        }
+        return;
+    }
+    const long n = planes * H * W;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int ix = (int)(e % W), iy = (int)((e / W) % H);
+        const long pl = e / ((long)W * H);
+        dx[e] = ((ix | iy) & 1) ? 0.f : dy[(pl * OH + iy / 2) * OW + ix / 2];
+    }
+}
+}  // namespace
+
+extern "C" int uaps_subsample2_fwd(const float* x, float* y, long planes, int H, int W, uaps_stream_t stream) {
+    if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int vec = W % 8 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0;
+    const long n = planes * OH * (vec ? OW / 4 : OW);
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipLaunchKernelGGL(subsample2_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, planes, H, W, OH, OW, vec);
+    return (int)hipGetLastError();
+}
+extern "C" int uaps_subsample2_bwd(const float* dy, float* dx, long planes, int H, int W, uaps_stream_t stream) {
+    if (!dy || !dx || planes <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int vec = W % 8 == 0 && ((uintptr_t)dy | (uintptr_t)dx) % 16 == 0;
+    const long n = planes * H * (vec ? W / 8 : W);
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dx, planes, H, W, OH, OW, vec);
+    return (int)hipGetLastError();
+}
+
 // 3x3 / stride 2 / padding 1 max-pool over `planes` = B*C planes of H x W; idx: uint8 [planes, OH, OW] for the backward
 extern "C" int uaps_maxpool3x3s2_fwd(const float* x, float* y, void* idx, long planes, int H, int W, uaps_stream_t stream) {
     if (!x || !y || !idx || planes <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;

@@ -69,6 +69,13 @@ def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, 
         return F.relu(y) if relu else y
     slope = 0.0 if relu else 1.0
     k, d = cv.kernel_size[0], cv.dilation[0]
+    if k == 1 and cv.stride == (2, 2) and cv.padding == (0, 0) and d == 1 and cv.groups == 1 and cv.bias is None:
+        # the strided shortcut projection (resnet.py:157-161) = a stride-1 projection of every second row and column
+        x = conv.subsample2(x)
+        if training:
+            y, st = conv.conv2d_with_stats(x, cv.weight, None)
+            return fused.bn_act(y, None, bn, slope, 0.0, True, st)
+        return fused.bn_act(conv.conv2d(x, cv.weight, None), None, bn, slope, 0.0, False)
     own = cv.stride == (1, 1) and cv.groups == 1 and ((k == 1 and d == 1) or (k == 3 and d in (1, 2, 4) and cv.padding == (d, d))) \
         and not (k == 3 and d > 1 and cv.in_channels <= 4)
     if own and training:
