@@ -13,6 +13,9 @@ DEV = "cuda:0"
 CASES = [
     (2, 3, 64, 96, 96, 7, 2, 3),          # the stem
     (2, 3, 64, 50, 70, 7, 2, 3),          # odd sizes
+    (1, 1, 32, 64, 64, 7, 2, 3),          # grey-scale stem: one input channel (the stem weight-gradient kernel, 49 of 160 columns)
+    (2, 3, 80, 40, 72, 7, 2, 3),          # ... two blocks of output channels, partial tiles
+    (2, 3, 64, 320, 320, 7, 2, 3),
     (2, 128, 128, 40, 40, 3, 2, 1),       # layer2.0.conv2
     (2, 256, 512, 40, 40, 1, 2, 0),       # layer2.0.downsample
     (1, 20, 24, 17, 23, 3, 2, 1),

@@ -229,6 +229,95 @@ __global__ __launch_bounds__(256) void convs_wrw_kernel(SWrwArgs a) {
     }
 }
 
+// ---- weight gradient of the stem: 7x7 / stride 2 / padding 3 with <= 3 input channels (utilities/resnet.py:120) -------------
+// GEMM view: M = output channels, N = (ci, ky, kx) = Cin * 49 <= 147 columns (ten 16-wide tiles), K = output pixels.  The
+// general kernel above pads 3 input channels to a 16-channel block and restages the input for each of the 7 tap rows; here a
+// workgroup stages the 13 x 69 x Cin input patch of a 4 x 32 output tile once, and wave w owns output channels [16w, 16w + 16)
+// with all ten column tiles (40 accumulator registers), so no cross-wave sum is needed.  dy is read exactly once, straight
+// from global memory as 16-byte pieces: lane (j, kq) holds pixels 4kq .. 4kq + 3 of channel j, and MFMA step s contracts
+// pixel 4kq + s of every k-group (the order inside K is free as long as both operands agree), which the B operand follows by
+// reading x[ci][2 oy + ky - 3][2 (4kq + s) + kx - 3] from LDS: per-lane column offsets (10 registers) plus immediates.
+// Partials: slab [split][CoutS][160]; stem7_reduce_kernel sums the splits in a fixed order into dw [Cout][Cin][7][7].
+struct StemWrwArgs {
+    const float* dy; const float* x; float* slab;
+    int B, Cin, Cout, H, W, OH, OW, CoutS, nsplit, tiles_x, tiles_y;
+};
+constexpr int kStemN = 160;
+__global__ __launch_bounds__(256) void stem7_wrw_kernel(StemWrwArgs a) {
+    constexpr int TH = 4, TW = 32, IH = 2 * (TH - 1) + 7, IW = 2 * (TW - 1) + 7, PS = IH * IW, NT = kStemN / 16;
+    __shared__ float sX[3 * PS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kq = lane >> 4;
+    const int split = blockIdx.x, co0 = blockIdx.y * 64 + wave * 16;
+    int off[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + j;
+        const int ci = n / 49, t = n % 49;
+        off[nt] = (n < a.Cin * 49 ? ci * PS + (t / 7) * IW + t % 7 : 0) + 8 * kq;      // columns past Cin * 49 are never written out
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tiles_per_img = a.tiles_x * a.tiles_y, ntiles = a.B * tiles_per_img;
+    const int t_begin = (int)((long)ntiles * split / a.nsplit), t_end = (int)((long)ntiles * (split + 1) / a.nsplit);
+    const int co = co0 + j;
+    const bool co_ok = co < a.Cout;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int b = tile / tiles_per_img, tt = tile % tiles_per_img;
+        const int oy0 = (tt / a.tiles_x) * TH, ox0 = (tt % a.tiles_x) * TW;
+        const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+        __syncthreads();                              // the previous tile's fragments are read
+        for (int e = tid; e < 3 * PS; e += 256) {
+            const int c = e / PS, r = (e % PS) / IW, col = e % IW;
+            const int iy = iy0 + r, ix = ix0 + col;
+            sX[e] = (c < a.Cin && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? a.x[(((size_t)b * a.Cin + c) * a.H + iy) * a.W + ix] : 0.f;
+        }
+        __syncthreads();
+        const float* dyp = a.dy + ((size_t)b * a.Cout + (co_ok ? co : 0)) * a.OH * a.OW;
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+            const int oy = oy0 + r;
+#pragma unroll
+            for (int g = 0; g < TW / 16; ++g) {
+                const int px = ox0 + g * 16 + 4 * kq;          // OW % 4 == 0: the four pixels are all in or all out
+                const f32x4 av = (co_ok && oy < a.OH && px < a.OW) ? *reinterpret_cast<const f32x4*>(dyp + (size_t)oy * a.OW + px)
+                                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], sX[off[nt] + 2 * r * IW + 32 * g + 2 * st], acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // lane (j, kq), register r: output channel co0 + 4 kq + r, column nt * 16 + j
+    float* slab = a.slab + (size_t)split * a.CoutS * kStemN;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(size_t)(co0 + 4 * kq + r) * kStemN + nt * 16 + j] = acc[nt][r];
+}
+// dw[co][n] (n = ci * 49 + tap < Cin * 49) = sum over the splits, in split order: 32 outputs x 8 split groups per workgroup
+__global__ __launch_bounds__(256) void stem7_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout, int CoutS,
+                                                           int ncol) {
+    __shared__ float part[8][32];
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    const bool ok = o < Cout * ncol;
+    const int co = ok ? o / ncol : 0, n = ok ? o % ncol : 0;
+    const int s0 = (int)((long)nsplit * grp / 8), s1 = (int)((long)nsplit * (grp + 1) / 8);
+    float v = 0.f;
+    for (int sp = s0; sp < s1; ++sp) v += slab[((size_t)sp * CoutS + co) * kStemN + n];
+    part[grp][threadIdx.x & 31] = v;
+    __syncthreads();
+    if (grp == 0 && ok) {
+        float t = part[0][threadIdx.x];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += part[g][threadIdx.x];
+        dw[o] = t;
+    }
+}
+
 // ---- 3x3 stride-2 pad-1 max-pool (utilities/resnet.py:124) ------------------------------------------------------------------
 // forward: y and the position (0..8, row-major in the window, first maximum wins like torch) of the arg-max of each window;
 // backward: every input pixel gathers the gradients of the <= 4 windows whose arg-max it is (fixed order, no atomics).
@@ -357,9 +446,21 @@ extern "C" int uaps_convs_bwd_data(const float* dy, const float* wb, float* dx, 
 }
 
 namespace {
-struct SWrwPlan { int CoutS, CinS, ncob, ncib, nsplit, tiles_x, tiles_y; };
-SWrwPlan plan_swrw(int B, int Cin, int Cout, int OH, int OW, int ks) {
+struct SWrwPlan { int CoutS, CinS, ncob, ncib, nsplit, tiles_x, tiles_y; bool stem; };
+SWrwPlan plan_swrw(int B, int Cin, int Cout, int OH, int OW, int ks, int stride = 1, int pad = 0) {
     SWrwPlan p{};
+    // the stem form (stem7_wrw_kernel): 7x7 / 2 / 3, <= 3 input channels, 16-byte rows of dy
+    p.stem = ks == 7 && stride == 2 && pad == 3 && Cin <= 3 && OW % 4 == 0;
+    if (p.stem) {
+        p.ncob = (Cout + 63) / 64; p.ncib = 1;
+        p.CoutS = p.ncob * 64; p.CinS = kStemN;
+        p.tiles_x = (OW + 31) / 32; p.tiles_y = (OH + 3) / 4;
+        const long tiles = (long)B * p.tiles_x * p.tiles_y;
+        long want = 1024 / p.ncob;                    // ~4 workgroups per CU
+        if (want > tiles) want = tiles;
+        p.nsplit = (int)(want < 1 ? 1 : want);
+        return p;
+    }
     p.ncob = (Cout + 15) / 16; p.ncib = (Cin + 15) / 16;
     p.CoutS = p.ncob * 16; p.CinS = p.ncib * 16;
     p.tiles_x = (OW + 31) / 32; p.tiles_y = (OH + 3) / 4;
@@ -376,8 +477,8 @@ extern "C" int uaps_convs_wrw_workspace_bytes(int B, int Cin, int Cout, int H, i
     if (!out) return UAPS_EINVAL;
     int rc = check_sconv(B, Cin, Cout, H, W, ks, stride, pad);
     if (rc) return rc;
-    const SWrwPlan p = plan_swrw(B, Cin, Cout, (H + 2 * pad - ks) / stride + 1, (W + 2 * pad - ks) / stride + 1, ks);
-    *out = (size_t)p.nsplit * ks * ks * p.CoutS * p.CinS * sizeof(float);
+    const SWrwPlan p = plan_swrw(B, Cin, Cout, (H + 2 * pad - ks) / stride + 1, (W + 2 * pad - ks) / stride + 1, ks, stride, pad);
+    *out = (size_t)p.nsplit * (p.stem ? 1 : ks * ks) * p.CoutS * p.CinS * sizeof(float);
     return UAPS_OK;
 }
 
@@ -389,8 +490,18 @@ extern "C" int uaps_convs_bwd_weight(const float* dy, const float* x, float* dw,
     if (rc) return rc;
     if (ks != 1 && ks != 3 && ks != 7) return UAPS_ERANGE;
     const int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
-    const SWrwPlan p = plan_swrw(B, Cin, Cout, OH, OW, ks);
-    if (ws_bytes < (size_t)p.nsplit * ks * ks * p.CoutS * p.CinS * sizeof(float)) return UAPS_EWORKSPACE;
+    const SWrwPlan p = plan_swrw(B, Cin, Cout, OH, OW, ks, stride, pad);
+    if (ws_bytes < (size_t)p.nsplit * (p.stem ? 1 : ks * ks) * p.CoutS * p.CinS * sizeof(float)) return UAPS_EWORKSPACE;
+    if (p.stem && (uintptr_t)dy % 16 == 0) {
+        StemWrwArgs sa{dy, x, (float*)ws, B, Cin, Cout, H, W, OH, OW, p.CoutS, p.nsplit, p.tiles_x, p.tiles_y};
+        UAPS_LAUNCH_MAIN(stem7_wrw_kernel, dim3((unsigned)p.nsplit, (unsigned)p.ncob), dim3(256), 0, (hipStream_t)stream, sa);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return (int)e0;
+        const int nout = Cout * Cin * 49;
+        hipLaunchKernelGGL(stem7_reduce_kernel, dim3((unsigned)((nout + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dw, p.nsplit,
+                           Cout, p.CoutS, Cin * 49);
+        return (int)hipGetLastError();
+    }
     SWrwArgs a{dy, x, (float*)ws, B, Cin, Cout, H, W, OH, OW, ks, stride, pad, p.CoutS, p.CinS, p.ncob, p.ncib, p.nsplit, p.tiles_x, p.tiles_y};
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(p.nsplit * p.ncob * p.ncib), ks == 7 ? 7 : 1);
