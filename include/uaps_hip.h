@@ -149,6 +149,11 @@ int uaps_maxpool3x3s2_bwd(const float* dy, const void* idx, float* dx, long plan
 /* y [planes, OH, OW] = x[:, ::2, ::2] (OH = (H - 1) / 2 + 1) and its adjoint (dx [planes, H, W]: dy at the even positions, zero
  * elsewhere): the sampling of a 1x1 / stride 2 convolution (utilities/resnet.py:13-14, 157-161), which then runs as a
  * stride-1 uaps_conv_fwd on the sampled tensor */
+/* inverse == 0: xs [B, 4, C, H/2, W/2] = the four stride-2 sampling phases of x [B, C, H, W] (xs[b][2 py + px][c][i][j] =
+ * x[b][c][2 i + py][2 j + px]); inverse != 0: the first pointer is xs, the second receives x.  H % 2 == 0, W % 8 == 0, 16-byte
+ * aligned pointers (UAPS_ERANGE otherwise).  A 3x3 / stride 2 / padding 1 convolution (utilities/resnet.py:8-10 with stride 2)
+ * is a stride-1 uaps_conv_fwd over xs with re-arranged weights */
+int uaps_space_to_depth2(const float* x, float* xs, int B, int C, int H, int W, int inverse, uaps_stream_t stream);
 int uaps_subsample2_fwd(const float* x, float* y, long planes, int H, int W, uaps_stream_t stream);
 int uaps_subsample2_bwd(const float* dy, float* dx, long planes, int H, int W, uaps_stream_t stream);
 

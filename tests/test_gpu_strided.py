@@ -87,6 +87,46 @@ def test_subsample2_and_its_adjoint(B, C, H, W):
     assert torch.equal(x.grad, want)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 40, 40), (1, 16, 24, 18, 24), (2, 64, 32, 64, 64), (1, 8, 16, 6, 8)])
+@pytest.mark.parametrize("mode", ["h16", "split", "exact"])
+def test_conv3x3_stride2_over_sampling_phases(B, Cin, Cout, H, W, mode):
+    """layer2.0.conv2 (utilities/resnet.py:8-10 with stride 2): the stride-1 convolution over the four sampling phases
+    (uaps_space_to_depth2 + re-arranged weights) against F.conv2d(stride=2, padding=1) in float64: forward, input and weight
+    gradient; and the phase tensor itself, bit for bit, with its inverse."""
+    from uaps_amd import _lib, bounds, conv
+    x = torch.relu(_mk((B, Cin, H, W), 41))
+    w = _mk((Cout, Cin, 3, 3), 42) / np.sqrt(Cin * 9)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 2, 1)
+    dy = _mk(tuple(yr.shape), 43)
+    yr.backward(dy.double())
+    xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    xs = conv._SpaceToDepth2.apply(xg.detach())
+    want = torch.stack([xg.detach()[:, :, py::2, px::2] for py in (0, 1) for px in (0, 1)], dim=1).reshape(B, 4 * Cin, H // 2, W // 2)
+    assert torch.equal(xs, want)
+    back = torch.empty_like(xg.detach())
+    _lib.check(_lib.lib().uaps_space_to_depth2(xs.data_ptr(), back.data_ptr(), B, Cin, H, W, 1, _lib.current_stream(xs.device)), "inverse")
+    assert torch.equal(back, xg.detach())
+    prev = conv.get_mode()
+    conv.set_mode(mode)
+    try:
+        y, st = conv.conv3x3s2(bounds.put(xg, bounds.from_value(xg.detach().abs().max()), 1.0), wg, with_stats=True)
+        dyg = dy.to(DEV)
+        y.backward(bounds.put(dyg, bounds.from_value(dyg.abs().max()), 1.0))
+    finally:
+        conv.set_mode(prev)
+
+    def close(a, ref, what):
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((a.detach().cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+    close(y, yr.detach(), "y")
+    close(xg.grad, xr.grad, "dx")
+    close(wg.grad, wr.grad, "dw")
+    np.testing.assert_allclose(st[..., 0].double().sum((1, 2)).cpu().numpy(), yr.detach().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
 def test_no_library_convolution_or_pooling_on_the_resnet_path():
     """The ResNet-50 encoder on the GPU must not call F.conv2d / max-pool: run its forward + backward under a profiler-free
     check -- torch's convolution and pooling entry points are patched to raise."""

@@ -94,6 +94,7 @@ SIGNATURES = {
     "uaps_convs_bwd_weight": (C.c_int, [_PTR] * 3 + [C.c_int] * 8 + [_PTR, C.c_size_t, _PTR]),
     "uaps_maxpool3x3s2_fwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, C.c_int, C.c_int, _PTR]),
     "uaps_maxpool3x3s2_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, C.c_int, C.c_int, _PTR]),
+    "uaps_space_to_depth2": (C.c_int, [_PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _PTR]),
     "uaps_subsample2_fwd": (C.c_int, [_PTR, _PTR, C.c_long, C.c_int, C.c_int, _PTR]),
     "uaps_subsample2_bwd": (C.c_int, [_PTR, _PTR, C.c_long, C.c_int, C.c_int, _PTR]),
     "uaps_sum_tensors": (C.c_int, [_PTR, C.c_int, _PTR, C.c_long, _PTR]),

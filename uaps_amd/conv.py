@@ -560,6 +560,68 @@ def subsample2(x: torch.Tensor) -> torch.Tensor:
     return bounds.carry(x, _Subsample2.apply(x))
 
 
+class _SpaceToDepth2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_device(x, "space_to_depth2")
+        x = x.contiguous()
+        B, Cc, H, W = x.shape
+        xs = torch.empty((B, 4 * Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        with _lib.device_guard(x.device):
+            rc = _lib.lib().uaps_space_to_depth2(x.data_ptr(), xs.data_ptr(), B, Cc, H, W, 0, _lib.current_stream(x.device))
+        _lib.check(rc, "uaps_space_to_depth2")
+        ctx.shape = (B, Cc, H, W)
+        return xs
+
+    @staticmethod
+    def backward(ctx, dxs):
+        B, Cc, H, W = ctx.shape
+        b = bounds.get(dxs)
+        dxs = dxs.contiguous()
+        dx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=dxs.device)
+        with _lib.device_guard(dxs.device):
+            rc = _lib.lib().uaps_space_to_depth2(dxs.data_ptr(), dx.data_ptr(), B, Cc, H, W, 1, _lib.current_stream(dxs.device))
+        _lib.check(rc, "uaps_space_to_depth2")
+        if b is not None:
+            bounds.put(dx, *b)
+        return dx
+
+
+_S2D_INDEX = {}
+
+
+def _s2d_index(dev):
+    """[4 phases, 9 taps] -> index into the 9 taps of the stride-2 kernel, 9 = the appended zero: along one axis the stride-2 tap
+    k = 0, 1, 2 reads sampling phase (1, 0, 1) at stride-1 tap (0, 1, 1) (x[2 i + k - 1] = phase_1[i - 1], phase_0[i], phase_1[i])."""
+    idx = _S2D_INDEX.get(dev)
+    if idx is None:
+        t = torch.full((2, 2, 3, 3), 9, dtype=torch.long)
+        ph, tap = (1, 0, 1), (0, 1, 1)
+        for ky in range(3):
+            for kx in range(3):
+                t[ph[ky], ph[kx], tap[ky], tap[kx]] = ky * 3 + kx
+        idx = _S2D_INDEX[dev] = t.reshape(36).to(dev)
+    return idx
+
+
+def conv3x3s2_supported(x: torch.Tensor) -> bool:
+    return x.is_cuda and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0
+
+
+def conv3x3s2(x: torch.Tensor, weight: torch.Tensor, with_stats: bool = False):
+    """F.conv2d(x, weight, None, stride=2, padding=1) for a 3x3 kernel (utilities/resnet.py:8-10, layer2.0.conv2) as a stride-1
+    3x3 convolution over the four sampling phases of x stacked as channels (uaps_space_to_depth2) with the 9 taps scattered
+    into a [Cout, 4 Cin, 3, 3] kernel: the same products and, per output, the same sums plus exact zeros -- on the split
+    kernels of the stride-1 path, with their BatchNorm statistics epilogue.  H even, W % 8 == 0."""
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    xs = bounds.carry(x, _SpaceToDepth2.apply(x))
+    w9 = torch.cat([weight.reshape(Cout, Cin, 9), weight.new_zeros(Cout, Cin, 1)], dim=2)
+    wq = w9.index_select(2, _s2d_index(weight.device)).reshape(Cout, Cin, 4, 9).permute(0, 2, 1, 3).reshape(Cout, 4 * Cin, 3, 3)
+    if with_stats:
+        return conv2d_with_stats(xs, wq, None)
+    return conv2d(xs, wq, None)
+
+
 class _MaxPool3x3s2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -580,6 +580,45 @@ __global__ __launch_bounds__(256) void subsample2_bwd_kernel(const float* __rest
 }
 }  // namespace
 
+// x [B, C, H, W] <-> xs [B, 4, C, H/2, W/2] with xs[b][2 py + px][c][i][j] = x[b][c][2 i + py][2 j + px] (H, W even): the four
+// sampling phases of a stride-2 convolution as extra channels.  A 3x3 / 2 / padding-1 convolution of x is a 3x3 / 1 /
+// padding-1 convolution of xs whose weights hold the 9 taps at (phase, tap) = (1, 0), (0, 1), (1, 1) per axis for
+// ky / kx = 0, 1, 2 and zeros elsewhere (uaps_amd/conv.py: conv3x3s2), which runs on the split kernels.
+namespace {
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void space_depth2_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W) {
+    const int q = W / 8, OH = H / 2, OW = W / 2;
+    const long n = (long)B * C * H * q;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const int g = (int)(e % q), iy = (int)((e / q) % H);
+        const long bc = e / ((long)q * H);
+        const int c = (int)(bc % C);
+        const long b = bc / C;
+        const size_t full = ((size_t)bc * H + iy) * W + 8 * g;
+        const size_t ph0 = ((((size_t)b * 4 + 2 * (iy & 1)) * C + c) * OH + iy / 2) * OW + 4 * g, ph1 = ph0 + (size_t)C * OH * OW;
+        if constexpr (!INVERSE) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(src + full), v = *reinterpret_cast<const f32x4*>(src + full + 4);
+            *reinterpret_cast<f32x4*>(dst + ph0) = f32x4{u.x, u.z, v.x, v.z};
+            *reinterpret_cast<f32x4*>(dst + ph1) = f32x4{u.y, u.w, v.y, v.w};
+        } else {
+            const f32x4 e0 = *reinterpret_cast<const f32x4*>(src + ph0), o0 = *reinterpret_cast<const f32x4*>(src + ph1);
+            *reinterpret_cast<f32x4*>(dst + full) = f32x4{e0.x, o0.x, e0.y, o0.y};
+            *reinterpret_cast<f32x4*>(dst + full + 4) = f32x4{e0.z, o0.z, e0.w, o0.w};
+        }
+    }
+}
+}  // namespace
+
+extern "C" int uaps_space_to_depth2(const float* x, float* xs, int B, int C, int H, int W, int inverse, uaps_stream_t stream) {
+    if (!x || !xs || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (H % 2 || W % 8 || ((uintptr_t)x | (uintptr_t)xs) % 16) return UAPS_ERANGE;
+    const long n = (long)B * C * H * (W / 8);
+    const int blocks = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    if (inverse) hipLaunchKernelGGL(space_depth2_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, B, C, H, W);
+    else hipLaunchKernelGGL(space_depth2_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xs, B, C, H, W);
+    return (int)hipGetLastError();
+}
+
 extern "C" int uaps_subsample2_fwd(const float* x, float* y, long planes, int H, int W, uaps_stream_t stream) {
     if (!x || !y || planes <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;

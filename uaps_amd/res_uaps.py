@@ -76,6 +76,12 @@ def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, 
             y, st = conv.conv2d_with_stats(x, cv.weight, None)
             return fused.bn_act(y, None, bn, slope, 0.0, True, st)
         return fused.bn_act(conv.conv2d(x, cv.weight, None), None, bn, slope, 0.0, False)
+    if k == 3 and cv.stride == (2, 2) and cv.padding == (1, 1) and d == 1 and cv.groups == 1 and cv.bias is None and conv.conv3x3s2_supported(x):
+        # the strided 3x3 of layer2.0 (resnet.py:147 via 8-10): stride 1 over the four sampling phases
+        if training:
+            y, st = conv.conv3x3s2(x, cv.weight, with_stats=True)
+            return fused.bn_act(y, None, bn, slope, 0.0, True, st)
+        return fused.bn_act(conv.conv3x3s2(x, cv.weight), None, bn, slope, 0.0, False)
     own = cv.stride == (1, 1) and cv.groups == 1 and ((k == 1 and d == 1) or (k == 3 and d in (1, 2, 4) and cv.padding == (d, d))) \
         and not (k == 3 and d > 1 and cv.in_channels <= 4)
     if own and training:
