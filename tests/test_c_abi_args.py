@@ -117,3 +117,44 @@ def test_tensors_of_two_gib_or_more_are_refused_before_any_launch(L):
     assert L.uaps_conv_bwd_data(fake, fake, fake, *big, 3, 0, None) == ERANGE
     assert L.uaps_conv_bwd_weight_partial(fake, fake, 0, *big, 3, 0, fake, 1 << 40, None) == ERANGE
     assert L.uaps_conv_fwd(fake, fake, None, fake, 1, 16, 16, 64, 64, 5, 0, None) == ERANGE      # 5x5 does not exist
+
+
+def test_process_wide_switches_and_the_round3_plans(L):
+    """uaps_conv_set_tuning / uaps_set_error_word (the library reads no environment itself), and the plans added for the
+    ResNet-50 configuration: GEMM-tiled 1x1 kernels, dilated split kernels, the stem weight gradient's workspace, the
+    sampling-phase helpers."""
+    import re, os
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "uaps_hip.h")).read()
+    tune = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(UAPS_TUNE_\w+)\s+\(?(\d+)u?\)?", hdr)}
+    assert tune["UAPS_TUNE_NO_SPLIT_FWD"] == 1 and tune["UAPS_TUNE_NO_SPLIT_WRW"] == 2 and len(tune) == 6
+    L.uaps_conv_get_tuning.restype = C.c_uint
+    buf, parts, n = C.create_string_buffer(96), C.c_int(), C.c_size_t()
+    prev_mode, prev_tune = L.uaps_conv_get_mode(), L.uaps_conv_get_tuning()
+    try:
+        assert L.uaps_conv_set_mode(1) == OK and L.uaps_conv_set_tuning(0) == OK
+        wide = (16, 256, 64, 160, 160, 1, 0)                                             # layer1's 1x1 reduction at configs[4]'s shape
+        assert L.uaps_conv_fwd_variant(*wide, buf, 96) == OK and buf.value.decode() == "conv_g1s_kernel<64>"
+        assert L.uaps_conv_fwd_stats_parts(*wide, C.byref(parts)) == OK and parts.value == 160 * 160 // 128
+        assert L.uaps_conv_wrw_variant(*wide, buf, 96) == OK and buf.value.decode() == "conv_gw1s_kernel"
+        assert L.uaps_conv_fwd_variant(16, 512, 512, 80, 80, 3, 4 << 24, buf, 96) == OK and buf.value.decode() == "conv_s32d_kernel<64, 4>"
+        assert L.uaps_conv_set_tuning(tune["UAPS_TUNE_NO_SPLIT_FWD"] | tune["UAPS_TUNE_NO_SPLIT_WRW"]) == OK
+        assert L.uaps_conv_get_tuning() == 3
+        assert L.uaps_conv_fwd_variant(*wide, buf, 96) == OK and buf.value.decode().startswith("conv_fwd_kernel<1,")
+        assert L.uaps_conv_fwd_stats_parts(*wide, C.byref(parts)) == OK and parts.value == 20 * 5      # 8 x 32 pixel tiles again
+        assert L.uaps_conv_wrw_variant(*wide, buf, 96) == OK and buf.value.decode().startswith("conv_wrw_kernel<1,")
+        assert L.uaps_conv_fwd_variant(16, 512, 512, 80, 80, 3, 4 << 24, buf, 96) == OK and buf.value.decode().endswith(", 4>") \
+            and buf.value.decode().startswith("conv_fwd_kernel<3,")
+    finally:
+        L.uaps_conv_set_mode(prev_mode)
+        L.uaps_conv_set_tuning(prev_tune)
+    assert L.uaps_set_error_word(C.c_void_p(2)) == EINVAL                                # a 4-byte word
+    assert L.uaps_set_error_word(None) == OK                                             # detaches (nothing is reported)
+    # the stem weight gradient (7x7 / 2 / 3, <= 3 input channels, OW % 4 == 0): 1024 splits of [64 channels][160 columns]
+    assert L.uaps_convs_wrw_workspace_bytes(16, 3, 64, 640, 640, 7, 2, 3, C.byref(n)) == OK and n.value == 1024 * 64 * 160 * 4
+    assert L.uaps_convs_wrw_workspace_bytes(2, 3, 64, 50, 70, 7, 2, 3, C.byref(n)) == OK and n.value % (49 * 64 * 16 * 4) == 0      # odd width: the general kernel's slabs
+    fake = C.c_void_p(1 << 20)
+    assert L.uaps_space_to_depth2(None, fake, 1, 8, 8, 8, 0, None) == EINVAL
+    assert L.uaps_space_to_depth2(fake, fake, 1, 8, 7, 8, 0, None) == ERANGE             # odd height
+    assert L.uaps_space_to_depth2(fake, fake, 1, 8, 8, 12, 1, None) == ERANGE            # rows of 8-float groups
+    assert L.uaps_subsample2_fwd(None, fake, 4, 8, 8, None) == EINVAL and L.uaps_subsample2_bwd(fake, None, 4, 8, 8, None) == EINVAL
+    assert L.uaps_subsample2_fwd(fake, fake, 0, 8, 8, None) == EINVAL

@@ -118,3 +118,39 @@ def test_validation_and_training_metrics_average_per_batch_like_the_reference():
     em = tr.epoch_metrics()
     ref = uaps_amd.mean_batch_metrics(cms)
     assert all((np.isnan(em[k]) and np.isnan(ref[k])) or em[k] == ref[k] for k in em) and tr._cms == []
+
+
+def test_fit_runs_the_epoch_loop_on_the_device_and_resumes(tmp_path):
+    """UAPSTrainer.fit with the real device work (UAPS_train.py:279-450): 2 epochs of 3 steps on a small net, validation,
+    best-checkpoint saving; then a second trainer resumes from the checkpoint and continues with the same iteration count,
+    scheduler epoch and mixing-weight stream, and its first resumed step equals the uninterrupted run's step bit for bit
+    when the model state is the checkpointed one."""
+    import os
+    import uaps_amd
+    g = torch.Generator().manual_seed(5)
+
+    def loader(n, seed_off):
+        return [(torch.randn(2, 3, 64, 64, generator=g).to(DEV), torch.randint(0, 4, (2, 64, 64), generator=g).to(DEV)) for _ in range(n)]
+
+    lab, unl, val = loader(2, 0), loader(3, 1), loader(2, 2)
+    torch.manual_seed(3)
+    model = uaps_amd.UNet_UAPS(3, 4, feature_chns=[16, 32, 32, 32, 32]).to(DEV)
+    tr = uaps_amd.UAPSTrainer(model, base_lr=1e-3)
+    path = os.path.join(tmp_path, "ck", "UAPS.pth")
+    seen = []
+    hist = tr.fit(lab, unl, val, epochs=3, iter_per_epoch=4, checkpoint_path=path, log=seen.append)
+    assert [h["epoch"] for h in hist] == [1, 2] and tr.iter_num == 6 and seen == hist
+    assert all(np.isfinite(h[k]) for h in hist for k in ("loss", "sup", "unsup", "val_mdice", "val_loss", "train_mdice"))
+    assert hist[0]["saved"] and os.path.exists(path)                          # the first validation beats best_dice = 0
+    ck = torch.load(path, weights_only=False)
+    assert ck["epoch"] in (1, 2) and ck["iter_num"] == 3 * ck["epoch"] and ck["best_dice_1"] == max(h["val_mdice"] for h in hist[:ck["epoch"]])
+    # resume
+    model2 = uaps_amd.UNet_UAPS(3, 4, feature_chns=[16, 32, 32, 32, 32]).to(DEV)
+    tr2 = uaps_amd.UAPSTrainer(model2, base_lr=1e-3)
+    got = tr2.load_checkpoint(path)
+    assert tr2.iter_num == ck["iter_num"] and tr2.scheduler.last_epoch == ck["epoch"]
+    for (k1, v1), (k2, v2) in zip(ck["state_dict"].items(), model2.state_dict().items()):
+        assert k1 == "module." + k2 and torch.equal(v1.to(DEV), v2)
+    h2 = tr2.fit(lab, unl, val, epochs=ck["epoch"] + 2, iter_per_epoch=4, start_epoch=got["epoch"] + 1, best_dice=got["best_dice_1"])
+    assert [h["epoch"] for h in h2] == [ck["epoch"] + 1] and tr2.iter_num == ck["iter_num"] + 3
+    assert all(np.isfinite(h2[0][k]) for k in ("loss", "val_mdice"))
