@@ -357,7 +357,10 @@ def main():
                 torch.cuda.synchronize()
                 per_bucket.append({"bucket": name, "bytes": flat.numel() * 4, "allreduce_ms": round(e0.elapsed_time(e1) / 5, 4)})
             kept, trainer.buckets = trainer.buckets, None
+            kept.muted = True                                # the post-accumulate hooks stay registered: they must neither count nor launch
             nocomm_ms = eager_leg(args.exact_steps)          # replicas drift apart from here on: nothing below compares ranks
+            kept.muted = False
+            kept.reset()
             trainer.buckets = kept
             comm = {"backend": backend, "buckets": per_bucket, "bytes_per_step": sum(p["bytes"] for p in per_bucket),
                     "eager_step_ms": round(eager_ms, 3), "eager_step_without_exchange_ms": round(nocomm_ms, 3),

@@ -181,6 +181,32 @@ def test_bench_two_ranks_one_line(tmp_path):
     assert abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3)) / out["value"] < 0.02
 
 
+def test_bench_four_ranks_at_the_metric_batch(tmp_path):
+    """`bench.py --gpus 4` as the driver launches it, at the metric's own per-GPU batch (16 + 16 images of 256 x 256, the full
+    net): four ranks time-share this box's card, gloo carries the collectives.  The line must report all four ranks
+    (`ranks_seen`), the whole-job rate, the bucket exchange (`comm`: 3 buckets, 14.9 MB of gradients) and finite losses."""
+    import json
+    import subprocess
+    env = dict(os.environ, UAPS_BENCH_BACKEND="gloo", UAPS_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "2",
+           "--analysis-steps", "1", "--exact-steps", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["ranks_seen"] == 4 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp4" and np.isfinite(out["config"]["final_loss"])
+    per_step = 4 * (16 + 16)
+    assert abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3)) / out["value"] < 0.02
+    comm = out["comm"]
+    assert len(comm["buckets"]) >= 3 and abs(sum(b["bytes"] for b in comm["buckets"]) - 4 * 3713952) < 4 * 4096
+    assert all(b["allreduce_ms"] > 0 for b in comm["buckets"]) and np.isfinite(comm["exposed_ms"])
+
+
 def _graph_worker(rank, world, port, out_dir, use_graph, steps):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

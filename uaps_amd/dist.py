@@ -84,6 +84,7 @@ class GradBuckets:
                 _graddest.register(p, flat, o)
         self._hooks = []
         self.defer = False
+        self.muted = False                     # hooks do nothing (a caller that steps without any exchange: bench.py's no-exchange leg)
         if self.world > 1 and overlap:
             for bi, params in enumerate(self.buckets):
                 for p in params:
@@ -98,7 +99,7 @@ class GradBuckets:
 
     def _make_hook(self, bi: int):
         def hook(_param):
-            if self.defer:                     # captured backward (graph.StepGraph): the exchange is launched by finish(), after the replay
+            if self.defer or self.muted:       # captured backward (graph.StepGraph): the exchange is launched by finish(), after the replay
                 return
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
