@@ -81,6 +81,8 @@ class _timed:
                     self.name = ("conv_hp16_bn_kernel" if "_bn_" in self.name else "conv_hp16_kernel") + ("<2>" if kin <= 16 else "<4>")
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
+                if self.name.startswith("conv_hwrw") and "_kernel<4, 1, " in self.name and H >= 8 and not (_lib.lib().uaps_conv_get_tuning() & 32):
+                    self.name = self.name.replace("_kernel<4, 1, ", "_kernel<8, 1, ")      # 16 output channels: the 8-row tiles (csrc/conv_wrw.hip: launch_swrw)
                 if self.name.startswith("conv_wrw_kernel<3, 4, 32, 2, 2, 4, ") and not self.name.endswith(" 1>") and W >= 32 and Cin >= 16:
                     self.name = "conv_hwrw_d_kernel<4, 2, 2, " + self.name.split(",")[-1].strip()      # the dilated fp16 form (csrc/conv_wrw.hip)
             self.on = EVENT_FILTER is None or self.name in EVENT_FILTER
