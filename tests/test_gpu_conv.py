@@ -50,6 +50,9 @@ SHAPES = [
     (1, 512, 128, 32, 48, 1),
     (2, 200, 136, 32, 32, 1),   # channel counts that are no multiples of the block sizes (stays on the 3x3-style tiling: CoutP % 64)
     (1, 1024, 256, 40, 40, 1),
+    # 32-channel blocks on 16-row tiles (csrc/conv_split.hpp, MR = 4): >= 512 tiles of 16 x 32 pixels, ragged in both directions
+    (5, 24, 32, 200, 264, 3),
+    (4, 32, 32, 256, 256, 3),
 ]
 
 
@@ -138,7 +141,8 @@ def test_conv_refuses_cpu_tensors():
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16),
-                                            (4, 32, 32, 256, 256), (4, 16, 64, 252, 256)])          # the last two: persistent slice kernels
+                                            (4, 32, 32, 256, 256), (4, 16, 64, 252, 256),           # these two: persistent slice kernels
+                                            (6, 24, 32, 200, 264)])          # 32-channel block on 16-row tiles, the last one half outside: parts stay per 8 rows
 def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
     """conv2d_with_stats: the per-tile (sum, sum of squares) written by the conv epilogue must add up to the
     statistics of y, and bn_act fed with them must equal bn_act running its own statistics pass."""

@@ -100,7 +100,8 @@ def test_bn_act_dropout_consistency(shape, p):
     assert torch.equal(out2 != 0, out != 0)
 
 
-@pytest.mark.parametrize("B,Cs,Cl,h,w", [(2, 4, 4, 5, 6), (16, 16, 16, 128, 128), (3, 7, 5, 1, 1), (2, 8, 8, 2, 3), (4, 128, 128, 16, 16)])
+@pytest.mark.parametrize("B,Cs,Cl,h,w", [(2, 4, 4, 5, 6), (16, 16, 16, 128, 128), (3, 7, 5, 1, 1), (2, 8, 8, 2, 3), (4, 128, 128, 16, 16),
+                                         (1, 2, 3, 40, 36), (2, 1, 2, 70, 64)])
 def test_up_cat_vs_torch(B, Cs, Cl, h, w):
     from uaps_amd import fused
     torch.manual_seed(4)
@@ -117,7 +118,7 @@ def test_up_cat_vs_torch(B, Cs, Cl, h, w):
 
 
 @pytest.mark.parametrize("B,Cl,h,w", [(2, 4, 5, 6), (32, 16, 128, 128), (3, 5, 1, 1), (2, 8, 2, 3), (4, 128, 16, 16), (2, 3, 24, 40),
-                                      (1, 2, 9, 34), (2, 2, 33, 18), (1, 1, 1, 2)])
+                                      (1, 2, 9, 34), (2, 2, 33, 18), (1, 1, 1, 2), (1, 3, 40, 36), (2, 2, 70, 64)])
 def test_upsample2x_vs_torch_and_gather_kernel(B, Cl, h, w):
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (UAPS_unet.py:74-75) as the LDS-tiled kernel
     (W % 4 == 0) or the gather kernel, against torch and -- bit for bit -- against the up_cat kernel's interpolation."""

@@ -61,7 +61,7 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
         name = buf.value.decode()
         if kind.endswith("_bn"):      # the variants that apply BatchNorm + LeakyReLU while staging (fused._BnActConv)
             name = (name.replace("conv_fwd_kernel", "conv_fwd_bn_kernel").replace("conv_wrw_kernel", "conv_wrw_bn_kernel")
-                    .replace("conv_sfwd_kernel", "conv_sfwd_bn_kernel").replace("conv_s32_kernel", "conv_s32_bn_kernel").replace("conv_swrw_kernel", "conv_swrw_bn_kernel")
+                    .replace("conv_sfwd_kernel", "conv_sfwd_bn_kernel").replace("conv_s32_kernel", "conv_s32_bn_kernel").replace("conv_s32t_kernel", "conv_s32t_bn_kernel").replace("conv_swrw_kernel", "conv_swrw_bn_kernel")
                     .replace("conv_small_kernel", "conv_small_bn_kernel").replace("conv_small_wrw_kernel", "conv_small_wrw_bn_kernel"))
         _variant_cache[key] = name
     return name

@@ -165,10 +165,28 @@ int launch_s32(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// 16-row tiles, 32 output channels per workgroup (conv_s32t/h32t kernels)
+int launch_s32t(ConvFwdArgs a, hipStream_t s) {
+    a.tiles_x = (a.W + 31) / 32;
+    a.tiles_y = (a.H + 15) / 16;
+    a.nblk = a.CoutP / 32;
+    const long grid = ((long)a.B * a.tiles_x * a.tiles_y * a.nblk + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    if (a.wscale) {
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_h32t_bn_kernel<32>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_h32t_kernel<32>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        return (int)hipGetLastError();
+    }
+    if (a.xf) UAPS_LAUNCH_MAIN((conv_s32t_bn_kernel<32>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    else UAPS_LAUNCH_MAIN((conv_s32t_kernel<32>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 // split: one of the bf16-split kernels runs; s32: the 32x32x16 form (3x3, 8x32 tiles, >= 32 output channels)
 // small: 1 = the exact-N VALU kernel for <= 4 output channels (conv_small.hpp)
 // g1: the GEMM-tiled 1x1 kernels of conv_gemm1x1.hpp (128 consecutive pixels x 128 / 64 output channels per workgroup)
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; bool g1; };
+// s32t: 16-row tiles for the 32-channel blocks (the statistics parts stay per 8 rows)
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; bool g1, s32t; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
@@ -218,6 +236,10 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
         p->sck = 8;
         p->sbn = (p->CoutP % 64 == 0 && tiles * (p->CoutP / 64) >= 512) ? 64 : 32;
         if (bn_req == 32 || (bn_req == 64 && p->CoutP % 64 == 0)) p->sbn = bn_req;
+        // 32-channel blocks: 16-row tiles while that still gives every CU two workgroups (cfg bit 23 keeps the 8-row tiles)
+        const long tiles16 = (long)B * ((H + 15) / 16) * ((W + 31) / 32);
+        p->s32t = p->sbn == 32 && p->dil == 1 && !(cfg & (1 << 23)) && !(g_conv_tuning & UAPS_TUNE_NO_TALL_FWD) &&
+                  tiles16 * (p->CoutP / 32) >= 512;
     } else if (p->split && bn_req) {
         if ((bn_req != 16 && bn_req != 32) || p->CoutP % bn_req) return UAPS_EINVAL;
         p->sbn = bn_req;
@@ -291,6 +313,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             }
         }
         if (p.dil > 1) return p.sbn == 64 ? launch_s32d<64>(a, p.dil, s) : launch_s32d<32>(a, p.dil, s);
+        if (p.s32 && p.s32t) return launch_s32t(a, s);
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
         if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
@@ -426,6 +449,7 @@ extern "C" int uaps_conv_fwd_variant(int B, int Cin, int Cout, int H, int W, int
     if (p.small) snprintf(buf, buflen, "conv_small_kernel<8, 4>");
     else if (p.g1) snprintf(buf, buflen, "conv_g1s_kernel<%d>", p.CoutP % 128 == 0 ? 128 : 64);
     else if (p.s32 && p.dil > 1) snprintf(buf, buflen, "conv_s32d_kernel<%d, %d>", p.sbn, p.dil);
+    else if (p.s32 && p.s32t) snprintf(buf, buflen, "conv_s32t_kernel<32>");
     else if (p.s32) snprintf(buf, buflen, "conv_s32_kernel<%d>", p.sbn);
     else if (p.split) snprintf(buf, buflen, "conv_sfwd_kernel<%d, %d, %d, %d, %d>", ks, p.th, p.tw, p.sbn, p.sck);
     else snprintf(buf, buflen, "conv_fwd_kernel<%d, %d, %d, %d, %d, %d, %d>", ks, p.th, p.tw, p.bn, p.ck, p.vec ? 4 : 1, p.dil);

@@ -373,10 +373,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // DIL = dilation of the 3x3 kernel with padding = DIL (the dilated stages of utilities/resnet.py:8-10, 201-203; round 3): the
 // halo is DIL rows and DIL <= 4 columns inside the 4-float margin, a tap is DIL pixels away.
-template <int BN, bool XF, bool H16 = false, int DIL = 1>
+// MR = output rows per wave (2, or 4 = 16-row tiles for the 32-channel layers, round 3: half the workgroups, twice the matrix
+// work per staged weight fragment and per barrier; the BatchNorm statistics are still written per 8-row half).
+template <int BN, bool XF, bool H16 = false, int DIL = 1, int MR = 2>
 __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     constexpr int NP = H16 ? 2 : 3;                   // pieces per operand: three bf16 (six products) or two fp16 (three products)
-    constexpr int TH = 8, TW = 32, IH = TH + 2 * DIL, IW = TW + 8, PLANE = IH * IW, XS = 4 - DIL;     // rows start 4 floats left of the tile
+    constexpr int TH = 4 * MR, TW = 32, IH = TH + 2 * DIL, IW = TW + 8, PLANE = IH * IW, XS = 4 - DIL;     // rows start 4 floats left of the tile
     constexpr int NQ = 9, NKS = 5, NQP = 2 * NKS;
     constexpr int NT = BN / 32;                       // 32-channel N tiles per wave (every wave covers all BN channels)
     constexpr int NHU = IH * (IW / 2);                // staging half-units: 2 consecutive pixels x 8 channels
@@ -442,7 +444,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 
     f32x2 rin[NHT][8];
     u32x4 rw[NWT];
-    f32x2 rxf[XF ? 8 : 1];
+    f32x2 rxf[XF ? NHT : 1][XF ? 8 : 1];
     u32x4 pk[NHT][NP][2];
 
     auto load_chunk = [&](int ci0) {
@@ -455,23 +457,24 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 rin[t][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, uin[t] ? (int)(ugoff[t] + (uint32_t)c * HW4) : (int)kOob, 0, 0));
-        if constexpr (XF) {                           // (staging-time BatchNorm: one half-unit per thread, i.e. no dilation 4)
+        if constexpr (XF) {                           // (scale, shift) of the chunk's channels; zeros for a half-unit outside the image
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                    rs_xf, uin[0] ? (int)((uint32_t)(ci0 + c) * 8u) : (int)kOob, 0, 0));
+            for (int t = 0; t < NHT; ++t)
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    rxf[t][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        rs_xf, uin[t] ? (int)((uint32_t)(ci0 + c) * 8u) : (int)kOob, 0, 0));
         }
         const uint32_t wbase = (uint32_t)(ci0 / 8) * a.CoutP * 16u;
 #pragma unroll
         for (int n = 0; n < NWT; ++n)
             rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wgoff[n] == kOob ? kOob : wgoff[n] + wbase), 0, 0));
     };
-    static_assert(!XF || NHT == 1, "the staging-time BatchNorm form keeps one half-unit per thread");
     auto split_pair_t = [&](int t, int idx) {        // channel pair c2 of pixel p of this thread's half-unit t
         const int p = idx / 4, c2 = idx % 4;
         float v0 = rin[t][2 * c2][p], v1 = rin[t][2 * c2 + 1][p];
         if constexpr (XF) {
-            const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
+            const float z0 = __builtin_fmaf(v0, rxf[t][2 * c2].x, rxf[t][2 * c2].y), z1 = __builtin_fmaf(v1, rxf[t][2 * c2 + 1].x, rxf[t][2 * c2 + 1].y);
             v0 = __builtin_fmaxf(z0, z0 * a.xf_slope); v1 = __builtin_fmaxf(z1, z1 * a.xf_slope);
         }
         if constexpr (H16) {
@@ -485,10 +488,12 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         }
     };
     auto split_pair = [&](int idx) { split_pair_t(0, idx); };
+    constexpr int NU = NKS * MR;                      // units (k-step, row) of 6 * NT MFMAs
+    constexpr bool SPLIT_IN_LOOP = NHT == 2 && NU >= 18;      // both half-units are split behind the matrix units of the previous chunk
     auto store_chunk = [&]() {
 #pragma unroll
         for (int t = 0; t < NHT; ++t) {
-            if constexpr (NHT > 1) {                  // (the second half-unit is split here, between the barriers)
+            if constexpr (NHT > 1 && !SPLIT_IN_LOOP) {      // (the second half-unit is split here, between the barriers)
                 if (t > 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) split_pair_t(t, i);
@@ -507,18 +512,18 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             if (wloff[n] >= 0) sW[wloff[n]] = rw[n];
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MR][NT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
     // A: lane (pixel r, half h) of the wave's row m reads unit abase[m] + kstep[ks]; k-group q = 2 ks + h is tap q
-    int abase[2];
+    int abase[MR];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) abase[m] = (wave * 2 + m) * IW + r + XS;
+    for (int m = 0; m < MR; ++m) abase[m] = (wave * MR + m) * IW + r + XS;
     int kstep[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -527,11 +532,14 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     }
     const int boff = h * BN + r;
 
-    constexpr int NU = NKS * 2;                       // units (k-step, row) of 6 * NT MFMAs
     const int nchunks = (a.Cin + 7) / 8;
     load_chunk(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) split_pair(i);
+    if constexpr (SPLIT_IN_LOOP) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split_pair_t(1, i);
+    }
     store_chunk();
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -540,7 +548,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         bf16x8 af[2][NP], bfr[2][NT][NP];
         auto read_a = [&](int u, bf16x8 (&dst)[NP]) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * PLANE + abase[u % 2] + kstep[u / 2]]);
+            for (int p = 0; p < NP; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * PLANE + abase[u % MR] + kstep[u / MR]]);
         };
         auto read_b = [&](int ks, bf16x8 (&dst)[NT][NP]) {
 #pragma unroll
@@ -552,8 +560,8 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         read_a(0, af[0]);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int ks = u / 2, m = u % 2;
-            const bool new_b = u + 1 < NU && (u + 1) % 2 == 0;
+            const int ks = u / MR, m = u % MR;
+            const bool new_b = u + 1 < NU && (u + 1) % MR == 0;
             if (u + 1 < NU) read_a(u + 1, af[(u + 1) & 1]);
             if (new_b) read_b(ks + 1, bfr[(ks + 1) & 1]);
 #pragma unroll
@@ -577,7 +585,8 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, NP + NP * NT, 0);
             else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, (H16 ? 3 : 6) * NT, 0);
-            if (u >= 2) split_pair(u - 2);            // the next chunk's 8 channel pairs, one per unit behind the first k-step
+            if (u >= 2 && u < 10) split_pair(u - 2);  // the next chunk's 8 channel pairs, one per unit behind the first k-step
+            if constexpr (SPLIT_IN_LOOP) { if (u >= 10 && u < 18) split_pair_t(1, u - 10); }
         }
         __syncthreads();
         if (more) store_chunk();
@@ -598,8 +607,8 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         float* out_c = coc < a.Osplit ? a.out + ((size_t)b * a.Osplit + coc) * HW
                                       : a.out2 + ((size_t)b * (a.Cout - a.Osplit) + (coc - a.Osplit)) * HW;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int gy = y0 + wave * 2 + m;
+        for (int m = 0; m < MR; ++m) {
+            const int gy = y0 + wave * MR + m;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int gx = x0 + 8 * g + 4 * h;
@@ -625,12 +634,23 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             red[((wave * 2 + h) * BN + n * 32 + r) * 2 + 1] = st_q[n];
         }
         __syncthreads();
-        if (tid < BN && co0 + tid < a.Cout) {
-            float s0 = 0.f, q0 = 0.f;
+        if constexpr (MR == 2) {
+            if (tid < BN && co0 + tid < a.Cout) {
+                float s0 = 0.f, q0 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { s0 += red[(k * BN + tid) * 2]; q0 += red[(k * BN + tid) * 2 + 1]; }
-            const int tpi = a.tiles_x * a.tiles_y;
-            a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
+                for (int k = 0; k < 8; ++k) { s0 += red[(k * BN + tid) * 2]; q0 += red[(k * BN + tid) * 2 + 1]; }
+                const int tpi = a.tiles_x * a.tiles_y;
+                a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
+            }
+        } else {                                  // 16-row tile: one part per 8-row half (waves 0-1 / 2-3), the layout of the 8-row kernels
+            static_assert(MR == 2 || MR == 4, "rows per wave");
+            const int half = tid / BN, ch = tid % BN, ty8 = 2 * ty + half, tiles8_y = (a.H + 7) / 8;
+            if (tid < 2 * BN && co0 + ch < a.Cout && ty8 < tiles8_y) {
+                float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s0 += red[((half * 4 + k) * BN + ch) * 2]; q0 += red[((half * 4 + k) * BN + ch) * 2 + 1]; }
+                a.stats[((size_t)(co0 + ch) * a.B + b) * (a.tiles_x * tiles8_y) + ty8 * a.tiles_x + tx] = make_float2(s0, q0);
+            }
         }
     }
 }
@@ -644,6 +664,15 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_h32_kernel(ConvFwdArgs a
 template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_h32_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true, true>(a); }
 // dilated 3x3 (dilation 2 / 4, padding = dilation), no staging-time BatchNorm
+// 16-row tiles (4 rows per wave) for the 32-channel layers
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_s32t_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, false, 1, 4>(a); }
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_s32t_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true, false, 1, 4>(a); }
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_h32t_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, true, 1, 4>(a); }
+template <int BN>
+__global__ __launch_bounds__(kConvThreads, 2) void conv_h32t_bn_kernel(ConvFwdArgs a) { conv_s32_body<BN, true, true, 1, 4>(a); }
 template <int BN, int DIL>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_s32d_kernel(ConvFwdArgs a) { conv_s32_body<BN, false, false, DIL>(a); }
 template <int BN, int DIL>

@@ -82,10 +82,12 @@ __global__ __launch_bounds__(kThreads) void up_cat_fwd_kernel(const float* __res
 // of one (b, c) plane, stages the <= 18 x 34 low-resolution patch it reads with coalesced loads, and every thread
 // produces 4 consecutive outputs from LDS (16 ds_read_b32 instead of 16 scattered global loads per 16-byte store;
 // the gather kernel above is load-instruction-bound at 2.3 TB/s).  Arithmetic and association are bilerp()'s.
-template <int TC>
+template <int TC, int RPT>
 __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __restrict__ low, float* __restrict__ out, int h, int w,
                                                               float rh, float rw, int tiles_x, int tiles_y, float* __restrict__ amax_out) {
-    constexpr int TR = 1024 / TC, LR = TR / 2 + 2, LC = TC / 2 + 2, LCP = LC + 1;
+    // RPT row groups per thread (round 3): 4 x fewer, longer workgroups -- the 1024-output form spent its time in launch,
+    // barrier and max-reduction overhead (3.0 TB/s on the 256 x 256 maps)
+    constexpr int TG = 1024 / TC, TR = TG * RPT, LR = TR / 2 + 2, LC = TC / 2 + 2, LCP = LC + 1;
     __shared__ float sL[LR * LCP];
     const int H = 2 * h, W = 2 * w;
     int bid = blockIdx.x;
@@ -102,8 +104,19 @@ __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __res
     }
     __syncthreads();
     const int xg = threadIdx.x % (TC / 4), row = threadIdx.x / (TC / 4);
-    const int oy = oy0 + row, ox = ox0 + xg * 4;
+    const int ox = ox0 + xg * 4;
     float am = 0.f;                              // max|output| of this thread (uaps_call_hints::out_amax)
+    int w0[4], w1[4];
+    float lw0[4], lw1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sx = mul_rn(rw, (float)(ox + k));
+        w0[k] = (int)sx; w1[k] = w0[k] + (w0[k] < w - 1 ? 1 : 0);
+        lw1[k] = sx - w0[k]; lw0[k] = 1.f - lw1[k];
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+    const int oy = oy0 + row + i * TG;
     if (oy < H && ox < W) {
     const float sy = mul_rn(rh, (float)oy);
     const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
@@ -113,15 +126,13 @@ __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __res
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float sx = mul_rn(rw, (float)(ox + k));
-        const int w0 = (int)sx, w1 = w0 + (w0 < w - 1 ? 1 : 0);
-        const float lw1 = sx - w0, lw0 = 1.f - lw1;
-        const float top = lerp2(lw0, r0[w0], lw1, r0[w1]);
-        const float bot = lerp2(lw0, r1[w0], lw1, r1[w1]);
+        const float top = lerp2(lw0[k], r0[w0[k]], lw1[k], r0[w1[k]]);
+        const float bot = lerp2(lw0[k], r1[w0[k]], lw1[k], r1[w1[k]]);
         v[k] = lerp2(lh0, top, lh1, bot);
     }
     *reinterpret_cast<float4*>(out + (plane * H + oy) * W + ox) = make_float4(v[0], v[1], v[2], v[3]);
-    am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    am = fmaxf(am, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
     }
     if (amax_out) {                              // uniform branch
         __shared__ float sm[16];
@@ -137,7 +148,9 @@ __global__ __launch_bounds__(kThreads) void up2x_tiled_kernel(const float* __res
 // coalesced 16-byte loads, reduces it along x into T[22][32] (each thread's 7 column weights are computed
 // once), then along y.  Same association as the plain double loop, 26 LDS reads per output instead of 49
 // scattered global ones.
-constexpr int kLy = 8, kLx = 32, kPr = 2 * kLy + 6, kPc = 2 * kLx + 8;   // patch rows / columns (x origin 2*ix0 - 4)
+// Round 3: LY = 32 low-resolution rows per block where the map has them (70 patch rows for 64 own: 9 % halo instead of 37 %,
+// four outputs per thread, a quarter of the workgroups); LY = 8 is the round-1 form.
+constexpr int kLx = 32, kPc = 2 * kLx + 8;   // tile / patch columns (x origin 2*ix0 - 4)
 
 __device__ __forceinline__ float tap_weight(float r, int o, int n_out, int n_in, int i) {
     if (o < 0 || o >= n_out) return 0.f;
@@ -147,9 +160,11 @@ __device__ __forceinline__ float tap_weight(float r, int o, int n_out, int n_in,
     return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
 }
 
+template <int kLy>
 __global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* __restrict__ dout, float* __restrict__ dlow, int B,
                                                                   int Cs, int Cl, int h, int w, float rh, float rw,
                                                                   int tiles_x, int tiles_y) {
+    constexpr int kPr = 2 * kLy + 6;             // patch rows
     __shared__ __attribute__((aligned(16))) float sA[kPr * kPc];
     __shared__ float sT[kPr * kLx];
     __shared__ float sWx[kLx][7], sWy[kLy][7];      // interpolation weights of the tile's columns / rows, computed once
@@ -189,14 +204,14 @@ __global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* _
         const int l = threadIdx.x / 7, k = threadIdx.x % 7;
         sWy[l][k] = tap_weight(rh, 2 * (iy0 + l) - 3 + k, H, h, iy0 + l);
     }
-    const int lx = threadIdx.x % kLx, ly = threadIdx.x / kLx;
-    const int ix = ix0 + lx, iy = iy0 + ly;
+    const int lx = threadIdx.x % kLx, ly0 = threadIdx.x / kLx;
+    const int ix = ix0 + lx;
     __syncthreads();
-    float wx[7], wy[7];
+    float wx[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) { wx[k] = sWx[lx][k]; wy[k] = sWy[ly][k]; }
+    for (int k = 0; k < 7; ++k) wx[k] = sWx[lx][k];
     // ---- reduce along x: T[r][lx] = sum_k wx[k] * A[r][2*lx + 1 + k]   (2*ix - 3 + k - ox0 = 2*lx + 1 + k) ----
-    for (int r = ly; r < kPr; r += kThreads / kLx) {
+    for (int r = ly0; r < kPr; r += kThreads / kLx) {
         // columns 2*lx .. 2*lx + 7 as four 8-byte reads: lanes are 2 floats apart, so ds_read_b64 covers all 64 banks once
         // (seven ds_read_b32 at that stride are 2-way conflicted); a[k] = column 2*lx + 1 + k
         const float2* a2 = reinterpret_cast<const float2*>(&sA[r * kPc + 2 * lx]);
@@ -209,11 +224,15 @@ __global__ __launch_bounds__(kThreads) void up_cat_bwd_low_kernel(const float* _
     }
     __syncthreads();
     // ---- reduce along y: rows 2*iy - 3 + k - oy0 = 2*ly + k ----
-    if (ix < w && iy < h) {
-        float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc += wy[k] * sT[(2 * ly + k) * kLx + lx];
-        dlow[(((long)b * Cl + c) * h + iy) * w + ix] = acc;
+    for (int j = 0; j < kLy / 8; ++j) {
+        const int ly = ly0 + 8 * j, iy = iy0 + ly;
+        if (ix < w && iy < h) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) acc += sWy[ly][k] * sT[(2 * ly + k) * kLx + lx];
+            dlow[(((long)b * Cl + c) * h + iy) * w + ix] = acc;
+        }
     }
 }
 
@@ -245,13 +264,14 @@ extern "C" int uaps_up_cat_fwd(const float* skip, const float* low, float* out, 
     const long total = (long)B * (Cs + Cl) * H * W;
     if (amax_out && !(Cs == 0 && W % 4 == 0 && al16(out))) return UAPS_ERANGE;      // only the plain up-sampling form tracks max|out|
     if (Cs == 0 && W % 4 == 0 && al16(out)) {            // plain up-sampling: the LDS-tiled kernel
-        const bool wide = W >= 64;
-        const int TC = wide ? 64 : 32, TR = 1024 / TC;
+        const bool wide = W >= 64, tall = wide && H >= 64;      // 64 x 64 output tiles (4 row groups per thread) where the map holds one
+        const int TC = wide ? 64 : 32, TR = (1024 / TC) * (tall ? 4 : 1);
         const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR;
         const long nblk = (long)B * Cl * tiles_x * tiles_y;
         if (nblk > 0x7fffffffL) return UAPS_ERANGE;
-        if (wide) hipLaunchKernelGGL(up2x_tiled_kernel<64>, dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
-        else hipLaunchKernelGGL(up2x_tiled_kernel<32>, dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
+        if (tall) hipLaunchKernelGGL((up2x_tiled_kernel<64, 4>), dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
+        else if (wide) hipLaunchKernelGGL((up2x_tiled_kernel<64, 1>), dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
+        else hipLaunchKernelGGL((up2x_tiled_kernel<32, 1>), dim3((unsigned)nblk), dim3(kThreads), 0, s, low, out, h, w, rh, rw, tiles_x, tiles_y, amax_out);
         return (int)hipGetLastError();
     }
     if (W % 4 == 0 && al16(skip) && al16(out))
@@ -274,9 +294,11 @@ extern "C" int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int
         else
             hipLaunchKernelGGL(slice_channels_kernel<false>, dim3(grid_for((long)B * Cs * HW)), dim3(kThreads), 0, s, dout, dskip, B, Cs + Cl, 0, Cs, HW);
     }
-    const int tiles_x = (w + kLx - 1) / kLx, tiles_y = (h + kLy - 1) / kLy;
+    const int ly = h >= 32 ? 32 : 8;
+    const int tiles_x = (w + kLx - 1) / kLx, tiles_y = (h + ly - 1) / ly;
     const long nblk = (long)B * Cl * tiles_x * tiles_y;
     if (nblk > 0x7fffffffL) return UAPS_ERANGE;
-    hipLaunchKernelGGL(up_cat_bwd_low_kernel, dim3((unsigned)nblk), dim3(kThreads), 0, s, dout, dlow, B, Cs, Cl, h, w, rh, rw, tiles_x, tiles_y);
+    if (ly == 32) hipLaunchKernelGGL(up_cat_bwd_low_kernel<32>, dim3((unsigned)nblk), dim3(kThreads), 0, s, dout, dlow, B, Cs, Cl, h, w, rh, rw, tiles_x, tiles_y);
+    else hipLaunchKernelGGL(up_cat_bwd_low_kernel<8>, dim3((unsigned)nblk), dim3(kThreads), 0, s, dout, dlow, B, Cs, Cl, h, w, rh, rw, tiles_x, tiles_y);
     return (int)hipGetLastError();
 }
