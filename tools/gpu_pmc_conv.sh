@@ -6,8 +6,8 @@ layer=${1:-dec.up2b}
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_conv
 mkdir -p $out
 cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/p1 -o pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py --batch 32 --only "$layer" > $out/p1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --output-format csv -d $out/p2 -o pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py --batch 32 --only "$layer" > $out/p2.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/p1 -o pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py --batch 32 --only "$layer" > $out/p1.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES --output-format csv -d $out/p2 -o pmc -- python3 $GRAFT_REPO_ROOT/tools/bench_conv.py --batch 32 --only "$layer" > $out/p2.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, collections
