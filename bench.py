@@ -115,21 +115,29 @@ def cpu_baseline(batch, H, W, budget_s=25.0):
 
 def other_configs(steps, dev):
     """BASELINE.json configs[3] (K = 5 decoders, DAGM-shaped 1 x 512 x 512, 2 classes, 8 + 8 images) and the per-GPU shape of
-    configs[4] (ResNet-50 encoder, K = 3, 640 x 640, 2 classes, 8 + 8 images): `steps` eager training steps each after two
-    warm-up steps, HIP events around the timed steps."""
+    configs[4] (ResNet-50 encoder, K = 3, 640 x 640, 2 classes, 8 + 8 images): `steps` training steps each in the headline launch
+    mode (configs[3]: captured hipGraph + streams; the ResNet net steps eagerly), HIP events around the timed steps, then one
+    single-stream eager step with dispatch events on every convolution launch for the step's algorithmic flops, the dominant
+    kernel and the step-level roofline (t_min = max(flops at each kernel's matrix peak, HBM bytes / 8 TB/s); the HBM bytes come
+    from profiles/pmc_traffic_<tag>.json when the PMC passes of that configuration are committed)."""
     import gc
+    import numpy as np
     import torch
     import uaps_amd
+    import uaps_amd.unet as _unet
+    from uaps_amd import conv
     out = []
-    for name, net, in_chns, classes, aux, batch, size in (
-            ("configs[3]: UAPS K=5 decoders, DAGM-shaped 1x512x512 2-class, batch 8+8", "unet_uaps", 1, 2, 5, 8, 512),
-            ("configs[4] per-GPU shape: UAPS ResNet-50 encoder K=3, KoSDD2-shaped 3x640x640 2-class, batch 8+8", "resnet50_uaps", 3, 2, 3, 8, 640)):
+    for tag, name, net, in_chns, classes, aux, batch, size in (
+            ("configs3", "configs[3]: UAPS K=5 decoders, DAGM-shaped 1x512x512 2-class, batch 8+8", "unet_uaps", 1, 2, 5, 8, 512),
+            ("configs4", "configs[4] per-GPU shape: UAPS ResNet-50 encoder K=3, KoSDD2-shaped 3x640x640 2-class, batch 8+8", "resnet50_uaps", 3, 2, 3, 8, 640)):
+        streams, wrw = _unet._DECODER_STREAMS, conv.WRW_STREAMS
         try:
             torch.manual_seed(1337)
             model = uaps_amd.net_factory(net, in_chns, classes, n_aux=aux)
-            trainer = uaps_amd.UAPSTrainer(model, seed=1337)
+            use_graph = net == "unet_uaps"
+            trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
             data = uaps_amd.data.SyntheticBatches(batch, in_chns, classes, size, size, n_batches=2, seed=1337, device=dev)
-            for _ in range(2):
+            for _ in range(4 if use_graph else 2):           # two eager steps, the capture and a first replay
                 trainer.train_step(*data.next())
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,14 +149,99 @@ def other_configs(steps, dev):
             ms = e0.elapsed_time(e1) / steps
             loss = float(trainer.last["loss"])
             trainer.check_errors()
-            out.append({"workload": name, "images_per_s": round(2 * batch / ms * 1e3, 1), "ms_per_step": round(ms, 2), "steps": steps,
-                        "final_loss": round(loss, 5), "launch_mode": "eager, one HIP stream per auxiliary decoder"})
+            graph_used = trainer.step_graph is not None and trainer.step_graph.graph is not None
+            rec = {"workload": name, "images_per_s": round(2 * batch / ms * 1e3, 1), "ms_per_step": round(ms, 2), "steps": steps,
+                   "final_loss": round(loss, 5),
+                   "launch_mode": ("captured hipGraph replayed per step, " if graph_used else "eager, ") + "one HIP stream per auxiliary decoder"}
+            # ---- one single-stream eager step with events on every conv launch: flops, dominant kernel, roofline ----
+            _unet._DECODER_STREAMS = False
+            conv.set_wrw_streams(False)
+            trainer.step_graph, trainer.optimizer.from_step_state = None, False
+            trainer.train_step(*data.next())
+            torch.cuda.synchronize()
+            conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, None
+            trainer.train_step(*data.next())
+            torch.cuda.synchronize()
+            ev, conv.KERNEL_EVENTS = conv.KERNEL_EVENTS, None
+            per = {k: {"calls": len(v), "us": float(sum(s.elapsed_time(e) for s, e, _ in v)) * 1e3, "work": float(sum(r[2] for r in v))}
+                   for k, v in ev.items()}
+            flops = sum(v["work"] for v in per.values())
+            t_mfma = sum(v["work"] / (mfma_peak_for(k) * 1e12) for k, v in per.items()) * 1e3
+            pmc = {}
+            try:
+                with open(os.path.join(ROOT, "profiles", f"pmc_traffic_{tag}.json")) as f:
+                    pmc = json.load(f)
+            except (OSError, ValueError):
+                pass
+            hbm = pmc.get("__step_total_bytes")
+            t_hbm = hbm / (HBM_PEAK_GBS * 1e9) * 1e3 if hbm else None
+            t_min = max(t_mfma, t_hbm or 0.0)
+            dom = max(per, key=lambda k: per[k]["us"]) if per else None
+            roof = {"step_flops": flops, "step_hbm_bytes": hbm, "t_min_mfma_ms": round(t_mfma, 3),
+                    "t_min_hbm_ms": round(t_hbm, 3) if t_hbm else None, "t_min_ms": round(t_min, 3), "frac_step": round(t_min / ms, 4),
+                    "step_TFLOPs": round(flops / ms / 1e9, 2),
+                    "note": "flops: 2*B*H*W*Cin*Cout*k*k summed over every stride-1 convolution launch of one step (the three strided "
+                            "convolutions of the ResNet stem / layer2 are not counted); t_min_mfma: each launch at the peak of the matrix "
+                            "instruction it runs on; HBM bytes: rocprofv3 --pmc passes of this configuration (profiles/), null when not collected"}
+            if dom:
+                d = per[dom]
+                ach = d["work"] / d["us"] / 1e6
+                roof["dominant_kernel"] = {"kernel": dom, "launches_per_step": d["calls"], "avg_us": round(d["us"] / d["calls"], 2),
+                                           "achieved": round(ach, 2), "peak": round(mfma_peak_for(dom), 1), "unit": "TFLOP/s",
+                                           "frac": round(ach / mfma_peak_for(dom), 4), "traffic": pmc.get(dom),
+                                           "note": "single-stream eager step, dispatch events (1 step)"}
+            rec["roofline"] = roof
+            out.append(rec)
             del trainer, model, data
         except Exception as e:                               # never lose the headline line to a side measurement
             out.append({"workload": name, "error": f"{type(e).__name__}: {e}"[:300]})
+        finally:
+            conv.KERNEL_EVENTS = None
+            _unet._DECODER_STREAMS = streams
+            conv.set_wrw_streams(wrw)
         gc.collect()
         torch.cuda.empty_cache()
     return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N ...` without torch.distributed.run: start N fresh copies of this command, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as the launcher would), wait for them and return the job's exit code.
+    Called before anything has touched the GPU; the children are new processes, never an exec of this one.  Rank 0 inherits
+    stdout (the one JSON line); the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    codes = []
+    try:
+        # one rank failing must not leave the others waiting in a collective for ever
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is not None:
+                    pending.discard(r)
+                    codes.append(rc)
+                    if rc != 0:
+                        for q in pending:
+                            procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p in procs:
+        p.wait()
+    bad = [c for c in (p.returncode for p in procs) if c != 0]
+    return 0 if not bad else (bad[0] if bad[0] > 0 else 1)
 
 
 def main():
@@ -160,6 +253,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--classes", type=int, default=4)
     ap.add_argument("--aux", type=int, default=3)
+    ap.add_argument("--in-chns", type=int, default=3, help="image channels (1 for the DAGM-shaped configs[3])")
     ap.add_argument("--net", default="unet_uaps", help="unet_uaps (BASELINE.json configs[1], the reported metric) or resnet50_uaps (configs[4] shape study)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
@@ -174,6 +268,10 @@ def main():
                     help="N = 1 only: steps timed of each of BASELINE.json configs[3] and the per-GPU shape of configs[4] after everything else (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: this process becomes one (it has touched no GPU and imports no torch) and exits with the job's code
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -181,15 +279,20 @@ def main():
     from uaps_amd import losses
 
     import uaps_amd.unet as _unet
-    _unet._DECODER_STREAMS = not args.single_stream
+    from uaps_amd import conv as _conv
+    _unet._DECODER_STREAMS = not args.single_stream and os.environ.get("UAPS_BENCH_DECODER_STREAMS", "1") != "0"      # (experiment hook)
+    # weight-gradient launches on companion streams of the decoder / main streams (uaps_amd/conv.py: WRW_STREAMS): part of the
+    # headline stream mode; UAPS_WRW_STREAMS=0 is the A/B switch
+    wrw_streams = not args.single_stream and os.environ.get("UAPS_WRW_STREAMS", "1") != "0"
+    _conv.set_wrw_streams(wrw_streams)
     if os.environ.get("UAPS_BENCH_CPUS"):                   # experiment hook: this process on its first n usable cores (what one of 8 ranks gets)
         os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:int(os.environ["UAPS_BENCH_CPUS"])])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch --nproc-per-node {args.gpus} ranks "
+                         "(or run without a launcher: this script then starts the ranks itself)")
     # test hooks (tests/test_gpu_two_ranks.py runs the N = 2 code path on a one-GPU box): every rank on one device, gloo
     # instead of RCCL, which refuses two ranks on a device
     backend = os.environ.get("UAPS_BENCH_BACKEND", "nccl")
@@ -229,7 +332,7 @@ def main():
                     affinity = None
     torch.manual_seed(1337)
     D, C, H, W, b = args.aux + 1, args.classes, args.size, args.size, args.batch
-    model = uaps_amd.net_factory(args.net, 3, C, n_aux=args.aux)
+    model = uaps_amd.net_factory(args.net, args.in_chns, C, n_aux=args.aux)
     uaps_amd.dist.broadcast_model(model)
     if saved_stdout is not None:
         dist.barrier()
@@ -244,7 +347,7 @@ def main():
     # rank here, where tools/diag/rccl_split_graph.py once aborted behind other process groups of the same process -- so not the default)
     use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or os.environ.get("UAPS_GRAPH_MULTI", "0") == "1")
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
-    data = uaps_amd.data.SyntheticBatches(b, 3, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
+    data = uaps_amd.data.SyntheticBatches(b, args.in_chns, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
 
     from uaps_amd import conv
 
@@ -291,6 +394,7 @@ def main():
     discover, ev, cev, single_ms = None, {}, {}, None
     if args.analysis_steps > 0:                              # every rank steps (the gradient exchange is collective); rank 0's events are reported
         _unet._DECODER_STREAMS = False
+        _conv.set_wrw_streams(False)
         trainer.step_graph, trainer.optimizer.from_step_state = None, False     # eager launches: events can bracket each kernel
         trainer.train_step(*data.next())                   # re-warm in the new mode
         torch.cuda.synchronize()
@@ -315,6 +419,7 @@ def main():
         ev, losses.KERNEL_EVENTS = losses.KERNEL_EVENTS, None
         cev, conv.KERNEL_EVENTS, conv.EVENT_FILTER = conv.KERNEL_EVENTS, None, None
         _unet._DECODER_STREAMS = not args.single_stream
+        _conv.set_wrw_streams(wrw_streams)
     else:
         dominant = None
 
@@ -444,6 +549,8 @@ def main():
                          "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
         mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (same kernels as single-stream)"
+        if wrw_streams:
+            mode += ", weight-gradient launches on a companion stream of each"
         if graph_used and not graph_split:
             mode = "captured hipGraph of the whole step, replayed once per step (the eager step's kernels and arithmetic; DESIGN.md section 4 on bit reproducibility); " + mode
         elif graph_split:
@@ -505,6 +612,11 @@ def main():
         print(json.dumps(res), flush=True)
     if distributed:
         dist.destroy_process_group()
+    if ranks_seen != world:
+        # the process group did not see every rank the job was launched with: the line above says so (ranks_seen), and the
+        # run fails rather than pass for an N-GPU measurement
+        print(f"bench.py: ranks_seen = {ranks_seen} but n_gpus = {world}", file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -14,8 +14,8 @@
  *     caller through the entry points named here and none of it stream-ordered (change it between steps):
  *       process-wide   the convolution arithmetic (uaps_conv_set_mode) and planner switches (uaps_conv_set_tuning), the pointer
  *                      to the device-resident step state (uaps_set_step_state: NULL outside a state-mode step; two trainers in
- *                      one process each bracket their steps with set / clear, see uaps_amd/graph.py) and the pointer to the
- *                      sticky device error word (uaps_set_error_word);
+ *                      one process each bracket their steps with set / clear, see uaps_amd/graph.py) and, per device, the pointer
+ *                      to that device's sticky error word (uaps_set_error_word);
  *       per thread     the one-shot side arguments of the NEXT call (uaps_next_call_hints, uaps_next_launch_events), consumed
  *                      and cleared by that call;
  *   - return value: 0 on success, a negative UAPS_E* code for bad arguments, a positive hipError_t
@@ -361,7 +361,9 @@ unsigned uaps_conv_get_tuning(void);
  * NaN.  Those kernels check what they store and OR a UAPS_ERR_* bit into *device_word (4-byte aligned device memory owned
  * and zeroed by the caller; NULL = no reporting) when a stored value is not finite -- so a violated bound, or non-finite data
  * entering a convolution, is reported instead of training on.  Read the word whenever the host synchronises anyway
- * (UAPSTrainer.epoch_metrics / validate / check_errors do). */
+ * (UAPSTrainer.epoch_metrics / validate / check_errors do).  One word per DEVICE: the call binds (or, with NULL, unbinds) the
+ * word of the current device, and a launch reports to the word of the device it runs on.  The word must outlive every
+ * launch made while it is bound (the Python package keeps one never-freed word per device, uaps_amd._lib.error_word). */
 #define UAPS_ERR_CONV_NONFINITE 1u     /* an fp16-split forward / input-gradient convolution stored a non-finite value */
 #define UAPS_ERR_WRW_NONFINITE 2u      /* an fp16-split weight-gradient convolution produced a non-finite partial sum */
 int uaps_set_error_word(unsigned* device_word);

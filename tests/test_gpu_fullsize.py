@@ -313,10 +313,11 @@ def test_real_width_step_256_vs_float64_oracle(mode):
     worst <= 3 x the float32 oracle's, over all parameters -- a composed error of 23 layers of 22-bit operand pieces (mode
     h16) that exceeded fp32's would show here.  FeatureDropout's keep mask is a step function of the features
     (UAPS_unet.py:161-169), so the masks the float64 oracle drew are replayed everywhere (the threshold logic itself is pinned
-    bit for bit by fixture g3).  4 + 4 images of 256 x 256 by default (UAPS_TEST_F64_BATCH)."""
+    bit for bit by fixture g3).  The default arithmetic (h16) runs at the metric's own batch, 16 + 16 images of 256 x 256; the two
+    other modes at 4 + 4 (UAPS_TEST_F64_BATCH overrides both)."""
     import os
     from uaps_amd import conv, losses, perturb, unet
-    B, H, W, C = int(os.environ.get("UAPS_TEST_F64_BATCH", "4")), 256, 256, 4
+    B, H, W, C = int(os.environ.get("UAPS_TEST_F64_BATCH", "16" if mode == "h16" else "4")), 256, 256, 4
     sd0, xl, xu, yl, w, rec, keeps, cw1, cw2, res = _float64_and_float32_oracle_step(B, H, W, C)
     r64, r32 = res[torch.float64], res[torch.float32]
     model = unet.UNet_UAPS(3, C, n_aux=3, dropout=[0.0] * 5)

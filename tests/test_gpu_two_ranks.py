@@ -181,6 +181,29 @@ def test_bench_two_ranks_one_line(tmp_path):
     assert abs(out["value"] - per_step / (out["ms_per_step"] * 1e-3)) / out["value"] < 0.02
 
 
+def test_bench_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` exactly as the N = 1 command with another --gpus (no torch.distributed.run): the script
+    starts its two ranks itself as fresh processes (before it touches the GPU), rank 0 prints the ONE line, the exit code is the
+    job's.  Same gloo / one-card hooks as above."""
+    import json
+    import subprocess
+    env = dict(os.environ, UAPS_BENCH_BACKEND="gloo", UAPS_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "64",
+           "--analysis-steps", "0", "--exact-steps", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["parallelism"] == "dp2" and out["value"] > 0
+    # a launch whose process group is smaller than --gpus says so and fails
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run(cmd, cwd=ROOT, env=env1, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
 def test_bench_four_ranks_at_the_metric_batch(tmp_path):
     """`bench.py --gpus 4` as the driver launches it, at the metric's own per-GPU batch (16 + 16 images of 256 x 256, the full
     net): four ranks time-share this box's card, gloo carries the collectives.  The line must report all four ranks

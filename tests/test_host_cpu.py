@@ -159,7 +159,7 @@ def test_checkpoint_layout_round_trip(tmp_path):
     tr.iter_num = 1234
     tr.scheduler.step(0.4)
     tr.save_checkpoint(path, epoch=7, best_dice=0.5)
-    ck = torch.load(path, weights_only=False)
+    ck = torch.load(path)              # the plain call of the reference's loaders and of user tools: weights_only=True since torch 2.6
     # the reference's four keys (UAPS_train.py:443-448) + the resume extras its loaders ignore
     assert {"epoch", "best_dice_1", "state_dict", "optimizer"} <= set(ck) <= {"epoch", "best_dice_1", "state_dict", "optimizer", "iter_num", "scheduler", "mix_rng", "step_key"}
     assert all(k.startswith("module.") for k in ck["state_dict"]) and len(ck["state_dict"]) == 334
@@ -175,6 +175,7 @@ def test_checkpoint_layout_round_trip(tmp_path):
     assert tr3.load_checkpoint(path)["epoch"] == 7
     assert tr3.iter_num == 1234 and tr3.scheduler.best == 0.4              # the ramp and the plateau state resume
     assert abs(tr3.consistency_weights()[0] - tr.consistency_weights()[0]) < 1e-15
+    assert np.array_equal(tr3.mix_rng.dirichlet(np.ones(4), size=3), tr.mix_rng.dirichlet(np.ones(4), size=3))      # the mixing stream resumes
     # scheduler surface of UAPS_train.py:113, 402
     tr.scheduler.step(0.3)
     assert tr.optimizer.param_groups[0]["lr"] == 1e-3
@@ -210,3 +211,18 @@ def test_mean_batch_metrics_follow_the_reference_loop():
         assert abs(m[k] - np.mean([p[k] for p in per])) < 1e-12
     pooled = uaps_amd.metrics_from_confusion(cms.sum(0))
     assert abs(pooled["mdice"] - m["mdice"]) > 1e-6      # the two conventions differ on this data
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the failure path of a box without a GPU")
+def test_bench_starts_its_own_ranks_and_propagates_their_failure():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes itself (bench.spawn_ranks) and exits with their
+    code: without a GPU both ranks fail at the first device call, and the command fails with them instead of hanging."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    # (the first rank to fail ends the job: the other one is terminated, with or without having reported itself)
+    assert "No HIP GPUs are available" in r.stderr or "Traceback" in r.stderr, r.stderr[-2000:]

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--mode", default="h16", choices=["h16", "split", "exact"],
                     help="convolution arithmetic (uaps_amd.conv.set_mode); h16 passes the operands' magnitude bounds like the step does")
+    ap.add_argument("--no-miopen", action="store_true", help="skip the MIOpen / ATen columns (large batches)")
     ap.add_argument("--lds-sweep", action="store_true", help="forward kernel with 0..56 KB of extra (unused) LDS = fewer workgroups per CU")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -72,9 +73,12 @@ def main():
         t_f = timeit(lambda: C.conv_fwd_raw(x, wf, None, Cout, ks, xb=xb))
         t_b = timeit(lambda: C.conv_bwd_data_raw(dy, wb, Cin, ks, dyb=dyb))
         t_w = timeit(lambda: C.conv_bwd_weight_raw(dy, x, ks, False, dyb=dyb, xb=xb))
-        m_f = timeit(lambda: F.conv2d(x, w, None, padding=ks // 2))
-        m_b = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [ks // 2] * 2, [1, 1], False, [0, 0], 1, [True, False, False]))
-        m_w = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [ks // 2] * 2, [1, 1], False, [0, 0], 1, [False, True, False]))
+        if args.no_miopen:
+            m_f = m_b = m_w = 0.0
+        else:
+            m_f = timeit(lambda: F.conv2d(x, w, None, padding=ks // 2))
+            m_b = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [ks // 2] * 2, [1, 1], False, [0, 0], 1, [True, False, False]))
+            m_w = timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [ks // 2] * 2, [1, 1], False, [0, 0], 1, [False, True, False]))
         for k, v in zip(("fwd", "bwd", "wrw", "mfwd", "mbwd", "mwrw"), (t_f, t_b, t_w, m_f, m_b, m_w)):
             tot[k] += v * calls
         print(f"{name:28s} {gf:6.2f} | {t_f:8.1f} {gf / t_f * 1e3:6.1f} {m_f:8.1f} | {t_b:8.1f} {gf / t_b * 1e3:6.1f} {m_b:8.1f} | {t_w:8.1f} {gf / t_w * 1e3:6.1f} {m_w:8.1f}", flush=True)

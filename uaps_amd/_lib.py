@@ -227,6 +227,23 @@ class LaunchTimer:
         return self.start.elapsed_time(self.stop)
 
 
+_error_words = {}      # device index -> int32[1] tensor, never freed (the library holds its raw pointer)
+
+
+def error_word(device):
+    """The sticky error word of `device` (include/uaps_hip.h, uaps_set_error_word): allocated once per device, bound for good and
+    never freed, so that the raw pointer the library keeps cannot dangle whatever happens to trainers and models.  Shared by
+    everything that runs on the device; UAPSTrainer.check_errors reads and clears it."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _error_words.get(idx)
+    if w is None:
+        w = _error_words[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    with torch.cuda.device(idx):           # (re)bound on every call: a caller of the C ABI may have pointed the library elsewhere
+        check(lib().uaps_set_error_word(w.data_ptr()), "uaps_set_error_word")
+    return w
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().uaps_error_string(rc).decode()

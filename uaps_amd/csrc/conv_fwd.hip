@@ -385,6 +385,15 @@ extern "C" int uaps_conv_pack_weights_batch(const float* const* w, float* const*
     return UAPS_OK;
 }
 
+#ifdef UAPS_STAMPS
+// diagnostic build only (stamps.hpp; not part of include/uaps_hip.h): where the stamped kernels of this file write, nwaves * 20 words
+extern "C" int uaps_debug_set_stamp_buffer(unsigned long long* buf, unsigned long long nwaves) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(uaps::g_stamp_buf), &buf, sizeof buf);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(uaps::g_stamp_waves), &nwaves, sizeof nwaves);
+    return (int)e;
+}
+#endif
+
 extern "C" int uaps_conv_fwd(const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                              int ks, int cfg, uaps_stream_t stream) {
     return conv_fwd_any(x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream);

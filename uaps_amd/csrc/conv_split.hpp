@@ -19,6 +19,14 @@
 #pragma once
 #include "conv_kernels.hpp"
 #include "hints.hpp"
+#include "stamps.hpp"
+
+// UAPS_ABLATE (diagnostic builds only, with UAPS_STAMPS: `make stamps`; 0 = the shipped kernel): parts of conv_s32_body removed
+// behind the first chunk -- 5: no global loads, splits or LDS stores; 6: also no barriers; 7: also no LDS fragment reads (a pure
+// MFMA stream on register operands).  Results are garbage; only the time is of interest.
+#ifndef UAPS_ABLATE
+#define UAPS_ABLATE 0
+#endif
 
 namespace uaps {
 
@@ -394,6 +402,8 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 
     int bid = xcd_swizzle(blockIdx.x, gridDim.x);
     if (bid >= a.B * a.tiles_x * a.tiles_y * a.nblk) return;
+    UAPS_STAMP_DECL;                                  // phases (diagnostic build only, stamps.hpp): 0 prologue, 1 first chunk fetched + stored,
+                                                      // per chunk: 2 load issue, 3 matrix loop, 4 barrier, 5 LDS stores, 6 barrier; 7 epilogue stores, 8 statistics
     stagger_by_wave_slot();
     const int nb = bid % a.nblk; bid /= a.nblk;
     const int tx = bid % a.tiles_x; bid /= a.tiles_x;
@@ -533,6 +543,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     const int boff = h * BN + r;
 
     const int nchunks = (a.Cin + 7) / 8;
+    UAPS_STAMP(0);
     load_chunk(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) split_pair(i);
@@ -542,9 +553,12 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
     }
     store_chunk();
     __syncthreads();
+    UAPS_STAMP(1);
     for (int ch = 0; ch < nchunks; ++ch) {
         const bool more = ch + 1 < nchunks;
-        if (more) load_chunk((ch + 1) * 8);
+        if (more && UAPS_ABLATE < 5) load_chunk((ch + 1) * 8);
+        UAPS_STAMP(2);
+        UAPS_STAMP_FIRST_MFMA();
         bf16x8 af[2][NP], bfr[2][NT][NP];
         auto read_a = [&](int u, bf16x8 (&dst)[NP]) {
 #pragma unroll
@@ -556,13 +570,16 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
 #pragma unroll
                 for (int p = 0; p < NP; ++p) dst[n][p] = __builtin_bit_cast(bf16x8, sW[(p * NQP + 2 * ks) * BN + boff + n * 32]);
         };
-        read_b(0, bfr[0]);
-        read_a(0, af[0]);
+        if (UAPS_ABLATE < 7 || ch == 0) {
+            read_b(0, bfr[0]);
+            read_a(0, af[0]);
+            if constexpr (UAPS_ABLATE >= 7) { read_b(1, bfr[1]); read_a(1, af[1]); }
+        }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int ks = u / MR, m = u % MR;
-            const bool new_b = u + 1 < NU && (u + 1) % MR == 0;
-            if (u + 1 < NU) read_a(u + 1, af[(u + 1) & 1]);
+            const bool new_b = UAPS_ABLATE < 7 && u + 1 < NU && (u + 1) % MR == 0;
+            if (UAPS_ABLATE < 7 && u + 1 < NU) read_a(u + 1, af[(u + 1) & 1]);
             if (new_b) read_b(ks + 1, bfr[(ks + 1) & 1]);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {           // smallest partial products first
@@ -585,12 +602,16 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             if (new_b) __builtin_amdgcn_sched_group_barrier(0x100, NP + NP * NT, 0);
             else if (u + 1 < NU) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, (H16 ? 3 : 6) * NT, 0);
-            if (u >= 2 && u < 10) split_pair(u - 2);  // the next chunk's 8 channel pairs, one per unit behind the first k-step
-            if constexpr (SPLIT_IN_LOOP) { if (u >= 10 && u < 18) split_pair_t(1, u - 10); }
+            if (UAPS_ABLATE < 5 && u >= 2 && u < 10) split_pair(u - 2);  // the next chunk's 8 channel pairs, one per unit behind the first k-step
+            if constexpr (SPLIT_IN_LOOP && UAPS_ABLATE < 5) { if (u >= 10 && u < 18) split_pair_t(1, u - 10); }
         }
-        __syncthreads();
-        if (more) store_chunk();
-        __syncthreads();
+        UAPS_STAMP(3);
+        if (UAPS_ABLATE < 6) __syncthreads();
+        UAPS_STAMP(4);
+        if (more && UAPS_ABLATE < 5) store_chunk();
+        UAPS_STAMP(5);
+        if (UAPS_ABLATE < 6) __syncthreads();
+        UAPS_STAMP(6);
     }
 
     // ---- epilogue.  C/D of 32x32: lane (n = r, h) register i holds pixel 8 (i >> 2) + 4 h + (i & 3) of channel n ----
@@ -626,6 +647,7 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
         }
     }
     if constexpr (H16) report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
+    UAPS_STAMP(7);
     if (a.stats != nullptr) {                    // per-tile BatchNorm partial sums: 8 partials (4 waves x 2 halves) per channel, fixed order
         float* red = reinterpret_cast<float*>(sIn);
 #pragma unroll
@@ -653,6 +675,8 @@ __device__ __forceinline__ void conv_s32_body(const ConvFwdArgs& a) {
             }
         }
     }
+    UAPS_STAMP(8);
+    UAPS_STAMP_FLUSH();
 }
 
 template <int BN>

@@ -5,7 +5,9 @@ namespace {
 thread_local uaps_call_hints g_hints;
 thread_local bool g_have = false;
 thread_local uaps::LaunchEvents g_launch;
-unsigned* g_error_word = nullptr;      // process-wide, like the convolution mode
+constexpr int kMaxDevices = 64;
+unsigned* g_error_word[kMaxDevices] = {};      // one per device: a kernel only ever writes to a word of the device it runs on
+int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices ? d : 0; }
 }
 
 namespace uaps {
@@ -16,12 +18,12 @@ uaps_call_hints take_hints() {
     return h;
 }
 LaunchEvents& launch_events() { return g_launch; }
-unsigned* error_word() { return g_error_word; }
+unsigned* error_word() { return g_error_word[current_device()]; }
 }  // namespace uaps
 
 extern "C" int uaps_set_error_word(unsigned* device_word) {
     if ((uintptr_t)device_word % 4) return UAPS_EINVAL;
-    g_error_word = device_word;
+    g_error_word[current_device()] = device_word;      // the word of the CURRENT device (hipSetDevice), like every launch here
     return UAPS_OK;
 }
 

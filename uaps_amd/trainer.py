@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import conv as _conv
 from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
@@ -58,8 +59,8 @@ class UAPSTrainer:
         self.last: Dict[str, torch.Tensor] = {}
         # sticky device error word (include/uaps_hip.h, uaps_set_error_word): the fp16-split convolutions flag non-finite
         # outputs there -- a violated magnitude bound, or non-finite data -- and check_errors() raises on it
-        self._err = torch.zeros(1, dtype=torch.int32, device=self.device) if on_gpu else None
-        self._bind_error_word()
+        # one never-freed word per device, bound once (_lib.error_word): no pointer of a dropped trainer is left in the library
+        self._err = _lib.error_word(self.device) if on_gpu else None
         # step_state: per-step scalars and the RNG key travel through the device-resident step state instead of kernel
         # arguments (uaps_amd.graph); use_graph: that step is captured as a hipGraph after two warm-up steps and replayed
         self.step_graph = None
@@ -68,10 +69,6 @@ class UAPSTrainer:
             self.step_graph = StepGraph(self, capture=bool(use_graph))
 
     # -- device-side error reporting --
-    def _bind_error_word(self) -> None:
-        if self._err is not None:
-            _lib.check(_lib.lib().uaps_set_error_word(self._err.data_ptr()), "uaps_set_error_word")
-
     def check_errors(self, flags: Optional[int] = None) -> None:
         """Raise if a kernel reported an error since the last check (one device->host copy unless `flags` is given)."""
         if self._err is None:
@@ -98,7 +95,6 @@ class UAPSTrainer:
 
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u: torch.Tensor, w=None) -> Dict[str, torch.Tensor]:
         """Returns device scalars (loss, sup, unsup); nothing here synchronises with the host."""
-        self._bind_error_word()                          # process-wide registration: the trainer that steps owns it
         if self.step_graph is not None and w is None and x_l.shape == x_u.shape:
             return self.step_graph.step(x_l, y_l, x_u)
         if self.step_graph is not None:
@@ -134,6 +130,7 @@ class UAPSTrainer:
                 out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
         self.optimizer.zero_grad(set_to_none=True)                                # :285
         out.loss.backward()                                                       # :287
+        _conv.join_wrw_streams()                         # weight-gradient side streams (conv.WRW_STREAMS) rejoin the step's stream
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :292
@@ -170,7 +167,6 @@ class UAPSTrainer:
         mDice, each averaged over the batches -- the mDice returned here is what the reference feeds to
         ReduceLROnPlateau.step (:402) and to the best-checkpoint test (:427).  One device->host copy at the end.
         `pooled=True`: metrics of the summed confusion matrix instead (a different number, see epoch_metrics)."""
-        self._bind_error_word()
         self.model.eval()
         cms, ces = [], []
         for x, y in batches:
@@ -256,9 +252,10 @@ class UAPSTrainer:
         sd = self.model.state_dict()
         if dataparallel_prefix and not any(k.startswith("module.") for k in sd):
             sd = {"module." + k: v for k, v in sd.items()}     # the reference saves nn.DataParallel(model).state_dict()
-        # the reference's four keys (UAPS_train.py:443-448) + what a resume needs (its loaders ignore unknown keys)
+        # the reference's four keys (UAPS_train.py:443-448) + what a resume needs, all of it plain Python / torch types so that
+        # a plain `torch.load(path)` (weights_only=True since torch 2.6) -- the reference's loaders, a user's tools -- reads it
         ck = {"epoch": epoch, "best_dice_1": best_dice, "state_dict": sd, "optimizer": self.optimizer.state_dict(),
-              "iter_num": self.iter_num, "scheduler": self.scheduler.state_dict(), "mix_rng": self.mix_rng.get_state()}
+              "iter_num": self.iter_num, "scheduler": self.scheduler.state_dict(), "mix_rng": _rng_state_plain(self.mix_rng)}
         if self.step_graph is not None:
             ck["step_key"] = int(self.step_graph.state.key)      # the Philox key of the state-mode perturbation streams
         return ck
@@ -283,7 +280,7 @@ class UAPSTrainer:
             if "scheduler" in ck:
                 self.scheduler.load_state_dict(ck["scheduler"])
             if "mix_rng" in ck:
-                self.mix_rng.set_state(ck["mix_rng"])
+                self.mix_rng.set_state(_rng_state_numpy(ck["mix_rng"]))
         if self.step_graph is not None:
             # a captured step holds the OLD Adam moment buffers through frozen pointers (load_state_dict replaced them):
             # drop the capture, it is re-recorded after the warm-up steps; the Adam step count is re-read from the loaded state
@@ -313,6 +310,7 @@ class BaselineTrainer(UAPSTrainer):
         s = losses.uaps_sup_loss((main,), y_l)                                    # :161-164, 0.5 * (dice + CE)
         self.optimizer.zero_grad(set_to_none=True)                                # :166
         s.loss.backward()                                                         # :168
+        _conv.join_wrw_streams()
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :173
@@ -322,6 +320,20 @@ class BaselineTrainer(UAPSTrainer):
         sc = losses.sup_scalars(s.scalars, 1, main.shape[1])
         self.last = {"loss": s.loss.detach(), "ce": sc["ce"][0], "dice": sc["dice"][0]}
         return self.last
+
+
+def _rng_state_plain(rng: np.random.RandomState):
+    """np.random.RandomState.get_state() with the key array as a torch tensor: nothing a weights-only unpickler refuses."""
+    name, keys, pos, has_gauss, cached = rng.get_state()
+    return (str(name), torch.from_numpy(np.asarray(keys, dtype=np.uint32).astype(np.int64)), int(pos), int(has_gauss), float(cached))
+
+
+def _rng_state_numpy(state):
+    """Inverse of _rng_state_plain; also accepts the raw numpy tuple older checkpoints of this package hold."""
+    name, keys, pos, has_gauss, cached = state
+    if torch.is_tensor(keys):
+        keys = keys.cpu().numpy()
+    return (str(name), np.asarray(keys).astype(np.uint32), int(pos), int(has_gauss), float(cached))
 
 
 def load_state_dict_any_prefix(model: torch.nn.Module, sd: Dict[str, torch.Tensor]):
