@@ -281,9 +281,9 @@ def main():
     import uaps_amd.unet as _unet
     from uaps_amd import conv as _conv
     _unet._DECODER_STREAMS = not args.single_stream and os.environ.get("UAPS_BENCH_DECODER_STREAMS", "1") != "0"      # (experiment hook)
-    # weight-gradient launches on companion streams of the decoder / main streams (uaps_amd/conv.py: WRW_STREAMS): part of the
-    # headline stream mode; UAPS_WRW_STREAMS=0 is the A/B switch
-    wrw_streams = not args.single_stream and os.environ.get("UAPS_WRW_STREAMS", "1") != "0"
+    # weight-gradient launches on companion streams of the decoder / main streams (uaps_amd/conv.py: WRW_STREAMS): an experiment
+    # switch, UAPS_WRW_STREAMS=1
+    wrw_streams = not args.single_stream and os.environ.get("UAPS_WRW_STREAMS", "0") != "0"      # measured slower: off
     _conv.set_wrw_streams(wrw_streams)
     if os.environ.get("UAPS_BENCH_CPUS"):                   # experiment hook: this process on its first n usable cores (what one of 8 ranks gets)
         os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:int(os.environ["UAPS_BENCH_CPUS"])])

@@ -158,7 +158,8 @@ def lib() -> C.CDLL:
 # planner switches of uaps_conv_set_tuning (include/uaps_hip.h: UAPS_TUNE_*) <- the environment variables the ablation and
 # diagnosis scripts set; the library itself reads no environment
 _TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, None), ("UAPS_DIAG_NO_SMALL", 4, None),
-             ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"), ("UAPS_FWD_TALL", 64, "0"))
+             ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"), ("UAPS_FWD_TALL", 64, "0"),
+             ("UAPS_DIAG_NO_ROW16", 128, None))
 
 
 def _configure_from_environment(l) -> None:

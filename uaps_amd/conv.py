@@ -100,6 +100,11 @@ class wrw_stream:
         return False
 
 
+def _bound_tensors(*bs):
+    """The device bounds (uaps_amd.bounds) a side-stream kernel reads: they must outlive it like its operands."""
+    return tuple(b[0] for b in bs if b is not None)
+
+
 def join_wrw_streams(*_args, end_of_backward: bool = True, **_kwargs) -> None:
     """The current stream waits for every weight-gradient side stream with work outstanding (no host synchronisation).
     end_of_backward=False: a join in the middle of a backward (a bucket's all-reduce) -- the parameters seen so far stay noted."""
@@ -174,7 +179,8 @@ class _timed:
                 kin = Cout if kind == "bwd_data" else Cin
                 if self.name.startswith("conv_sfwd") and "<3, 8, 32, 16," in self.name and 8 < kin <= 32:
                     # <= 16 output channels on a wide map: the persistent kernels of csrc/conv_split_n16.hpp
-                    self.name = ("conv_hp16_bn_kernel" if "_bn_" in self.name else "conv_hp16_kernel") + ("<2>" if kin <= 16 else "<4>")
+                    row = W == 256 and H % 16 == 0 and not (_lib.lib().uaps_conv_get_tuning() & 128)      # csrc/conv_fwd.hip: launch_hr16
+                    self.name = ("conv_h%s16_bn_kernel" if "_bn_" in self.name else "conv_h%s16_kernel") % ("r" if row else "p") + ("<2>" if kin <= 16 else "<4>")
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
                 if self.name.startswith("conv_hwrw") and "_kernel<4, 1, " in self.name and H >= 8 and not (_lib.lib().uaps_conv_get_tuning() & 32):
@@ -372,7 +378,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     L = _lib.lib()
     n = C.c_size_t()
     _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-    with _lib.device_guard(dev), wrw_stream(dev, (dy, x), (wkey, bkey)) as side:
+    with _lib.device_guard(dev), wrw_stream(dev, (dy, x) + _bound_tensors(dyb, xb), (wkey, bkey)) as side:
         ws = _workspace(dev, n.value)
         dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
         db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
@@ -525,7 +531,7 @@ class _Conv2dCat(torch.autograd.Function):
             if ctx.needs_input_grad[2] or want_db:
                 n = C.c_size_t()
                 _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-                with wrw_stream(dev, (dy, x1, x2), ctx.keys) as side:
+                with wrw_stream(dev, (dy, x1, x2) + _bound_tensors(dyb, b1, b2), ctx.keys) as side:
                     st = _lib.current_stream(dev)
                     ws = _workspace(dev, n.value)
                     dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)

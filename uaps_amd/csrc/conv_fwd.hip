@@ -6,6 +6,7 @@
 #include "conv_kernels.hpp"
 #include "conv_split.hpp"
 #include "conv_split_n16.hpp"
+#include "conv_split_row16.hpp"
 #include "conv_small.hpp"
 #include "conv_gemm1x1.hpp"
 #include "hints.hpp"
@@ -116,6 +117,23 @@ int launch_hp16(ConvFwdArgs a, hipStream_t s) {
     } else {
         if (a.xf) UAPS_LAUNCH_MAIN((conv_hp16_bn_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
         else UAPS_LAUNCH_MAIN((conv_hp16_kernel<4>), dim3(grid), dim3(kConvThreads), 0, s, a);
+    }
+    return (int)hipGetLastError();
+}
+
+// full-width-row kernels of conv_split_row16.hpp (fp16 form, 256-pixel-wide maps, H % 16 == 0): runs of 16 rows, 2 workgroups of
+// 256 threads per CU for 16 input channels, 1 workgroup of 512 threads (135 KB of LDS) for 32
+int launch_hr16(ConvFwdArgs a, hipStream_t s) {
+    const long nruns = (long)a.B * (a.H / 16);
+    if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
+    const long want = a.Cin <= 16 ? 512 : 256;
+    const unsigned grid = (unsigned)(((nruns < want ? nruns : want) + 7) / 8 * 8);
+    if (a.Cin <= 16) {
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16_bn_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hr16_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+        if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16_bn_kernel<4>), dim3(grid), dim3(512), 0, s, a);
+        else UAPS_LAUNCH_MAIN((conv_hr16_kernel<4>), dim3(grid), dim3(512), 0, s, a);
     }
     return (int)hipGetLastError();
 }
@@ -316,7 +334,10 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         if (p.s32 && p.s32t) return launch_s32t(a, s);
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
-        if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) return launch_hp16(a, s);
+        if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) {
+            if (W == 256 && H % 16 == 0 && !(g_conv_tuning & UAPS_TUNE_NO_ROW16)) return launch_hr16(a, s);
+            return launch_hp16(a, s);
+        }
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
         return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);
     }

@@ -19,7 +19,12 @@ template <int NCG, bool XF>
 __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
     constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 8, PLANE = IH * IW, XS = 3;
     constexpr int NQ = 9 * NCG, NSTEP = (NQ + 3) / 4;
-    constexpr int UPR = IW / 4, UPC = IH * UPR, NUNITS = NCG * UPC, NU = (NUNITS + kConvThreads - 1) / kConvThreads;
+    // staging: a WAVE stages one channel group (WPC waves share a group's UPC units), so that the source tensor of a two-tensor
+    // input and the BatchNorm coefficients are wave-uniform -- with units dealt out by thread id the buffer descriptor differed
+    // between the lanes of a wave and every global load became a waterfall loop whose results were waited for at once
+    // (round 4: the prefetch of the next tile was not a prefetch at all)
+    constexpr int UPR = IW / 4, UPC = IH * UPR, WPC = 4 / NCG, NU = (UPC + 64 * WPC - 1) / (64 * WPC);
+    static_assert(NCG == 2 || NCG == 4, "one or two waves per channel group");
     constexpr int MW = 4;                             // M tiles (16 pixels) per wave: 2 rows x 2 halves
 
     __shared__ __attribute__((aligned(16))) u32x4 sIn[2 * NCG * PLANE];      // [piece][channel group][row][column]
@@ -39,6 +44,8 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
     const int bid = xcd_swizzle(blockIdx.x, gridDim.x), nblk = gridDim.x;
     const int t_begin = (int)((long)ntiles * bid / nblk), t_end = (int)((long)ntiles * (bid + 1) / nblk);
     if (t_begin >= t_end) return;
+    UAPS_STAMP_DECL;      // phases (diagnostic build only): 0 prologue + weight fragments, 1 first tile fetched + stored, per tile: 2 load issue,
+                          // 3 matrix loop, 4 epilogue stores, 5 barrier, 6 wait + split + LDS stores, 7 barrier
 
     // ---- weight fragments, once: lane (n = j, k-group kq) of step s holds k-group q = 4 s + kq = (tap q / NCG, channel group q % NCG) ----
     bf16x8 bfr[NSTEP][2];
@@ -59,18 +66,20 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
     const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
     const float sh = stats_shift(a, co, co_ok);
 
-    // ---- staging units: 4 consecutive pixels x the 8 channels of one channel group ----
-    int ucg[NU], ur[NU], ucu[NU], uloff[NU];
+    // ---- staging units: 4 consecutive pixels x the 8 channels of this wave's channel group ----
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int ucg = wave_u / WPC;                     // wave-uniform
+    int ur[NU], ucu[NU], uloff[NU];
     bool has[NU];
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
-        const int u = tid + n * kConvThreads;
-        has[n] = u < NUNITS;
-        ucg[n] = u / UPC; ur[n] = (u % UPC) / UPR; ucu[n] = u % UPR;
-        uloff[n] = (ucg[n] * IH + ur[n]) * IW + ucu[n] * 4;
+        const int u = (n * WPC + wave_u % WPC) * 64 + lane;
+        has[n] = u < UPC;
+        ur[n] = u / UPR; ucu[n] = u % UPR;
+        uloff[n] = (ucg * IH + ur[n]) * IW + ucu[n] * 4;
     }
     float rin[NU][8][4];
-    f32x2 rxf[XF ? NU : 1][XF ? 8 : 1];      // (scale, shift) of this thread's channels: reloaded only when the statistics group changes
+    f32x2 rxf[XF ? 8 : 1];                   // (scale, shift) of this wave's channels: reloaded only when the statistics group changes
     int xf_group = -1;
     bool uin[NU], uin_next[NU];
 
@@ -90,26 +99,34 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
                 xf_group = g;
                 const __amdgpu_buffer_rsrc_t rs_xf = make_rsrc(a.xf + (size_t)g * a.Cin, (uint32_t)a.Cin * 8u);
 #pragma unroll
-                for (int n = 0; n < NU; ++n)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c)       // channels past Cin read (0, 0)
-                        rxf[n][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, (int)((uint32_t)(ucg[n] * 8 + c) * 8u), 0, 0));
+                for (int c = 0; c < 8; ++c)           // channels past Cin read (0, 0)
+                    rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, (int)((uint32_t)(ucg * 8 + c) * 8u), 0, 0));
             }
         }
+        const int c0 = ucg * 8;
+        const bool second = c0 >= a.Csplit;           // wave-uniform: a channel group lies in one source (Csplit % 8 == 0)
+        const __amdgpu_buffer_rsrc_t rs = second ? rs2 : rs1;
+        const uint32_t cbase = (uint32_t)((second ? c0 - a.Csplit : c0) * HW) * 4u;
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
-            const int gy = y0 - 1 + ur[n], gx = x0 - 4 + ucu[n] * 4, c0 = ucg[n] * 8;
+            const int gy = y0 - 1 + ur[n], gx = x0 - 4 + ucu[n] * 4;
             uin_next[n] = has[n] && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 < a.Cin;      // W % 4 == 0: all 4 pixels in or out
-            const bool second = c0 >= a.Csplit;       // a channel group lies in one source (Csplit % 8 == 0)
-            const uint32_t off = (uint32_t)((second ? c0 - a.Csplit : c0) * HW + gy * a.W + gx) * 4u;
+            const uint32_t off = cbase + (uint32_t)(gy * a.W + gx) * 4u;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) buf_load<4>(second ? rs2 : rs1, uin_next[n] ? off + (uint32_t)c * HW4 : kOob, rin[n][c]);
+            for (int c = 0; c < 8; ++c) buf_load<4>(rs, uin_next[n] ? off + (uint32_t)c * HW4 : kOob, rin[n][c]);
         }
     };
     // fetched unit -> two fp16 pieces per element (XF: leaky_relu(fma(y, scale, shift)) first; padding stays zero), into LDS
     auto store_tile = [&]() {
 #pragma unroll
         for (int n = 0; n < NU; ++n) uin[n] = uin_next[n];       // the tile whose registers are being split
+        // the fetched registers are first TOUCHED here: without this the compiler re-arranges them for the packed split arithmetic
+        // right behind the loads (v_mov + s_waitcnt vmcnt(0) in front of the matrix loop: the prefetch was waited for at once)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NU; ++n)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rin[n][c][0]), "+v"(rin[n][c][1]), "+v"(rin[n][c][2]), "+v"(rin[n][c][3]));
 #pragma unroll
         for (int n = 0; n < NU; ++n) {
             if (!has[n]) continue;
@@ -120,7 +137,7 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
                 for (int c2 = 0; c2 < 4; ++c2) {
                     float v0 = rin[n][2 * c2][p], v1 = rin[n][2 * c2 + 1][p];
                     if constexpr (XF) {               // padding pixels stay zero (the coefficients are not zeroed per pixel any more)
-                        const float z0 = __builtin_fmaf(v0, rxf[n][2 * c2].x, rxf[n][2 * c2].y), z1 = __builtin_fmaf(v1, rxf[n][2 * c2 + 1].x, rxf[n][2 * c2 + 1].y);
+                        const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
                         v0 = uin[n] ? __builtin_fmaxf(z0, z0 * a.xf_slope) : 0.f; v1 = uin[n] ? __builtin_fmaxf(z1, z1 * a.xf_slope) : 0.f;
                     }
                     unsigned q0, q1;
@@ -146,12 +163,16 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
         astep[s] = q < NQ ? cg * PLANE + (tap / 3) * IW + (tap % 3) : 0;         // padded k-groups meet zero weights
     }
 
+    UAPS_STAMP(0);
     load_tile(t_begin);
     store_tile();
     __syncthreads();
+    UAPS_STAMP(1);
     for (int t = t_begin; t < t_end; ++t) {
         const bool more = t + 1 < t_end;
         if (more) load_tile(t + 1);
+        UAPS_STAMP(2);
+        UAPS_STAMP_FIRST_MFMA();
 
         f32x4 acc[MW];
 #pragma unroll
@@ -178,6 +199,7 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                       // ... then this unit's MFMAs
         }
 
+        UAPS_STAMP(3);
         // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every M tile ----
         int b, y0, x0, part;
         tile_of(t, b, y0, x0, part);
@@ -203,8 +225,11 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
             sRed[((wave * 4 + kq) * 16 + j) * 2 + 0] = st_s;
             sRed[((wave * 4 + kq) * 16 + j) * 2 + 1] = st_q;
         }
+        UAPS_STAMP(4);
         __syncthreads();                              // every wave is done with the LDS image; the partial sums are visible
+        UAPS_STAMP(5);
         if (more) store_tile();
+        UAPS_STAMP(6);
         if (a.stats != nullptr && tid < 16 && tid < a.Cout) {      // per-tile BatchNorm partial sums, fixed order (see conv_fwd_body)
             float s0 = 0.f, q0 = 0.f;
 #pragma unroll
@@ -212,7 +237,9 @@ __device__ __forceinline__ void conv_hp16_body(const ConvFwdArgs& a) {
             a.stats[((size_t)tid * a.B + b) * tpi + part] = make_float2(s0, q0);
         }
         __syncthreads();
+        UAPS_STAMP(7);
     }
+    UAPS_STAMP_FLUSH();
 }
 
 template <int NCG>

@@ -1,0 +1,248 @@
+// 3x3 forward / input-gradient convolutions with <= 16 output channels on 256-pixel-wide maps (the top level of the U-Net at the
+// metric's image size: in_conv, up4, the input gradients that end in 16 channels; utilities/UAPS_unet.py:36-44, 110, 152), two-piece
+// fp16 form of conv_split.hpp, FULL-WIDTH ROWS (round 4).
+//
+// Why.  These layers are HBM-bound (arithmetic intensity ~36 flop / byte), and the 8 x 32-pixel tiles of conv_hp16_body fetch every
+// channel's tile as 10 row pieces of 160 bytes 1 KiB apart, each a full cache line plus two 16-byte halo pieces of its neighbours:
+// ~20 line requests per KiB.  That pattern alone tops out at 2.1-3.0 TB/s (tools/diag/tile_probe.hip: a copy kernel with the tile
+// kernel's loads and stores, no arithmetic), and in-kernel stamps showed the waves of conv_hp16 parked on the ISSUE of their
+// loads and stores (5.4 k of 17 k cycles per tile each).  The same bytes as whole rows -- every wave-instruction one 1-KiB row of
+// one channel, every row fetched once -- stream at 5.4-5.6 TB/s in the same probe.
+//
+// How.  A workgroup owns ROWS = 16 consecutive rows of one image at full width and walks down them two rows per step.  The staged
+// input lives in an LDS ring of four row slots per channel group (row r in slot (r + 1) & 3), laid out like conv_hp16's image
+// ([piece][channel group][slot][column] of 16-byte units = 8 channels of one pixel, 4 zero units of margin on either side: the image
+// edge), so the A fragment of 16 consecutive pixels is the same conflict-free ds_read_b128.  Per step the two rows below the
+// ring's live rows are fetched into registers (wave = one (row, channel group): 8 loads of 1 KiB), the matrix work of the two output
+// rows runs on the four live rows (M tiles of 16 pixels, K = (tap, channel), weight fragments resident in registers as in conv_hp16),
+// and the fetched rows replace the two rows that fell out of reach.  No row is fetched twice inside a run (two warm-up rows per run
+// of 16), no halo columns exist.  Same arithmetic, k order and results as conv_hp16_body / conv_sfwd_body<3, 8, 32, 16, 16, XF, true>;
+// the BatchNorm partial sums keep the 8 x 32-tile layout of those kernels (uaps_conv_fwd_stats_parts does not depend on which runs).
+#pragma once
+#include "conv_split.hpp"
+
+namespace uaps {
+
+// NCG = input channels / 8 (2 or 4); threads = 128 * NCG (one wave per (row of the pair, channel group)); XF as in conv_fwd_body
+template <int NCG, bool XF>
+__device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
+    constexpr int WIDTH = 256, IW = WIDTH + 8, NSLOT = 4, ROWS = 16, XS = 3;
+    constexpr int NWV = 2 * NCG, NTHR = 64 * NWV, HALF = NWV / 2;
+    constexpr int NQ = 9 * NCG, NSTEP = (NQ + 3) / 4;
+    constexpr int MW = 32 / NWV;                      // M tiles (16 pixels) per wave and step: 2 output rows x 16 tiles over the waves
+    constexpr int NTC = MW / 2;                       // 32-pixel statistics columns per wave
+    constexpr int CGU = NSLOT * IW, PIECE = NCG * CGU;       // 16-byte units between channel groups / pieces
+    static_assert(NCG == 2 || NCG == 4, "16 or 32 input channels");
+
+    __shared__ __attribute__((aligned(16))) u32x4 sIn[2 * PIECE];      // [piece][channel group][slot][column]: 67.6 KB (NCG 2), 135 KB (NCG 4)
+    __shared__ float sRed[NWV * 4 * NTC * 16 * 2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int HW = a.H * a.W;
+    const uint32_t HW4 = (uint32_t)HW * 4u;
+    const int CGP = a.CinP;                           // padded channel groups of the packed split weights
+
+    const f32x2 sc = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
+    const float in_scale = sc.x, out_scale_a = sc.y, out_scale_w = a.wscale[1];
+
+    const int rpi = a.H / ROWS, nruns = a.B * rpi;    // runs per image (H % 16 == 0: the launcher checks)
+    const int nblk = gridDim.x;
+    int run = xcd_swizzle(blockIdx.x, gridDim.x);     // consecutive runs share their two boundary rows: one XCD's L2
+    if (run >= nruns) return;
+
+    // ---- weight fragments, once: lane (n = j, k-group kq) of step s holds k-group q = 4 s + kq = (tap q / NCG, channel group q % NCG) ----
+    bf16x8 bfr[NSTEP][2];
+    {
+        const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(2 * 9) * CGP * a.CoutP * 16u);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int q = 4 * s + kq, tap = q / NCG, cg = q % NCG;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t off = q < NQ ? (uint32_t)(((p * 9 + tap) * CGP + cg) * a.CoutP + j) * 16u : kOob;
+                bfr[s][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
+            }
+        }
+    }
+    const int co = j;
+    const bool co_ok = co < a.Cout;
+    const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
+    const float sh = stats_shift(a, co, co_ok);
+
+    // the margins of every row slot (image columns -4 .. -1 and 256 .. 259) are zero for the kernel's life
+    for (int e = tid; e < 2 * NCG * NSLOT * 8; e += NTHR) {
+        const int rowslot = e / 8, c = e % 8;
+        sIn[rowslot * IW + (c < 4 ? c : IW - 8 + c)] = u32x4{0u, 0u, 0u, 0u};
+    }
+
+    // ---- staging: this wave stages channel group scg of row (pair base + srr); lane = pixels 4 lane .. 4 lane + 3 ----
+    const int scg = wave_u % NCG, srr = wave_u / NCG;
+    float rin[8][4];
+    f32x2 rxf[XF ? 8 : 1];
+    bool uin = false;
+    int urow = 0;                                     // the row the registers hold
+    const int c0 = scg * 8;
+    const bool second = c0 >= a.Csplit;               // wave-uniform: a channel group lies in one source (Csplit % 8 == 0)
+
+    auto load_pair = [&](int b, int y1) {             // rows y1 and y1 + 1 of image b
+        const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
+                                                 : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
+        const int gy = y1 + srr;
+        urow = gy;
+        uin = (unsigned)gy < (unsigned)a.H && c0 < a.Cin;
+        const uint32_t off = (uint32_t)((second ? c0 - a.Csplit : c0) * HW + gy * a.W + lane * 4) * 4u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) buf_load<4>(rs, uin ? off + (uint32_t)c * HW4 : kOob, rin[c]);
+    };
+    auto load_xf = [&](int b) {
+        if constexpr (XF) {
+            const __amdgpu_buffer_rsrc_t rs_xf = make_rsrc(a.xf + (size_t)(b / a.xf_Bg) * a.Cin, (uint32_t)a.Cin * 8u);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)               // channels past Cin read (0, 0)
+                rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, (int)((uint32_t)(c0 + c) * 8u), 0, 0));
+        }
+    };
+    // fetched row -> two fp16 pieces per element (XF: leaky_relu(fma(y, scale, shift)) first; rows outside the image stay zero), into its slot
+    auto store_pair = [&]() {
+        // first touch of the fetched registers (see conv_hp16_body: keeps the re-arrangement for the packed arithmetic behind the matrix loop)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rin[c][0]), "+v"(rin[c][1]), "+v"(rin[c][2]), "+v"(rin[c][3]));
+        const int base = (scg * NSLOT + ((urow + 1) & 3)) * IW + 4 + lane * 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            u32x4 p0, p1;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                float v0 = rin[2 * c2][p], v1 = rin[2 * c2 + 1][p];
+                if constexpr (XF) {
+                    const float z0 = __builtin_fmaf(v0, rxf[2 * c2].x, rxf[2 * c2].y), z1 = __builtin_fmaf(v1, rxf[2 * c2 + 1].x, rxf[2 * c2 + 1].y);
+                    v0 = uin ? __builtin_fmaxf(z0, z0 * a.xf_slope) : 0.f; v1 = uin ? __builtin_fmaxf(z1, z1 * a.xf_slope) : 0.f;
+                }
+                unsigned q0, q1;
+                conv_split2h(v0 * in_scale, v1 * in_scale, q0, q1);
+                p0[c2] = q0; p1[c2] = q1;
+            }
+            sIn[base + p] = p0;
+            sIn[PIECE + base + p] = p1;
+        }
+    };
+
+    // ---- matrix work: this wave's output row orr of the pair and its M tiles [tb, tb + MW) ----
+    const int orr = wave_u / HALF, tb = (wave_u % HALF) * MW;
+    int abase[MW], kxo[NSTEP], kyv[NSTEP];
+#pragma unroll
+    for (int m = 0; m < MW; ++m) abase[m] = (tb + m) * 16 + j + XS;
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int q = 4 * s + kq, qq = q < NQ ? q : 0, tap = qq / NCG, cg = qq % NCG;      // padded k-groups meet zero weights
+        kxo[s] = cg * CGU + tap % 3; kyv[s] = tap / 3;
+    }
+    float st_s[NTC], st_q[NTC];
+#pragma unroll
+    for (int i = 0; i < NTC; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    const int tiles8 = a.H / 8, tpi = tiles8 * 8;     // statistics parts per image: 8-row x 32-pixel tiles, as the tile kernels write them
+
+    {
+        const int b = run / rpi, r0 = (run % rpi) * ROWS;
+        load_pair(b, r0 - 1);
+    }
+    for (; run < nruns; run += nblk) {
+        const int b = run / rpi, r0 = (run % rpi) * ROWS;
+        const bool next_run = run + nblk < nruns;
+        load_xf(b);
+        store_pair();                                 // rows r0 - 1, r0
+        load_pair(b, r0 + 1);
+        store_pair();                                 // rows r0 + 1, r0 + 2
+        __syncthreads();
+        // branch-free output stores (lanes of padded channels store out of range): a store inside a branch makes the compiler's
+        // vmcnt bookkeeping conservative, and the wait for the prefetched rows then also waits for this step's stores
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
+        const uint32_t out_c = co_ok ? (uint32_t)co * HW4 : kOob;
+#pragma unroll 1
+        for (int k = 0; k < ROWS / 2; ++k) {
+            const int y = r0 + 2 * k;                 // output rows y, y + 1 from input rows y - 1 .. y + 2
+            if (k + 1 < ROWS / 2) load_pair(b, y + 3);
+            else if (next_run) { const int nr = run + nblk; load_pair(nr / rpi, (nr % rpi) * ROWS - 1); }
+
+            int aoff[NSTEP];
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) aoff[s] = kxo[s] + ((y + orr + kyv[s]) & 3) * IW;     // input row y + orr + ky - 1 -> its slot
+            f32x4 acc[MW];
+#pragma unroll
+            for (int m = 0; m < MW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            constexpr int NUN = NSTEP * MW;
+            bf16x8 af[2][2];
+            auto read_a = [&](int u, bf16x8 (&dst)[2]) {
+                const int s = u / MW, m = u % MW;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) dst[p] = __builtin_bit_cast(bf16x8, sIn[p * PIECE + abase[m] + aoff[s]]);
+            };
+            read_a(0, af[0]);
+#pragma unroll
+            for (int u = 0; u < NUN; ++u) {
+                const int s = u / MW, m = u % MW;
+                if (u + 1 < NUN) read_a(u + 1, af[(u + 1) & 1]);
+                const auto H = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
+                f32x4 c = acc[m];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][1]), H(bfr[s][0]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s][1]), c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s][0]), c, 0, 0, 0);
+                acc[m] = c;
+                if (u + 1 < NUN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // next unit's DS reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                       // ... then this unit's MFMAs
+            }
+
+            // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every M tile ----
+            const int gy = y + orr;
+            float chk = 0.f;
+#pragma unroll
+            for (int m = 0; m < MW; ++m) {
+                const int gx = (tb + m) * 16 + kq * 4;
+                f32x4 v = acc[m];
+                v *= out_scale_a; v *= out_scale_w;   // exact: powers of two
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                note_nonfinite(chk, v);               // (padded channels hold exact zeros: zero weights, no bias)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)(out_c + (uint32_t)(gy * a.W + gx) * 4u), 0, 0);
+                const f32x4 d = v - sh;
+                st_s[m / 2] += (d.x + d.y) + (d.z + d.w);
+                st_q[m / 2] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+            report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
+            const bool band_end = (k & 3) == 3;       // an 8-row band of statistics tiles is complete
+            if (a.stats != nullptr && band_end) {
+#pragma unroll
+                for (int i = 0; i < NTC; ++i) {
+                    sRed[(((wave * 4 + kq) * NTC + i) * 16 + j) * 2 + 0] = st_s[i];
+                    sRed[(((wave * 4 + kq) * NTC + i) * 16 + j) * 2 + 1] = st_q[i];
+                    st_s[i] = 0.f; st_q[i] = 0.f;
+                }
+            }
+            __syncthreads();                          // every wave is done with the rows that fall out of reach; the partial sums are visible
+            if (k + 1 < ROWS / 2) store_pair();
+            if (a.stats != nullptr && band_end && tid < 128 && (tid & 15) < a.Cout) {
+                // per-tile BatchNorm partial sums, fixed order: the tile's column tc lies with the waves (orr 0 / 1, tc / NTC), 4 lane groups each
+                const int tc = tid >> 4, ch = tid & 15, wv = tc / NTC, i = tc % NTC;
+                float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+                for (int o = 0; o < 2; ++o)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int e = ((((o * HALF + wv) * 4 + g) * NTC + i) * 16 + ch) * 2;
+                        s0 += sRed[e]; q0 += sRed[e + 1];
+                    }
+                a.stats[((size_t)ch * a.B + b) * tpi + ((r0 + 2 * k) / 8) * 8 + tc] = make_float2(s0, q0);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NCG>
+__global__ __launch_bounds__(128 * NCG) void conv_hr16_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false>(a); }
+template <int NCG>
+__global__ __launch_bounds__(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
+
+}  // namespace uaps

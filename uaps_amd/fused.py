@@ -246,7 +246,7 @@ class _BnActConv(torch.autograd.Function):
         want_db = has_bias and ctx.needs_input_grad[13]
         with _lib.device_guard(dev):
             # the weight gradient (input re-activated while staging) on the companion stream (conv.wrw_stream; off: this stream)
-            with _conv.wrw_stream(dev, (dz, y, xf), ctx.keys[3:5]) as side:
+            with _conv.wrw_stream(dev, (dz, y, xf) + _conv._bound_tensors(dzb, xb), ctx.keys[3:5]) as side:
                 st = _lib.current_stream(dev)
                 cws = _conv._workspace(dev, n.value)
                 dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
