@@ -130,7 +130,7 @@ def other_configs(steps, dev):
     for tag, name, net, in_chns, classes, aux, batch, size in (
             ("configs3", "configs[3]: UAPS K=5 decoders, DAGM-shaped 1x512x512 2-class, batch 8+8", "unet_uaps", 1, 2, 5, 8, 512),
             ("configs4", "configs[4] per-GPU shape: UAPS ResNet-50 encoder K=3, KoSDD2-shaped 3x640x640 2-class, batch 8+8", "resnet50_uaps", 3, 2, 3, 8, 640)):
-        streams, wrw = _unet._DECODER_STREAMS, conv.WRW_STREAMS
+        streams = _unet._DECODER_STREAMS
         try:
             torch.manual_seed(1337)
             model = uaps_amd.net_factory(net, in_chns, classes, n_aux=aux)
@@ -155,7 +155,6 @@ def other_configs(steps, dev):
                    "launch_mode": ("captured hipGraph replayed per step, " if graph_used else "eager, ") + "one HIP stream per auxiliary decoder"}
             # ---- one single-stream eager step with events on every conv launch: flops, dominant kernel, roofline ----
             _unet._DECODER_STREAMS = False
-            conv.set_wrw_streams(False)
             trainer.step_graph, trainer.optimizer.from_step_state = None, False
             trainer.train_step(*data.next())
             torch.cuda.synchronize()
@@ -198,7 +197,6 @@ def other_configs(steps, dev):
         finally:
             conv.KERNEL_EVENTS = None
             _unet._DECODER_STREAMS = streams
-            conv.set_wrw_streams(wrw)
         gc.collect()
         torch.cuda.empty_cache()
     return out
@@ -279,12 +277,7 @@ def main():
     from uaps_amd import losses
 
     import uaps_amd.unet as _unet
-    from uaps_amd import conv as _conv
-    _unet._DECODER_STREAMS = not args.single_stream and os.environ.get("UAPS_BENCH_DECODER_STREAMS", "1") != "0"      # (experiment hook)
-    # weight-gradient launches on companion streams of the decoder / main streams (uaps_amd/conv.py: WRW_STREAMS): an experiment
-    # switch, UAPS_WRW_STREAMS=1
-    wrw_streams = not args.single_stream and os.environ.get("UAPS_WRW_STREAMS", "0") != "0"      # measured slower: off
-    _conv.set_wrw_streams(wrw_streams)
+    _unet._DECODER_STREAMS = not args.single_stream
     if os.environ.get("UAPS_BENCH_CPUS"):                   # experiment hook: this process on its first n usable cores (what one of 8 ranks gets)
         os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:int(os.environ["UAPS_BENCH_CPUS"])])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,7 +387,6 @@ def main():
     discover, ev, cev, single_ms = None, {}, {}, None
     if args.analysis_steps > 0:                              # every rank steps (the gradient exchange is collective); rank 0's events are reported
         _unet._DECODER_STREAMS = False
-        _conv.set_wrw_streams(False)
         trainer.step_graph, trainer.optimizer.from_step_state = None, False     # eager launches: events can bracket each kernel
         trainer.train_step(*data.next())                   # re-warm in the new mode
         torch.cuda.synchronize()
@@ -419,7 +411,6 @@ def main():
         ev, losses.KERNEL_EVENTS = losses.KERNEL_EVENTS, None
         cev, conv.KERNEL_EVENTS, conv.EVENT_FILTER = conv.KERNEL_EVENTS, None, None
         _unet._DECODER_STREAMS = not args.single_stream
-        _conv.set_wrw_streams(wrw_streams)
     else:
         dominant = None
 
@@ -549,8 +540,6 @@ def main():
                          "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
         mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (same kernels as single-stream)"
-        if wrw_streams:
-            mode += ", weight-gradient launches on a companion stream of each"
         if graph_used and not graph_split:
             mode = "captured hipGraph of the whole step, replayed once per step (the eager step's kernels and arithmetic; DESIGN.md section 4 on bit reproducibility); " + mode
         elif graph_split:

@@ -1,14 +1,13 @@
 #!/bin/bash
-# How much concurrency pays: hardware queues x stream modes, headline protocol, one box.
+# How much launch concurrency pays: hardware queues (GPU_MAX_HW_QUEUES) under the headline stream mode (one stream per auxiliary
+# decoder), one box.  Round 4 also tried a companion stream per decoder stream for the weight-gradient launches (8 streams):
+# 14.13 -> 14.8-15.0 ms on 4 hardware queues, 20.7 ms on 8 -- more concurrent kernels thrash each other; the mechanism was removed.
 export TMPDIR=/tmp
 OUT=gpurun_out/ab_queues.txt
 : > $OUT
 B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --other-configs 0 --analysis-steps 0 --exact-steps 0"
 one() { echo "== $1" | tee -a $OUT; shift; env "$@" 2>>gpurun_out/ab_queues.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['step_ms']['p50'])" | tee -a $OUT; }
-for q in 1 2 3 4; do
-  one "decoder streams, wrw=0, hwq=$q" UAPS_WRW_STREAMS=0 GPU_MAX_HW_QUEUES=$q $B
+for q in 1 2 3 4 8; do
+  one "decoder streams, hwq=$q" GPU_MAX_HW_QUEUES=$q $B
 done
-one "decoder streams off, wrw=1, hwq=4" UAPS_WRW_STREAMS=1 UAPS_BENCH_DECODER_STREAMS=0 $B
-one "decoder streams off, wrw=1, hwq=2" UAPS_WRW_STREAMS=1 UAPS_BENCH_DECODER_STREAMS=0 GPU_MAX_HW_QUEUES=2 $B
-one "decoder streams, wrw=1, hwq=2" UAPS_WRW_STREAMS=1 GPU_MAX_HW_QUEUES=2 $B
-one "decoder streams, wrw=0, default" UAPS_WRW_STREAMS=0 $B
+one "single stream" $B --single-stream

@@ -9,12 +9,11 @@ fallback on this path: CPU tensors are refused.
 from __future__ import annotations
 
 import ctypes as C
-import os
 import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
-from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import _graddest, _lib, bounds
 
@@ -26,105 +25,6 @@ _packed: Dict[int, tuple] = {}
 _generation = 0
 
 
-# ---- weight-gradient launches on a side stream ----------------------------------------------------------------------------------
-# In a backward the input gradient of a convolution heads the chain the rest of the backward waits for, while its weight
-# gradient is needed by the optimizer only.  With WRW_STREAMS on, every stream that runs conv backwards gets a companion stream:
-# the weight-gradient launches (partial sums + fixed-order reduce: same kernels, same arithmetic, same results) are enqueued
-# there behind an event of the launching stream, so they overlap the input-gradient / BatchNorm-backward chain -- and each
-# other's ramps and tails, since a 512-workgroup launch leaves every CU room for a second kernel's workgroups -- instead of
-# sitting between two links of that chain.  Contract of the mode (UAPSTrainer keeps it; bench.py turns the mode on):
-#   * parameter gradients are None when the backward starts (zero_grad(set_to_none=True): autograd then adopts the tensors the
-#     kernels write; an accumulating `+=` would run on the launching stream, beside the side stream's kernel);
-#   * join_wrw_streams() before anything reads a gradient: the trainers call it behind backward(), dist.GradBuckets in front
-#     of a bucket's all-reduce, and a global optimizer pre-step hook joins as a last resort.
-# A parameter that gets a second gradient inside one backward (two forwards of one model) joins at once.
-WRW_STREAMS = os.environ.get("UAPS_WRW_STREAMS", "0") != "0"
-_side_of: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}      # (device, raw launching stream) -> its weight-gradient stream
-_side_dirty: Dict[int, "torch.cuda.Stream"] = {}               # side streams with launches since the last join
-_side_keys: set = set()                                        # parameters whose gradient a side stream writes since the last join
-_SIDE_KEEP: list = []                                          # under capture: what the side-stream kernels touch lives as long as the graph
-
-
-class wrw_stream:
-    """`with wrw_stream(dev, reads, keys):` -- the launches inside run on the companion stream of the current stream (see
-    WRW_STREAMS; nothing happens when the mode is off).  reads: tensors the launches read that other streams own; keys: ids of the
-    parameters whose gradients are written inside (allocated inside: they belong to the side stream)."""
-    __slots__ = ("dev", "reads", "keys", "cur", "side", "ctx", "made")
-
-    def __init__(self, dev, reads=(), keys=()):
-        self.dev, self.reads, self.keys, self.side = dev, reads, keys, None
-
-    def __enter__(self):
-        if not WRW_STREAMS:
-            return self
-        cur = torch.cuda.current_stream(self.dev)
-        key = (self.dev.index, cur.cuda_stream)
-        side = _side_of.get(key)
-        if side is None:
-            side = _side_of[key] = torch.cuda.Stream(device=self.dev)
-        side.wait_stream(cur)
-        self.cur, self.side = cur, side
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def written(self, *tensors):
-        """Gradient tensors produced inside the block (read later by the launching / joining stream)."""
-        self.made = tensors
-        return tensors
-
-    def __exit__(self, *a):
-        side = self.side
-        if side is None:
-            return False
-        self.ctx.__exit__(*a)
-        made = getattr(self, "made", ())
-        if torch.cuda.is_current_stream_capturing():
-            _SIDE_KEEP.extend(t for t in self.reads if t is not None)
-            _SIDE_KEEP.extend(t for t in made if t is not None)
-        else:
-            for t in self.reads:
-                if t is not None:
-                    t.record_stream(side)
-            for t in made:
-                if t is not None:
-                    t.record_stream(self.cur)
-        _side_dirty[side.cuda_stream] = side
-        again = False
-        for k in self.keys:
-            if k is not None:
-                again = again or k in _side_keys
-                _side_keys.add(k)
-        if again:                      # autograd is about to add this gradient to the first one, on the launching stream
-            self.cur.wait_stream(side)
-        return False
-
-
-def _bound_tensors(*bs):
-    """The device bounds (uaps_amd.bounds) a side-stream kernel reads: they must outlive it like its operands."""
-    return tuple(b[0] for b in bs if b is not None)
-
-
-def join_wrw_streams(*_args, end_of_backward: bool = True, **_kwargs) -> None:
-    """The current stream waits for every weight-gradient side stream with work outstanding (no host synchronisation).
-    end_of_backward=False: a join in the middle of a backward (a bucket's all-reduce) -- the parameters seen so far stay noted."""
-    if _side_dirty:
-        cur = torch.cuda.current_stream()
-        for side in _side_dirty.values():
-            if side.device == cur.device:
-                cur.wait_stream(side)
-        _side_dirty.clear()
-    if end_of_backward:
-        _side_keys.clear()
-
-
-def set_wrw_streams(on: bool) -> None:
-    global WRW_STREAMS
-    if not on and torch.cuda.is_available():
-        join_wrw_streams()
-    WRW_STREAMS = bool(on)
-
-
 def invalidate_packed_weights(*_args, **_kwargs) -> None:
     """Forget every packed weight buffer.  Runs automatically after each `optimizer.step()` of any
     torch.optim optimizer; call it yourself after writing to parameters through `.data` or other
@@ -134,7 +34,6 @@ def invalidate_packed_weights(*_args, **_kwargs) -> None:
 
 
 register_optimizer_step_post_hook(invalidate_packed_weights)
-register_optimizer_step_pre_hook(join_wrw_streams)      # last resort: an optimizer never reads a gradient a side stream is still writing
 
 
 # bench.py sets KERNEL_EVENTS to a dict {kernel instantiation name: [(start_event, end_event, flops), ...]}
@@ -370,19 +269,17 @@ def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg
 
 def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None,
                         dyb=None, xb=None):
-    """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest).
-    Runs on the companion stream of the current stream when WRW_STREAMS is on (wrw_stream)."""
+    """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest)."""
     B, Cout, H, W = dy.shape
     Cin = x.shape[1]
     dev = dy.device
     L = _lib.lib()
     n = C.c_size_t()
     _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-    with _lib.device_guard(dev), wrw_stream(dev, (dy, x) + _bound_tensors(dyb, xb), (wkey, bkey)) as side:
-        ws = _workspace(dev, n.value)
-        dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
-        db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
-        side.written(dw, db)
+    ws = _workspace(dev, n.value)
+    dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
+    db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
+    with _lib.device_guard(dev):
         st = _lib.current_stream(dev)
         with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, _h16(dyb, xb)):
             if dyb is not None and xb is not None:
@@ -392,7 +289,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
         _lib.check(rc, "uaps_conv_bwd_weight_partial")
         rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_bias else None, B, Cin, Cout, H, W,
                                            ks, cfg, st)
-        _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+    _lib.check(rc, "uaps_conv_bwd_weight_reduce")
     return dw, db
 
 
@@ -531,21 +428,18 @@ class _Conv2dCat(torch.autograd.Function):
             if ctx.needs_input_grad[2] or want_db:
                 n = C.c_size_t()
                 _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-                with wrw_stream(dev, (dy, x1, x2) + _bound_tensors(dyb, b1, b2), ctx.keys) as side:
-                    st = _lib.current_stream(dev)
-                    ws = _workspace(dev, n.value)
-                    dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
-                    db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
-                    side.written(dw, db)
-                    with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0, _h16(dyb, b1, b2)):
-                        if dyb is not None and b1 is not None and b2 is not None:
-                            _lib.hints((dyb, b1, b2))
-                        rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
-                                                                H, W, ks, 0, ws.data_ptr(), ws.numel(), st)
-                    _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
-                    rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
-                                                       H, W, ks, 0, st)
-                    _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+                ws = _workspace(dev, n.value)
+                dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
+                db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
+                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0, _h16(dyb, b1, b2)):
+                    if dyb is not None and b1 is not None and b2 is not None:
+                        _lib.hints((dyb, b1, b2))
+                    rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
+                                                            H, W, ks, 0, ws.data_ptr(), ws.numel(), st)
+                _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
+                rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
+                                                   H, W, ks, 0, st)
+                _lib.check(rc, "uaps_conv_bwd_weight_reduce")
         return dx1, dx2, dw, db, None, None
 
 

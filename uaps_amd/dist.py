@@ -113,9 +113,6 @@ class GradBuckets:
 
     def _launch(self, bi: int):
         flat = self._flat[bi]
-        if flat.is_cuda:                       # gradients written on weight-gradient side streams (conv.WRW_STREAMS) are complete
-            from . import conv                 # for the copies below and for the collective, which orders itself behind this stream
-            conv.join_wrw_streams(end_of_backward=False)
         for k, p in enumerate(self.buckets[bi]):
             v = self._view(bi, k)
             if p.grad is None:
@@ -166,9 +163,6 @@ class GradBuckets:
         """All buckets at once, no hooks involved (between the two replays of graph.StepGraph): all-reduce, wait, average."""
         if self.world == 1:
             return
-        if self._flat and self._flat[0].is_cuda:
-            from . import conv
-            conv.join_wrw_streams()
         hs = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self._flat]
         inv = 1.0 / self.world
         for flat, h in zip(self._flat, hs):

@@ -243,28 +243,24 @@ class _BnActConv(torch.autograd.Function):
         da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, dyb=dzb)
         n = C.c_size_t()
         _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
+        cws = _conv._workspace(dev, n.value)
+        dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
         want_db = has_bias and ctx.needs_input_grad[13]
+        db = _graddest.take(ctx.keys[4], (Cout,), dev) if want_db else None
+        dy = torch.empty_like(y)
+        dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys[:3]]      # dgamma, dbeta, d(conv bias) = 0
+        ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
-            # the weight gradient (input re-activated while staging) on the companion stream (conv.wrw_stream; off: this stream)
-            with _conv.wrw_stream(dev, (dz, y, xf) + _conv._bound_tensors(dzb, xb), ctx.keys[3:5]) as side:
-                st = _lib.current_stream(dev)
-                cws = _conv._workspace(dev, n.value)
-                dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
-                db = _graddest.take(ctx.keys[4], (Cout,), dev) if want_db else None
-                side.written(dw, db)
-                with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, 0, _conv._h16(dzb, xb)):
-                    if dzb is not None and xb is not None:
-                        _lib.hints((dzb, xb))
-                    rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
-                                                           Cout, H, W, ks, 0, cws.data_ptr(), cws.numel(), st)
-                _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
-                rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
-                                                   ks, 0, st)
-                _lib.check(rc, "uaps_conv_bwd_weight_reduce")
             st = _lib.current_stream(dev)
-            dy = torch.empty_like(y)
-            dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys[:3]]      # dgamma, dbeta, d(conv bias) = 0
-            ws = _bn_ws(dev, B, Cc, H, W)
+            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, 0, _conv._h16(dzb, xb)):
+                if dzb is not None and xb is not None:
+                    _lib.hints((dzb, xb))
+                rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
+                                                       Cout, H, W, ks, 0, cws.data_ptr(), cws.numel(), st)
+            _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
+            rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
+                                               ks, 0, st)
+            _lib.check(rc, "uaps_conv_bwd_weight_reduce")
             am = bounds.new_amax(dev) if bounds.enabled() else None
             if am is not None:
                 _lib.hints((), am)

@@ -126,7 +126,6 @@ class StepGraph:
         out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
         tr.optimizer.zero_grad(set_to_none=True)
         out.loss.backward()
-        conv.join_wrw_streams()                      # inside a capture: the side-stream branches rejoin the capturing stream
         return out, both
 
     def _tail(self, both, x_l, y_l):
@@ -228,8 +227,6 @@ class StepGraph:
         tr = self.tr
         dev = tr.device
         self.static = {"x_l": x_l.clone(), "y_l": y_l.clone(), "x_u": x_u.clone()}
-        conv.join_wrw_streams()
-        conv._SIDE_KEEP.clear()                      # what the previous capture's side-stream kernels touched
         conv.invalidate_packed_weights()             # the weight packing must be part of the captured step
         bounds.reset_pool()                          # ... and so must the zero fill of every max|.| scalar the kernels raise
         tr.optimizer.zero_grad(set_to_none=True)
@@ -259,7 +256,6 @@ class StepGraph:
         self.static["out"], self.static["cm"] = out, cm
         # the graph writes the packed weights through raw pointers: hold the buffers, whatever the cache does later
         self.static["packed"] = [(e[3], e[4]) for e in conv._packed.values()]
-        self.static["side_keep"], conv._SIDE_KEEP = conv._SIDE_KEEP, []      # tensors the weight-gradient branches read / wrote
         # the capture executed nothing (and its host-side Adam counter bump belongs to no step): undo that, then run the step
         opt = tr.optimizer
         steps = [opt.state[p]["step"] for gr in opt.param_groups for p in gr["params"] if p in opt.state]

@@ -15,7 +15,6 @@ import numpy as np
 import torch
 
 from . import _lib
-from . import conv as _conv
 from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
@@ -130,7 +129,6 @@ class UAPSTrainer:
                 out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
         self.optimizer.zero_grad(set_to_none=True)                                # :285
         out.loss.backward()                                                       # :287
-        _conv.join_wrw_streams()                         # weight-gradient side streams (conv.WRW_STREAMS) rejoin the step's stream
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :292
@@ -310,7 +308,6 @@ class BaselineTrainer(UAPSTrainer):
         s = losses.uaps_sup_loss((main,), y_l)                                    # :161-164, 0.5 * (dice + CE)
         self.optimizer.zero_grad(set_to_none=True)                                # :166
         s.loss.backward()                                                         # :168
-        _conv.join_wrw_streams()
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :173
