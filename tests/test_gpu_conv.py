@@ -53,6 +53,13 @@ SHAPES = [
     # 32-channel blocks on 16-row tiles (csrc/conv_split.hpp, MR = 4): >= 512 tiles of 16 x 32 pixels, ragged in both directions
     (5, 24, 32, 200, 264, 3),
     (4, 32, 32, 256, 256, 3),
+    # 256-wide maps, <= 16 output channels: the full-width-row kernels (csrc/conv_split_row16.hpp forward / input gradient,
+    # csrc/conv_split_wrw_row.hpp weight gradient) in the fp16 form; runs of 16 rows, several runs per workgroup at B = 40
+    (2, 16, 16, 32, 256, 3),
+    (3, 32, 16, 48, 256, 3),
+    (2, 16, 4, 32, 256, 3),     # out_conv: 4 classes on one padded 16-channel tile
+    (2, 32, 12, 16, 256, 3),
+    (40, 16, 16, 256, 256, 3),
 ]
 
 
@@ -142,7 +149,8 @@ def test_conv_refuses_cpu_tensors():
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16),
                                             (4, 32, 32, 256, 256), (4, 16, 64, 252, 256),           # these two: persistent slice kernels
-                                            (6, 24, 32, 200, 264)])          # 32-channel block on 16-row tiles, the last one half outside: parts stay per 8 rows
+                                            (6, 24, 32, 200, 264),          # 32-channel block on 16-row tiles, the last one half outside: parts stay per 8 rows
+                                            (4, 16, 16, 64, 256), (3, 32, 16, 32, 256), (2, 16, 10, 48, 256)])     # full-width-row kernels: parts stay 8 x 32 tiles
 def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
     """conv2d_with_stats: the per-tile (sum, sum of squares) written by the conv epilogue must add up to the
     statistics of y, and bn_act fed with them must equal bn_act running its own statistics pass."""
@@ -169,7 +177,8 @@ def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,C1,C2,Cout,H,W,ks", [(2, 16, 16, 16, 64, 64, 3), (2, 32, 32, 32, 32, 32, 3), (1, 128, 128, 128, 16, 16, 3),
-                                                  (2, 16, 24, 20, 24, 40, 3), (2, 32, 16, 8, 16, 16, 1), (4, 16, 16, 32, 256, 256, 3)])
+                                                  (2, 16, 24, 20, 24, 40, 3), (2, 32, 16, 8, 16, 16, 1), (4, 16, 16, 32, 256, 256, 3),
+                                                  (3, 16, 16, 16, 32, 256, 3)])      # two tensors into the full-width-row kernels
 def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
     """conv2d_cat(x1, x2, w) must be conv2d(cat([x1, x2]), w) bit for bit (same kernels, same order of operations),
     and so must its three gradients."""

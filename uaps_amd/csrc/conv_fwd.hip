@@ -309,7 +309,12 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     const bool wide = p.tw == 32;
     // a side with <= 4 channels: the exact-N fp32 kernels (no BatchNorm statistics epilogue, one tensor per side)
     const bool no_small = (g_conv_tuning & UAPS_TUNE_NO_SMALL) != 0;
-    if (!no_small && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
+    // (on 256-wide maps with bounded operands the full-width-row kernel serves <= 4 output channels too: padded to one 16-channel
+    // MFMA tile it streams at the HBM rate of a 16 -> 16 layer, which the 16 x 64-tile VALU kernel does not reach)
+    const bool row16 = p.split && conv_mode() == 2 && hints.bound[0] && ks == 3 && p.dil == 1 && W == 256 && H % 16 == 0 && p.CoutP == 16 &&
+                       Cin > 8 && Cin <= 32 && Cin % 8 == 0 && !y2 && (!x2 || Csplit >= Cin || hints.bound[1]) &&
+                       !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16));
+    if (!no_small && !row16 && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
     if (p.split) {
         // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
         a.wp = wp + (size_t)ks * ks * p.CinP * p.CoutP;

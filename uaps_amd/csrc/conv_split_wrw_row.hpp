@@ -1,0 +1,253 @@
+// Weight gradient of the 3x3 convolutions with <= 16 output channels and 16 / 32 input channels on 256-pixel-wide maps (the top
+// level of the U-Net at the metric's image size), two-piece fp16 form of conv_split_wrw.hpp, FULL-WIDTH ROWS (round 4).
+//
+// Same reason as conv_split_row16.hpp: these launches are HBM-bound, and the 4 / 8-row x 32-pixel tiles of conv_swrw_body read
+// every channel's tile as 128-byte row pieces 1 KiB apart plus two neighbour pixels per piece -- three line requests per piece; the
+// access pattern, not the arithmetic, set their time (2.3 TB/s at 32 -> 16 channels, B = 128).  Here a workgroup owns runs of 16
+// consecutive rows of one image at full width and walks down them one row per step: per step it fetches ONE new input row of
+// every channel and ONE dy row (every wave-instruction a 1-KiB row of one channel), keeps three input rows and the dy row in LDS
+// ([piece][channel][slot][34 groups of 8 pixels]: a zero group on either side is the image edge) and contracts dy row y with
+// the input rows y - 1, y, y + 1 over the row's 8 segments of 32 pixels.  The column taps come from the aligned fragment and the
+// neighbour groups' boundary dwords (v_alignbit), as in the dilated form of conv_swrw_body -- no edge loads at all.  A wave owns
+// two segments (the K dimension is split over the waves), the nine tap accumulators are summed over the waves at the end and go to
+// the same per-split slabs conv_swrw_body writes: plan, workspace and conv_wrw_reduce_kernel are unchanged.
+// Same arithmetic as conv_swrw_body<.., H16 = true> (fp32 accumulation of the three partial products); the order in which pixels
+// enter the sums differs, so the results agree to rounding, not bit for bit.
+#pragma once
+#include "conv_split_wrw.hpp"
+
+namespace uaps {
+
+// WCI = input channels / 16 (1 or 2); threads = 256 * WCI; XF: the input is a raw conv output, BatchNorm + LeakyReLU applied while staging
+template <int WCI, bool XF>
+__device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
+    constexpr int WIDTH = 256, NG = WIDTH / 8, XG = NG + 2, NSLOT = 3, ROWS = 16;
+    constexpr int CI = 16 * WCI, NWV = 4 * WCI, NTHR = 64 * NWV;
+    constexpr int NXL = CI / NWV, NDL = 16 / NWV;        // input / dy channels a wave fetches per row: 4 and 4 (WCI 1) or 4 and 2 (WCI 2)
+    constexpr int XCH = NSLOT * XG;                       // units per input channel
+    constexpr int X_UNITS = 2 * CI * XCH, D_UNITS = 2 * 16 * NG;
+    constexpr int RED_FLOATS = 2 * WCI * 10 * 256;        // cross-wave reduction scratch (aliases the staging image)
+    static_assert(RED_FLOATS / 4 <= X_UNITS, "the reduction scratch fits the input image");
+    static_assert(WCI == 1 || WCI == 2, "16 or 32 input channels");
+
+    __shared__ __attribute__((aligned(16))) u32x4 sX[X_UNITS];      // [piece][ci][slot][group]
+    __shared__ __attribute__((aligned(16))) u32x4 sD[D_UNITS];      // [piece][co][group]
+
+    const f32x2 sd = h16_scale(bound_of(a.dy_bound, a.dy_mul));
+    const f32x2 sx = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
+    const float sc_d = sd.x, inv_d = sd.y, sc_x = sx.x, inv_x = sx.y;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int sp = wave_u % 4, wci = wave_u / 4;          // segment pair (K split) and input-channel block of this wave's matrix work
+    const int HW = a.H * a.W;
+    const uint32_t HW4 = (uint32_t)HW * 4u;
+
+    const int split = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (split >= a.nsplit) return;
+    const int rpi = a.H / ROWS, nruns = a.B * rpi;
+    const int run_begin = (int)((long)nruns * split / a.nsplit), run_end = (int)((long)nruns * (split + 1) / a.nsplit);
+    const bool want_bias = a.bslab != nullptr;
+
+    // zero halo groups (image columns -8 .. -1 and 256 .. 263) of every (piece, channel, slot)
+    for (int e = tid; e < 2 * CI * NSLOT * 2; e += NTHR) sX[(e / 2) * XG + (e % 2) * (XG - 1)] = u32x4{0u, 0u, 0u, 0u};
+
+    // ---- staging: lane = pixels 4 lane .. 4 lane + 3 (half of an 8-pixel unit) of NXL input channels and NDL dy channels ----
+    float rx[NXL][4], rd[NDL][4];
+    f32x2 cf[XF ? NXL : 1];
+    bool x_in = false, d_in = false;
+    const int xc0 = wave_u * NXL;                        // this wave's input channels xc0 .. xc0 + NXL - 1 lie in one source (Csplit % 4 == 0)
+    const bool second = xc0 >= a.Csplit;
+    auto load_x = [&](int b, int gy, float (&dst)[NXL][4], bool& ok) {
+        ok = (unsigned)gy < (unsigned)a.H;
+        const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
+                                                 : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
+        const uint32_t off = (uint32_t)((second ? xc0 - a.Csplit : xc0) * HW + gy * a.W + lane * 4) * 4u;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) buf_load<4>(rs, (ok && xc0 + i < a.Cin) ? off + (uint32_t)i * HW4 : kOob, dst[i]);
+    };
+    auto load_d = [&](int b, int gy, float (&dst)[NDL][4], bool& ok) {
+        ok = (unsigned)gy < (unsigned)a.H;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dout + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            const int c = wave_u * NDL + i;
+            buf_load<4>(rs, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + lane * 4) * 4u : kOob, dst[i]);
+        }
+    };
+    auto store_x = [&](float (&src)[NXL][4], bool ok, int slot) {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            asm volatile("" : "+v"(src[i][0]), "+v"(src[i][1]), "+v"(src[i][2]), "+v"(src[i][3]));      // first touch (conv_hp16_body)
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = src[i][k];
+                if constexpr (XF) {                    // leaky_relu(fma(y, scale, shift)); rows outside the image stay zero
+                    const float z = __builtin_fmaf(v[k], cf[i].x, cf[i].y);
+                    v[k] = ok ? __builtin_fmaxf(z, z * a.xf_slope) : 0.f;
+                }
+            }
+            unsigned a0, a1, b0, b1;
+            conv_split2h(v[0] * sc_x, v[1] * sc_x, a0, a1);
+            conv_split2h(v[2] * sc_x, v[3] * sc_x, b0, b1);
+            const int c = wave_u * NXL + i;
+            unsigned* p0 = reinterpret_cast<unsigned*>(&sX[(c * NSLOT + slot) * XG + 1]) + lane * 2;      // 8 bytes per lane, consecutive
+            unsigned* p1 = reinterpret_cast<unsigned*>(&sX[((CI + c) * NSLOT + slot) * XG + 1]) + lane * 2;
+            *reinterpret_cast<uint2*>(p0) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(p1) = make_uint2(a1, b1);
+        }
+    };
+    auto store_d = [&](float (&src)[NDL][4]) {
+#pragma unroll
+        for (int i = 0; i < NDL; ++i) {
+            asm volatile("" : "+v"(src[i][0]), "+v"(src[i][1]), "+v"(src[i][2]), "+v"(src[i][3]));
+            unsigned a0, a1, b0, b1;
+            conv_split2h(src[i][0] * sc_d, src[i][1] * sc_d, a0, a1);
+            conv_split2h(src[i][2] * sc_d, src[i][3] * sc_d, b0, b1);
+            const int c = wave_u * NDL + i;
+            unsigned* p0 = reinterpret_cast<unsigned*>(&sD[c * NG]) + lane * 2;
+            unsigned* p1 = reinterpret_cast<unsigned*>(&sD[(16 + c) * NG]) + lane * 2;
+            *reinterpret_cast<uint2*>(p0) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2*>(p1) = make_uint2(a1, b1);
+        }
+    };
+
+    f32x4 acc[9];
+    f32x4 accb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr unsigned kOnes = 0x3C003C00u;               // two fp16 1.0
+    const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{kOnes, kOnes, kOnes, kOnes});
+
+    for (int run = run_begin; run < run_end; ++run) {
+        const int b = run / rpi, r0 = (run % rpi) * ROWS;
+        if constexpr (XF) {
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) {
+                const int c = wave_u * NXL + i;
+                f32x2 v = f32x2{0.f, 0.f};
+                if (c < a.Cin) { const float2 t = a.xf[(size_t)(b / a.xf_Bg) * a.Cin + c]; v = f32x2{t.x, t.y}; }
+                cf[i] = v;
+            }
+        }
+        // rows r0 - 1 and r0 into slots 0 and 1, then row r0 + 1 (slot 2) and dy row r0: two fetch rounds, both in flight together
+        {
+            float ra[NXL][4], rb[NXL][4];
+            bool oka, okb;
+            load_x(b, r0 - 1, ra, oka);
+            load_x(b, r0, rb, okb);
+            load_x(b, r0 + 1, rx, x_in);
+            load_d(b, r0, rd, d_in);
+            __builtin_amdgcn_sched_barrier(0);
+            store_x(ra, oka, 0);
+            store_x(rb, okb, 1);
+            store_x(rx, x_in, 2);
+            store_d(rd);
+        }
+        __syncthreads();
+        int s0 = 0;                                       // slot of input row y - 1; rows y, y + 1 follow cyclically
+#pragma unroll 1
+        for (int y = r0; y < r0 + ROWS; ++y) {
+            const bool more = y + 1 < r0 + ROWS;
+            if (more) { load_x(b, y + 2, rx, x_in); load_d(b, y + 1, rd, d_in); }
+
+#pragma unroll
+            for (int sgi = 0; sgi < 2; ++sgi) {
+                const int gq = (sp * 2 + sgi) * 4 + kq;  // this lane's 8-pixel group of the row
+                f16x8 af[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[p] = __builtin_bit_cast(f16x8, sD[(p * 16 + j) * NG + gq]);
+                if (want_bias && wci == 0) {              // every dy element exactly once
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], ones, accb, 0, 0, 0);
+                    accb = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], ones, accb, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    int slot = s0 + ky; slot = slot >= NSLOT ? slot - NSLOT : slot;
+                    f16x8 bf[3][2];                        // [shift kx][piece]
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int u = ((p * CI + wci * 16 + j) * NSLOT + slot) * XG + gq + 1;
+                        const u32x4 c = sX[u];
+                        const unsigned cl3 = reinterpret_cast<const unsigned*>(&sX[u - 1])[3];      // pixels x - 2, x - 1 of the group's first pixel
+                        const unsigned cr0 = reinterpret_cast<const unsigned*>(&sX[u + 1])[0];      // pixels x + 8, x + 9
+                        const unsigned t01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), t12 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
+                        const unsigned t23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
+                        const unsigned tE0 = __builtin_amdgcn_alignbit(c[0], cl3, 16), t3E = __builtin_amdgcn_alignbit(cr0, c[3], 16);
+                        bf[0][p] = __builtin_bit_cast(f16x8, u32x4{tE0, t01, t12, t23});           // pixels x - 1
+                        bf[1][p] = __builtin_bit_cast(f16x8, c);
+                        bf[2][p] = __builtin_bit_cast(f16x8, u32x4{t01, t12, t23, t3E});           // pixels x + 1
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        f32x4 c = acc[ky * 3 + kx];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bf[kx][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[kx][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[kx][0], c, 0, 0, 0);
+                        acc[ky * 3 + kx] = c;
+                    }
+                }
+            }
+            __syncthreads();                              // every wave is done with input row y - 1 and dy row y
+            if (more) { store_x(rx, x_in, s0); store_d(rd); }
+            s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
+            __syncthreads();
+        }
+    }
+
+    // ---- sum the four K-split partials of each input-channel block through LDS (fixed order), as conv_swrw_body ----
+    float* red = reinterpret_cast<float*>(sX);             // [slot][wci][10][4][64]; the staging image is dead (the loop ended with a barrier)
+#pragma unroll
+    for (int s = 2; s >= 1; s >>= 1) {
+        if (sp >= s && sp < 2 * s) {
+            float* p = red + (size_t)((sp - s) * WCI + wci) * 10 * 256 + lane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[(t * 4 + r) * 64] = acc[t][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[(36 + r) * 64] = accb[r];
+        }
+        __syncthreads();
+        if (sp < s) {
+            const float* p = red + (size_t)(sp * WCI + wci) * 10 * 256 + lane;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += p[(t * 4 + r) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accb[r] += p[(36 + r) * 64];
+        }
+        __syncthreads();
+    }
+    if (sp != 0) return;
+    // lane (j, kq), register r: co = kq * 4 + r, ci = wci * 16 + j; the slab may be narrower than 16 output channels (CoutS = 4: the
+    // exact-N plan of the class convolution)
+    float* slab = a.slab + (size_t)split * 9 * a.CoutS * a.CinS;
+    float chk = 0.f;
+    const float inv = inv_d * inv_x;                       // exact: powers of two
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        note_nonfinite(chk, acc[t]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = kq * 4 + r, ci = wci * 16 + j;
+            if (co < a.CoutS && ci < a.CinS) slab[((size_t)t * a.CoutS + co) * a.CinS + ci] = acc[t][r] * inv;
+        }
+    }
+    report_nonfinite(a.err, chk, UAPS_ERR_WRW_NONFINITE);
+    if (want_bias && wci == 0 && j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (kq * 4 + r < a.CoutS) a.bslab[(size_t)split * a.CoutS + kq * 4 + r] = accb[r] * inv_d;
+    }
+}
+
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true>(a); }
+
+}  // namespace uaps

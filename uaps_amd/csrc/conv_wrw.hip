@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include "conv_kernels.hpp"
 #include "conv_split_wrw.hpp"
+#include "conv_split_wrw_row.hpp"
 #include "conv_small.hpp"
 #include "conv_gemm1x1.hpp"
 #include "hints.hpp"
@@ -187,6 +188,26 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
+    // full-width-row kernels (conv_split_wrw_row.hpp): 256-wide maps, <= 16 output and 16 / 32 input channels, every operand bounded;
+    // they write the slabs of the plan above (split or exact-N), so workspace and reduction do not change
+    if (ks == 3 && p.dil == 1 && (p.split || p.small) && vec16 && W == 256 && H % 16 == 0 && Cout <= 16 && (Cin == 16 || Cin == 32) &&
+        p.CoutS <= 16 && p.CinS == Cin && p.ncob == 1 && p.ncib == 1 && uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1] &&
+        (!x2 || Csplit >= Cin || (hints.bound[2] && Csplit % 4 == 0)) &&
+        !(uaps_conv_get_tuning() & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_SPLIT_WRW))) {
+        a.dy_bound = hints.bound[0]; a.dy_mul = hints.mul[0];
+        a.in_bound = hints.bound[1]; a.in_mul = hints.mul[1];
+        if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
+        a.err = uaps::error_word();
+        const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
+        if (Cin == 16) {
+            if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw_bn_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+            else UAPS_LAUNCH_MAIN((conv_hrwrw_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+        } else {
+            if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw_bn_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+            else UAPS_LAUNCH_MAIN((conv_hrwrw_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+        }
+        return (int)hipGetLastError();
+    }
     if (p.g1) {
         if (x2 || xf || !vec16) return UAPS_ERANGE;
         a.tiles_x = (H * W) / 32; a.tiles_y = 1;
