@@ -29,7 +29,7 @@ def mfma_peak_for(kernel_name):
     dense 16-bit matrix peak / 3 and / 6."""
     if kernel_name.startswith("conv_h") or kernel_name.startswith("conv_g1h") or kernel_name.startswith("conv_gw1h"):
         return MFMA_BF16_PEAK_TF / 3.0
-    if kernel_name.startswith("conv_s") or kernel_name.startswith("conv_g1s") or kernel_name.startswith("conv_gw1s"):
+    if (kernel_name.startswith("conv_s") and not kernel_name.startswith("conv_small")) or kernel_name.startswith("conv_g1s") or kernel_name.startswith("conv_gw1s"):
         return MFMA_BF16_PEAK_TF / 6.0
     return MFMA_F32_PEAK_TF
 

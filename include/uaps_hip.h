@@ -354,6 +354,7 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above (default 2); proces
 #define UAPS_TUNE_WRW_SHORT_TILES 32u  /* split weight gradient: 4-row tiles also on the 16-output-channel layers */
 #define UAPS_TUNE_NO_TALL_FWD 64u     /* forward / input gradient of 32-channel blocks: 8-row tiles instead of 16-row ones */
 #define UAPS_TUNE_NO_ROW16 128u       /* no full-width-row kernels (csrc/conv_split_row16.hpp): the 8 x 32-tile persistent kernels instead */
+#define UAPS_TUNE_NO_ROW_WRW 256u     /* no full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp) */
 int uaps_conv_set_tuning(unsigned flags);
 unsigned uaps_conv_get_tuning(void);
 

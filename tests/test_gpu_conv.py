@@ -59,6 +59,7 @@ SHAPES = [
     (3, 32, 16, 48, 256, 3),
     (2, 16, 4, 32, 256, 3),     # out_conv: 4 classes on one padded 16-channel tile
     (2, 32, 12, 16, 256, 3),
+    (2, 32, 16, 32, 256, 3),    # its input gradient (16 -> 32 channels) takes two output tiles of the row kernel
     (40, 16, 16, 256, 256, 3),
 ]
 
@@ -150,7 +151,7 @@ def test_conv_refuses_cpu_tensors():
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16),
                                             (4, 32, 32, 256, 256), (4, 16, 64, 252, 256),           # these two: persistent slice kernels
                                             (6, 24, 32, 200, 264),          # 32-channel block on 16-row tiles, the last one half outside: parts stay per 8 rows
-                                            (4, 16, 16, 64, 256), (3, 32, 16, 32, 256), (2, 16, 10, 48, 256)])     # full-width-row kernels: parts stay 8 x 32 tiles
+                                            (4, 16, 16, 64, 256), (4, 32, 16, 32, 256), (2, 16, 10, 48, 256)])     # full-width-row kernels: parts stay 8 x 32 tiles
 def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
     """conv2d_with_stats: the per-tile (sum, sum of squares) written by the conv epilogue must add up to the
     statistics of y, and bn_act fed with them must equal bn_act running its own statistics pass."""

@@ -159,7 +159,7 @@ def lib() -> C.CDLL:
 # diagnosis scripts set; the library itself reads no environment
 _TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, None), ("UAPS_DIAG_NO_SMALL", 4, None),
              ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"), ("UAPS_FWD_TALL", 64, "0"),
-             ("UAPS_DIAG_NO_ROW16", 128, None))
+             ("UAPS_DIAG_NO_ROW16", 128, None), ("UAPS_DIAG_NO_ROW_WRW", 256, None))
 
 
 def _configure_from_environment(l) -> None:

@@ -84,11 +84,14 @@ class _timed:
                     # <= 16 output channels on a wide map: the persistent kernels of csrc/conv_split_n16.hpp
                     row = W == 256 and H % 16 == 0 and not (_lib.lib().uaps_conv_get_tuning() & 128)      # csrc/conv_fwd.hip: launch_hr16
                     self.name = ("conv_h%s16_bn_kernel" if "_bn_" in self.name else "conv_h%s16_kernel") % ("r" if row else "p") + ("<2>" if kin <= 16 else "<4>")
+                if (kind == "bwd_data" and ks == 3 and kin == 16 and Cin == 32 and W == 256 and H % 16 == 0 and self.name.startswith("conv_s32")
+                        and not (_lib.lib().uaps_conv_get_tuning() & (128 | 8))):
+                    self.name = "conv_hr16x2_kernel"       # 16 -> 16 + 16 channels: two output tiles of the full-width-row kernel
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
                 if (kind in ("wrw", "wrw_bn") and ks == 3 and W == 256 and H % 16 == 0 and Cout <= 16 and Cin in (16, 32)
                         and (self.name.startswith("conv_hwrw") or self.name.startswith("conv_small_wrw"))
-                        and not (_lib.lib().uaps_conv_get_tuning() & (128 | 2))):
+                        and not (_lib.lib().uaps_conv_get_tuning() & (256 | 2))):
                     # the full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp)
                     self.name = ("conv_hrwrw_bn_kernel<%d>" if "_bn_" in self.name else "conv_hrwrw_kernel<%d>") % (Cin // 16)
                 if self.name.startswith("conv_hwrw") and "_kernel<4, 1, " in self.name and H >= 8 and not (_lib.lib().uaps_conv_get_tuning() & 32):

@@ -138,6 +138,14 @@ int launch_hr16(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+int launch_hr16x2(ConvFwdArgs a, hipStream_t s) {
+    const long nruns = (long)a.B * (a.H / 16);
+    if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
+    const unsigned grid = (unsigned)(((nruns < 512 ? nruns : 512) + 7) / 8 * 8);
+    UAPS_LAUNCH_MAIN(conv_hr16x2_kernel, dim3(grid), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 int launch_g1(ConvFwdArgs a, int bn, hipStream_t s) {
     a.tiles_x = (a.H * a.W + 127) / 128;
     a.tiles_y = 1;
@@ -335,6 +343,10 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
                 return launch_g1(a, p.CoutP % 128 == 0 ? 128 : 64, s);
             }
         }
+        // 16 -> 32 channels on a 256-wide map without statistics (the input gradient of up4's two-tensor convolution): two output
+        // tiles of the full-width-row kernel, written as one or two 16-channel tensors
+        if (a.wscale && ks == 3 && p.dil == 1 && Cin == 16 && Cout == 32 && !stats && !xf && !x2 && (Osplit == Cout || Osplit == 16) &&
+            W == 256 && H % 16 == 0 && !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16))) return launch_hr16x2(a, s);
         if (p.dil > 1) return p.sbn == 64 ? launch_s32d<64>(a, p.dil, s) : launch_s32d<32>(a, p.dil, s);
         if (p.s32 && p.s32t) return launch_s32t(a, s);
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);

@@ -23,8 +23,10 @@
 
 namespace uaps {
 
-// NCG = input channels / 8 (2 or 4); threads = 128 * NCG (one wave per (row of the pair, channel group)); XF as in conv_fwd_body
-template <int NCG, bool XF>
+// NCG = input channels / 8 (2 or 4); threads = 128 * NCG (one wave per (row of the pair, channel group)); XF as in conv_fwd_body;
+// NT = 16-channel output tiles (2: the input gradient of the two-tensor convolution of up4, 16 -> 16 + 16 channels written as two
+// tensors, a.out / a.out2 with Osplit = 16; no statistics epilogue in that form)
+template <int NCG, bool XF, int NT = 1>
 __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     constexpr int WIDTH = 256, IW = WIDTH + 8, NSLOT = 4, ROWS = 16, XS = 3;
     constexpr int NWV = 2 * NCG, NTHR = 64 * NWV, HALF = NWV / 2;
@@ -33,9 +35,10 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     constexpr int NTC = MW / 2;                       // 32-pixel statistics columns per wave
     constexpr int CGU = NSLOT * IW, PIECE = NCG * CGU;       // 16-byte units between channel groups / pieces
     static_assert(NCG == 2 || NCG == 4, "16 or 32 input channels");
+    static_assert(NT == 1 || (NT == 2 && NCG == 2 && !XF), "two output tiles: 16 input channels, plain input");
 
     __shared__ __attribute__((aligned(16))) u32x4 sIn[2 * PIECE];      // [piece][channel group][slot][column]: 67.6 KB (NCG 2), 135 KB (NCG 4)
-    __shared__ float sRed[NWV * 4 * NTC * 16 * 2];
+    __shared__ float sRed[NT == 1 ? NWV * 4 * NTC * 16 * 2 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -53,23 +56,29 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     if (run >= nruns) return;
 
     // ---- weight fragments, once: lane (n = j, k-group kq) of step s holds k-group q = 4 s + kq = (tap q / NCG, channel group q % NCG) ----
-    bf16x8 bfr[NSTEP][2];
+    bf16x8 bfr[NSTEP][NT][2];
     {
         const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)(2 * 9) * CGP * a.CoutP * 16u);
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int q = 4 * s + kq, tap = q / NCG, cg = q % NCG;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const uint32_t off = q < NQ ? (uint32_t)(((p * 9 + tap) * CGP + cg) * a.CoutP + j) * 16u : kOob;
-                bfr[s][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
-            }
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const uint32_t off = q < NQ ? (uint32_t)(((p * 9 + tap) * CGP + cg) * a.CoutP + n * 16 + j) * 16u : kOob;
+                    bfr[s][n][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
+                }
         }
     }
-    const int co = j;
-    const bool co_ok = co < a.Cout;
-    const float bv = (a.bias && co_ok) ? a.bias[co] : 0.f;
-    const float sh = stats_shift(a, co, co_ok);
+    bool co_ok[NT];
+    float bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        co_ok[n] = n * 16 + j < a.Cout;
+        bv[n] = (a.bias && co_ok[n]) ? a.bias[n * 16 + j] : 0.f;
+    }
+    const float sh = stats_shift(a, j, co_ok[0]);
 
     // the margins of every row slot (image columns -4 .. -1 and 256 .. 259) are zero for the kernel's life
     for (int e = tid; e < 2 * NCG * NSLOT * 8; e += NTHR) {
@@ -159,8 +168,16 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
         __syncthreads();
         // branch-free output stores (lanes of padded channels store out of range): a store inside a branch makes the compiler's
         // vmcnt bookkeeping conservative, and the wait for the prefetched rows then also waits for this step's stores
-        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
-        const uint32_t out_c = co_ok ? (uint32_t)co * HW4 : kOob;
+        // (channels [0, Osplit) live in a.out, the rest in a.out2; Osplit is 16 or Cout)
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out + (size_t)b * a.Osplit * HW, (uint32_t)a.Osplit * HW4);
+        const __amdgpu_buffer_rsrc_t rs_out2 = NT == 2 && a.Osplit < a.Cout
+            ? make_rsrc(a.out2 + (size_t)b * (a.Cout - a.Osplit) * HW, (uint32_t)(a.Cout - a.Osplit) * HW4) : rs_out;
+        uint32_t out_c[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + j;
+            out_c[n] = co_ok[n] ? (uint32_t)(co < a.Osplit ? co : co - a.Osplit) * HW4 : kOob;
+        }
 #pragma unroll 1
         for (int k = 0; k < ROWS / 2; ++k) {
             const int y = r0 + 2 * k;                 // output rows y, y + 1 from input rows y - 1 .. y + 2
@@ -170,9 +187,11 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
             int aoff[NSTEP];
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) aoff[s] = kxo[s] + ((y + orr + kyv[s]) & 3) * IW;     // input row y + orr + ky - 1 -> its slot
-            f32x4 acc[MW];
+            f32x4 acc[MW][NT];
 #pragma unroll
-            for (int m = 0; m < MW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             constexpr int NUN = NSTEP * MW;
             bf16x8 af[2][2];
             auto read_a = [&](int u, bf16x8 (&dst)[2]) {
@@ -186,13 +205,16 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
                 const int s = u / MW, m = u % MW;
                 if (u + 1 < NUN) read_a(u + 1, af[(u + 1) & 1]);
                 const auto H = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
-                f32x4 c = acc[m];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][1]), H(bfr[s][0]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s][1]), c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s][0]), c, 0, 0, 0);
-                acc[m] = c;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 c = acc[m][n];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][1]), H(bfr[s][n][0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s][n][1]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(H(af[u & 1][0]), H(bfr[s][n][0]), c, 0, 0, 0);
+                    acc[m][n] = c;
+                }
                 if (u + 1 < NUN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // next unit's DS reads first ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                       // ... then this unit's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);                  // ... then this unit's MFMAs
             }
 
             // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every M tile ----
@@ -201,17 +223,24 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
                 const int gx = (tb + m) * 16 + kq * 4;
-                f32x4 v = acc[m];
-                v *= out_scale_a; v *= out_scale_w;   // exact: powers of two
-                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                note_nonfinite(chk, v);               // (padded channels hold exact zeros: zero weights, no bias)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)(out_c + (uint32_t)(gy * a.W + gx) * 4u), 0, 0);
-                const f32x4 d = v - sh;
-                st_s[m / 2] += (d.x + d.y) + (d.z + d.w);
-                st_q[m / 2] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = acc[m][n];
+                    v *= out_scale_a; v *= out_scale_w;   // exact: powers of two
+                    v.x += bv[n]; v.y += bv[n]; v.z += bv[n]; v.w += bv[n];
+                    note_nonfinite(chk, v);               // (padded channels hold exact zeros: zero weights, no bias)
+                    const bool second_out = NT == 2 && n * 16 >= a.Osplit;      // wave-uniform
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), second_out ? rs_out2 : rs_out,
+                                                           (int)(out_c[n] + (uint32_t)(gy * a.W + gx) * 4u), 0, 0);
+                    if constexpr (NT == 1) {
+                        const f32x4 d = v - sh;
+                        st_s[m / 2] += (d.x + d.y) + (d.z + d.w);
+                        st_q[m / 2] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                    }
+                }
             }
             report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
-            const bool band_end = (k & 3) == 3;       // an 8-row band of statistics tiles is complete
+            const bool band_end = NT == 1 && (k & 3) == 3;       // an 8-row band of statistics tiles is complete
             if (a.stats != nullptr && band_end) {
 #pragma unroll
                 for (int i = 0; i < NTC; ++i) {
@@ -244,5 +273,7 @@ template <int NCG>
 __global__ __launch_bounds__(128 * NCG) void conv_hr16_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false>(a); }
 template <int NCG>
 __global__ __launch_bounds__(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
+// 16 -> 32 channels (two 16-channel output tiles, one or two output tensors), no statistics
+__global__ __launch_bounds__(256) void conv_hr16x2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2>(a); }
 
 }  // namespace uaps

@@ -193,7 +193,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     if (ks == 3 && p.dil == 1 && (p.split || p.small) && vec16 && W == 256 && H % 16 == 0 && Cout <= 16 && (Cin == 16 || Cin == 32) &&
         p.CoutS <= 16 && p.CinS == Cin && p.ncob == 1 && p.ncib == 1 && uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1] &&
         (!x2 || Csplit >= Cin || (hints.bound[2] && Csplit % 4 == 0)) &&
-        !(uaps_conv_get_tuning() & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_SPLIT_WRW))) {
+        !(uaps_conv_get_tuning() & (UAPS_TUNE_NO_ROW_WRW | UAPS_TUNE_NO_SPLIT_WRW))) {
         a.dy_bound = hints.bound[0]; a.dy_mul = hints.mul[0];
         a.in_bound = hints.bound[1]; a.in_mul = hints.mul[1];
         if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
