@@ -513,6 +513,9 @@ int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map,
  * backward of both addends is dx = dout * (out > 0). */
 int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream);
 int uaps_relu_bwd(const float* dout, const float* out, float* dx, long n, uaps_stream_t stream);
+/* The same when the join's output had k <= 4 consumers: dx = (dout[0] + ... + dout[k-1]) * (out > 0), the k gradients (host
+ * array of device pointers) summed in order by this pass instead of by k - 1 accumulation passes in front of it. */
+int uaps_relu_bwd_sum(const float* const* dout_host, int k, const float* out, float* dx, long n, uaps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline: the per-sample work of the reference's training loader (utilities/dataloaders.py:60-119: albumentations

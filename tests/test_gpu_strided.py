@@ -148,6 +148,39 @@ def test_no_library_convolution_or_pooling_on_the_resnet_path():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
+def test_no_library_elementwise_add_in_the_resnet_backward():
+    """Residual joins hand one handle per consumer to the next block (res_uaps.add_relu): the gradients of a join's consumers are
+    summed inside its own backward pass (uaps_relu_bwd_sum), not by the autograd engine's accumulation -- which is an ATen
+    elementwise-add launch per join (20 per step of the ResNet-50 net, 3.6 ms at the configs[4] shape in round 3).  A training
+    step of the ResNet-50 UAPS net under the profiler must show no such kernel."""
+    import uaps_amd
+    try:
+        from torch.profiler import ProfilerActivity, profile
+    except Exception as e:                                   # pragma: no cover
+        pytest.skip(f"torch.profiler unavailable: {e}")
+    torch.manual_seed(0)
+    model = uaps_amd.net_factory("resnet50_uaps", 3, 2, n_aux=3)
+    tr = uaps_amd.UAPSTrainer(model, base_lr=1e-4)
+    data = uaps_amd.data.SyntheticBatches(2, 3, 2, 96, 96, n_batches=1, device=DEV)
+    xl, yl, xu = data.next()
+    tr.train_step(xl, yl, xu)
+    torch.cuda.synchronize()
+    try:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            tr.train_step(xl, yl, xu)
+            torch.cuda.synchronize()
+        counts = {e.key: e.count for e in prof.key_averages()}
+    except Exception as e:                                   # pragma: no cover
+        pytest.skip(f"device profiling not available here: {e}")
+    if not any("relu_bwd_sum_kernel" in n for n in counts):
+        pytest.skip("the profiler recorded no device kernels of this package")
+    # one scalar add belongs to the trainer's bookkeeping; the net has 16 joins, each of which was at least one add launch
+    adds = sum(c for n, c in counts.items() if "CUDAFunctor_add" in n)
+    assert adds <= 2, {n: c for n, c in counts.items() if "CUDAFunctor_add" in n}
+    joins = sum(c for n, c in counts.items() if "relu_bwd_sum_kernel" in n)
+    assert joins == 16, joins                                # 3 + 4 + 6 + 3 Bottleneck blocks
+
+
 def test_res_uaps_step_at_config4_shape():
     """BASELINE.json configs[4] per-GPU shape: ResNet-50 encoder, K = 3, 2 classes, 640 x 640, 8 labelled + 8 unlabelled
     images: steps through the product path; finite, decreasing loss, a finite gradient for every parameter."""

@@ -112,6 +112,7 @@ SIGNATURES = {
     "uaps_adam_step": (C.c_int, [_PTR] * 5 + [C.c_int] + [C.c_double] * 5 + [C.c_long, _PTR]),
     "uaps_add_relu": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_relu_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
+    "uaps_relu_bwd_sum": (C.c_int, [_PTR, C.c_int, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 

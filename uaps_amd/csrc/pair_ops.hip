@@ -294,8 +294,39 @@ __global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const float* __restr
     if (blockIdx.x == 0)
         for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) dx[i] = out[i] > 0.f ? dout[i] : 0.f;
 }
+// the join's output feeds K consumers (the next block's first convolution and its shortcut, a decoder): their K gradients are
+// summed here, in argument order, instead of by K - 1 separate accumulation passes of the autograd engine
+constexpr int kReluBwdMax = 4;
+struct ReluBwdIn { const float* g[kReluBwdMax]; int k; };
+__global__ __launch_bounds__(kThreads) void relu_bwd_sum_kernel(ReluBwdIn in, const float* __restrict__ out, float* __restrict__ dx, long n4, long n) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long)gridDim.x * kThreads) {
+        float4 g = reinterpret_cast<const float4*>(in.g[0])[i];
+#pragma unroll
+        for (int k = 1; k < kReluBwdMax; ++k)
+            if (k < in.k) { const float4 t = reinterpret_cast<const float4*>(in.g[k])[i]; g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+        const float4 o = reinterpret_cast<const float4*>(out)[i];
+        reinterpret_cast<float4*>(dx)[i] = make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    }
+    if (blockIdx.x == 0)
+        for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) {
+            float g = in.g[0][i];
+            for (int k = 1; k < in.k; ++k) g += in.g[k][i];
+            dx[i] = out[i] > 0.f ? g : 0.f;
+        }
+}
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace
+
+extern "C" int uaps_relu_bwd_sum(const float* const* dout_host, int k, const float* out, float* dx, long n, uaps_stream_t stream) {
+    if (!dout_host || k < 1 || k > kReluBwdMax || !out || !dx || n <= 0) return UAPS_EINVAL;
+    ReluBwdIn in{};
+    in.k = k;
+    bool al = al16p(out) && al16p(dx);
+    for (int i = 0; i < k; ++i) { if (!dout_host[i]) return UAPS_EINVAL; in.g[i] = dout_host[i]; al = al && al16p(dout_host[i]); }
+    const long n4 = al ? n / 4 : 0;
+    hipLaunchKernelGGL(relu_bwd_sum_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, in, out, dx, n4, n);
+    return (int)hipGetLastError();
+}
 
 extern "C" int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
     float* amax = uaps::take_hints().out_amax;

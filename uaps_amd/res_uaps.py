@@ -29,9 +29,14 @@ from .unet import ConvBlock, UpBlock, _PERTURBATIONS
 # ---- relu(a + b) with the hand-written kernels ---------------------------------------------------------------------
 
 class _AddRelu(torch.autograd.Function):
+    """relu(a + b) handed out as `n` handles on ONE tensor (the join's consumers: the next block's first convolution, its shortcut,
+    a decoder); the backward sums the n incoming gradients and masks them in one pass (uaps_relu_bwd_sum) -- without the handles
+    the autograd engine adds the gradients with a pass of its own (an ATen kernel) in front of the mask."""
+
     @staticmethod
-    def forward(ctx, a, b, am=None):
+    def forward(ctx, a, b, am, n):
         _lib.require_device(a, "add_relu")
+        ctx.set_materialize_grads(False)
         a, b = a.contiguous(), b.contiguous()
         out = torch.empty_like(a)
         with _lib.device_guard(a.device):
@@ -40,25 +45,32 @@ class _AddRelu(torch.autograd.Function):
             rc = _lib.lib().uaps_add_relu(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
         _lib.check(rc, "uaps_add_relu")
         ctx.save_for_backward(out)
-        return out
+        return tuple(out.view_as(out) for _ in range(n))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *grads):
         (out,) = ctx.saved_tensors
-        g = g.contiguous()
-        dx = torch.empty_like(g)
-        with _lib.device_guard(g.device):
-            rc = _lib.lib().uaps_relu_bwd(g.data_ptr(), out.data_ptr(), dx.data_ptr(), g.numel(), _lib.current_stream(g.device))
-        _lib.check(rc, "uaps_relu_bwd")
-        bounds.carry(g, dx)                       # a mask: |dx| <= |g|
-        return dx, dx, None
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None, None, None
+        dx = torch.empty_like(gs[0])
+        ptrs = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+        with _lib.device_guard(dx.device):
+            rc = _lib.lib().uaps_relu_bwd_sum(ptrs, len(gs), out.data_ptr(), dx.data_ptr(), dx.numel(), _lib.current_stream(dx.device))
+        _lib.check(rc, "uaps_relu_bwd_sum")
+        return dx, dx, None, None
 
 
-def add_relu(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def add_relu(a: torch.Tensor, b: torch.Tensor, n: int = 1):
+    """relu(a + b); n > 1: a tuple of n handles on the result, one per consumer (see _AddRelu)."""
     if not a.is_cuda:
-        return F.relu(a + b)
+        out = F.relu(a + b)
+        return out if n == 1 else (out,) * n
+    if not 1 <= n <= 4:
+        raise ValueError("add_relu: 1..4 consumers")
     am = bounds.new_amax(a.device) if bounds.enabled() else None      # max(out), raised by the kernel: the join feeds the next block's convolutions
-    return bounds.put(_AddRelu.apply(a, b, am), am)
+    outs = tuple(bounds.put(o, am) for o in _AddRelu.apply(a, b, am, n))
+    return outs[0] if n == 1 else outs
 
 
 def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, training: bool) -> torch.Tensor:
@@ -118,11 +130,13 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, x_id=None, n_out: int = 1):
+        """x_id: a second handle on the input for the shortcut, n_out: handles wanted on the output (add_relu)."""
+        x_id = x if x_id is None else x_id
         out = conv_bn_act(x, self.conv1, self.bn1, True, self.training)
         out = conv_bn_act(out, self.conv2, self.bn2, False, self.training)
-        identity = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], False, self.training)
-        return add_relu(out, identity)
+        identity = x_id if self.downsample is None else conv_bn_act(x_id, self.downsample[0], self.downsample[1], False, self.training)
+        return add_relu(out, identity, n_out)
 
 
 class Bottleneck(nn.Module):
@@ -141,12 +155,14 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, x_id=None, n_out: int = 1):
+        """x_id: a second handle on the input for the shortcut, n_out: handles wanted on the output (add_relu)."""
+        x_id = x if x_id is None else x_id
         out = conv_bn_act(x, self.conv1, self.bn1, True, self.training)
         out = conv_bn_act(out, self.conv2, self.bn2, True, self.training)
         out = conv_bn_act(out, self.conv3, self.bn3, False, self.training)
-        identity = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], False, self.training)
-        return add_relu(out, identity)
+        identity = x_id if self.downsample is None else conv_bn_act(x_id, self.downsample[0], self.downsample[1], False, self.training)
+        return add_relu(out, identity, n_out)
 
 
 class ResNet(nn.Module):
@@ -197,11 +213,25 @@ class ResNet(nn.Module):
         """(c1, c2, c3, c4), resnet.py:171-182."""
         x = conv_bn_act(x, self.conv1, self.bn1, True, self.training)
         x = conv.maxpool3x3s2(x) if x.is_cuda else self.maxpool(x)
-        c1 = self.layer1(x)
-        c2 = self.layer2(c1)
-        c3 = self.layer3(c2)
-        c4 = self.layer4(c3)
-        return c1, c2, c3, c4
+        if not (x.is_cuda and torch.is_grad_enabled() and x.requires_grad):
+            c1 = self.layer1(x)
+            c2 = self.layer2(c1)
+            c3 = self.layer3(c2)
+            c4 = self.layer4(c3)
+            return c1, c2, c3, c4
+        # training on the GPU: every residual join hands one handle to each of its consumers (next block's first convolution, its
+        # shortcut, and -- for a layer's last block -- the feature tuple), so their gradients meet inside the join's backward pass
+        feats = []
+        h = fused.fan_out(x, 2)                           # the pooled stem output feeds layer1.0's convolution and its shortcut
+        layers = (self.layer1, self.layer2, self.layer3, self.layer4)
+        for li, layer in enumerate(layers):
+            for bi, blk in enumerate(layer):
+                last = bi == len(layer) - 1
+                n_out = (1 if li == len(layers) - 1 else 3) if last else 2
+                h = blk(h[0], h[1], n_out)
+                h = h if isinstance(h, tuple) else (h,)
+            feats.append(h[-1])
+        return tuple(feats)
 
     forward = base_forward
 
