@@ -41,6 +41,7 @@ SHAPES = [
     (2, 64, 64, 16, 16, 3),
     (1, 128, 256, 16, 16, 3),
     (2, 256, 128, 16, 16, 1),   # UpBlock conv1x1
+    (4, 256, 128, 32, 32, 1),   # ... of up1 at a 512 x 512 input: 1024 pixels, the GEMM-tiled plan (plan_fwd's big_1x1 rule)
     (2, 32, 16, 64, 64, 1),
     (1, 20, 40, 18, 18, 3),     # channel counts that are not multiples of the tile sizes
     (1, 24, 24, 10, 10, 1),
@@ -200,6 +201,49 @@ def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
     assert torch.equal(g[0], xc.grad[:, :C1]) and torch.equal(g[1], xc.grad[:, C1:])
     assert torch.equal(g[2], w.grad) and torch.equal(g[3], b.grad)
     np.testing.assert_allclose(st[..., 0].double().sum((1, 2)).cpu().numpy(), y.detach().double().sum((0, 2, 3)).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+def test_wide_1x1_over_two_tensors_takes_the_exact_plan_in_every_entry_point():
+    """The GEMM-tiled 1x1 plan has no two-tensor form and its own statistics / workspace layouts: conv.plan_cfg gives such a call
+    cfg bit 28 in all its entry points (statistics parts, forward, both gradients, workspace, reduce), so they agree -- instead of
+    UAPS_ERANGE from the library or statistics in a layout the consumer does not expect."""
+    from uaps_amd import conv
+    from uaps_amd.conv import conv2d_cat
+    dev = torch.device("cuda:0")
+    B, C1, C2, Cout, H, W = 2, 64, 64, 128, 32, 32
+    assert conv.kernel_variant("fwd", B, C1 + C2, Cout, H, W, 1).startswith("conv_g1")          # what the single-tensor layer runs
+    assert conv.plan_cfg(1, 0, False) == 1 << 28 and conv.plan_cfg(3, 0, False) == 0
+    x1, x2 = _mk((B, C1, H, W), 31).to(dev).requires_grad_(True), _mk((B, C2, H, W), 32).to(dev).requires_grad_(True)
+    w = (_mk((Cout, C1 + C2, 1, 1), 33) / np.sqrt(C1 + C2)).to(dev).requires_grad_(True)
+    dy = _b(_mk((B, Cout, H, W), 35).to(dev))
+    y, st = conv2d_cat(_b(x1), _b(x2), w, None, with_stats=True)
+    y.backward(dy)
+    xc = torch.cat([x1, x2], 1).detach().double().cpu().requires_grad_(True)
+    wc = w.detach().double().cpu().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xc, wc)
+    yr.backward(dy.double().cpu())
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 1e-4
+    assert float((torch.cat([x1.grad, x2.grad], 1).cpu().double() - xc.grad).abs().max()) < 1e-4
+    assert float((w.grad.cpu().double() - wc.grad).abs().max()) < 1e-3 * float(wc.grad.abs().max())
+    np.testing.assert_allclose(st[..., 0].double().sum((1, 2)).cpu().numpy(), yr.detach().sum((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(st[..., 1].double().sum((1, 2)).cpu().numpy(), (yr.detach() ** 2).sum((0, 2, 3)).numpy(), rtol=1e-4)
+
+
+def test_packed_buffers_of_a_transient_weight_die_with_it():
+    """conv3x3s2 builds its re-arranged kernel as a fresh tensor on every forward: the packed-weight cache must not keep an entry
+    (2 x 8 MB for layer2.0.conv2) per call until some later purge."""
+    import gc
+    from uaps_amd import conv
+    dev = torch.device("cuda:0")
+    x = _b(_mk((1, 16, 16, 32), 41).to(dev))
+    gc.collect()
+    n0 = len(conv._packed)
+    for i in range(20):
+        w = (_mk((16, 16, 3, 3), 50 + i) / 12).to(dev)
+        conv.conv2d(x, w, None)
+        del w
+    gc.collect()
+    assert len(conv._packed) <= n0 + 1
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,dil", [(2, 32, 32, 40, 40, 2), (1, 64, 48, 32, 32, 4), (2, 16, 128, 20, 36, 2), (1, 256, 256, 16, 16, 4),

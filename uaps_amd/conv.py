@@ -146,6 +146,18 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     return w
 
 
+def _remember(weight: torch.Tensor, wf, wb) -> None:
+    """Cache entry of `weight`, dropped the moment the tensor dies (a transient weight -- conv3x3s2's re-arranged kernel is a fresh
+    non-leaf tensor every forward -- must not keep its packed buffers until some later purge)."""
+    key = id(weight)
+
+    def _gone(r, key=key, _packed=_packed):
+        ent = _packed.get(key)
+        if ent is not None and ent[0] is r:          # not an entry of a newer tensor that got the same id
+            del _packed[key]
+    _packed[key] = (weakref.ref(weight, _gone), weight._version, _generation, wf, wb)
+
+
 def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
     """Packed forward / input-gradient weight buffers of `weight` [Cout,Cin,ks,ks], cached until the
     parameter is modified in place (optimizer step) or replaced."""
@@ -170,10 +182,7 @@ def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
         rc = L.uaps_conv_pack_weights(w.data_ptr(), Cout, Cin, ks, wf.data_ptr(), wb.data_ptr() if need_bwd else None,
                                       _lib.current_stream(dev))
     _lib.check(rc, "uaps_conv_pack_weights")
-    if len(_packed) > 4096:
-        for k in [k for k, e in _packed.items() if e[0]() is None]:
-            del _packed[k]
-    _packed[key] = (weakref.ref(weight), weight._version, _generation, wf, wb)
+    _remember(weight, wf, wb)
     return wf, wb
 
 
@@ -236,11 +245,24 @@ def pack_all(weights) -> None:
                                             _lib.current_stream(dev))
     _lib.check(rc, "uaps_conv_pack_weights_batch")
     for wt, (_, wf, wb) in zip(todo, bufs):
-        _packed[id(wt)] = (weakref.ref(wt), wt._version, _generation, wf, wb)
+        _remember(wt, wf, wb)
 
 
 def _h16(*bs) -> bool:
     return all(b is not None for b in bs) and get_mode() == "h16"
+
+
+_EXACT = 1 << 28          # cfg bit 28: the exact fp32 kernels (include/uaps_hip.h)
+
+
+def plan_cfg(ks: int, cfg: int, plain: bool, *tensors) -> int:
+    """The ONE place that decides whether a 1x1 convolution may take the GEMM-tiled plan (csrc/conv_gemm1x1.hpp: `g1`): that plan
+    has its own BatchNorm-statistics and weight-gradient workspace layouts and only a single-tensor, 16-byte-aligned form, so a
+    two-tensor / BatchNorm-in-staging call (`plain` False) or an odd pointer gets cfg bit 28 (exact fp32 kernels) -- handed to
+    every entry point of the layer (statistics parts, forward, both gradients, workspace, reduce), which therefore agree."""
+    if ks == 1 and (not plain or any(t is not None and t.data_ptr() % 16 for t in tensors)):
+        return cfg | _EXACT
+    return cfg
 
 
 def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ks: int, cfg: int = 0,
@@ -251,6 +273,7 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     bp = bias.data_ptr() if bias is not None else None
+    cfg = plan_cfg(ks, cfg, True, x, y)
     if want_stats:
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
@@ -270,6 +293,7 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
 def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0, dyb=None):
     B, Cout, H, W = dy.shape
     dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    cfg = plan_cfg(ks, cfg, True, dy, dx)
     with _lib.device_guard(dy.device), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, _h16(dyb)):
         if dyb is not None:
             _lib.hints((dyb,))
@@ -287,6 +311,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     dev = dy.device
     L = _lib.lib()
     n = C.c_size_t()
+    cfg = plan_cfg(ks, cfg, True, dy, x)
     _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
     ws = _workspace(dev, n.value)
     dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
@@ -391,21 +416,22 @@ class _Conv2dCat(torch.autograd.Function):
             raise ValueError("conv2d_cat: the first tensor must have a multiple of 16 channels")
         wf, wb = pack_weights(weight, need_bwd=True)
         dev = x1.device
+        cfg = plan_cfg(ks, 0, False)
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
         stats = None
         if want_stats:
-            stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
+            stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg), 2), dtype=torch.float32, device=dev)
         b1, b2 = bounds.get(x1), bounds.get(x2)
         ctx.xb = (b1, b2)
-        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, 0, _h16(b1, b2)):
+        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(b1, b2)):
             if (b1 is not None and b2 is not None) or (want_stats and stat_shift is not None):
                 _lib.hints((b1, b2) if (b1 is not None and b2 is not None) else (), None, stat_shift if want_stats else None)
             rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
                                               bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                              stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, 0, _lib.current_stream(dev))
+                                              stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, cfg, _lib.current_stream(dev))
         _lib.check(rc, "uaps_conv_fwd_cat")
         ctx.save_for_backward(x1, x2, wb)
-        ctx.meta = (C1, C2, Cout, ks, bias is not None)
+        ctx.meta = (C1, C2, Cout, ks, bias is not None, cfg)
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -417,7 +443,7 @@ class _Conv2dCat(torch.autograd.Function):
         if dy is None:
             return None, None, None, None, None, None
         x1, x2, wb = ctx.saved_tensors
-        C1, C2, Cout, ks, has_bias = ctx.meta
+        C1, C2, Cout, ks, has_bias, cfg = ctx.meta
         dyb = bounds.get(dy)
         b1, b2 = ctx.xb
         dy = dy.contiguous()
@@ -430,27 +456,27 @@ class _Conv2dCat(torch.autograd.Function):
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx1 = torch.empty_like(x1)
                 dx2 = torch.empty_like(x2)
-                with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, 0, _h16(dyb)):
+                with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb)):
                     if dyb is not None:
                         _lib.hints((dyb,))
                     rc = L.uaps_conv_bwd_data_cat(dy.data_ptr(), wb.data_ptr(), dx1.data_ptr(), C1, dx2.data_ptr(), C2, B, Cout, H, W,
-                                                  ks, 0, st)
+                                                  ks, cfg, st)
                 _lib.check(rc, "uaps_conv_bwd_data_cat")
             want_db = has_bias and ctx.needs_input_grad[3]
             if ctx.needs_input_grad[2] or want_db:
                 n = C.c_size_t()
-                _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
+                _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
                 ws = _workspace(dev, n.value)
                 dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
                 db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
-                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, 0, _h16(dyb, b1, b2)):
+                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb, b1, b2)):
                     if dyb is not None and b1 is not None and b2 is not None:
                         _lib.hints((dyb, b1, b2))
                     rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
-                                                            H, W, ks, 0, ws.data_ptr(), ws.numel(), st)
+                                                            H, W, ks, cfg, ws.data_ptr(), ws.numel(), st)
                 _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
                 rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
-                                                   H, W, ks, 0, st)
+                                                   H, W, ks, cfg, st)
                 _lib.check(rc, "uaps_conv_bwd_weight_reduce")
         return dx1, dx2, dw, db, None, None
 

@@ -14,7 +14,6 @@ using namespace uaps;
 
 // 0 = exact fp32 matrix instructions (v_mfma_f32_16x16x4_f32), 1 = exact 3-way bf16 split on the bf16 matrix pipe,
 // 2 (default) = 1, and the two-piece fp16 split for operands with a known magnitude bound (conv_split.hpp).
-// Initialised from UAPS_CONV_MODE, switchable with uaps_conv_set_mode.
 // Set with uaps_conv_set_mode (the Python layer forwards UAPS_CONV_MODE once at load); the library itself reads no environment.
 static int g_conv_mode = 2;
 static unsigned g_conv_tuning = 0;      // UAPS_TUNE_* bits (uaps_conv_set_tuning): ablation / diagnosis switches of the planners
@@ -245,9 +244,10 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     // measured (tools/bench_modes.py, B = 32): the split forms win 1.2-1.7x on every 3x3 layer with more than 8 contraction
     // channels and lose on 1x1 convolutions (HBM-bound, the split only adds staging work) and on the <= 8-channel layers
     // (a chunk of 8 channels fills 9 of 12 k-groups); cfg bits 29-30 != 0 force a split form regardless
-    // 1x1 convolutions: the U-Net's (<= 256 -> 128 channels on <= 32 x 32 maps, or narrower) are HBM-bound and stay on the fp32
-    // instruction; the bottleneck projections of the ResNet encoders (64 ... 2048 channels, utilities/resnet.py:55-95) are
-    // compute-bound and take the split form
+    // 1x1 convolutions: narrow ones, and wide ones on maps of fewer than 32 x 32 pixels (the U-Net's 256 -> 128 projection at a
+    // 256^2 input), are HBM- or launch-bound and stay on the fp32 instruction; from 1024 pixels on (the same projection at a 512^2
+    // input, and the bottleneck projections of the ResNet encoders: 64 ... 2048 channels, utilities/resnet.py:55-95) they are
+    // compute-bound and take the split form.  plan_wrw (conv_wrw.hip) applies the same rule.
     const bool big_1x1 = ks == 1 && Cin >= 64 && (long)Cin * Cout >= 16384 && (long)H * W >= 1024;
     // dilated 3x3 (ResNet stages): the 32x32x16 split form only (>= 32 output channels, no forced settings)
     const bool dil_ok = p->dil == 1 || (ks == 3 && Cin > 8 && p->CoutP % 32 == 0 && !(cfg & 0x70ffffff));
@@ -262,9 +262,9 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
         p->sck = 8;
         p->sbn = (p->CoutP % 64 == 0 && tiles * (p->CoutP / 64) >= 512) ? 64 : 32;
         if (bn_req == 32 || (bn_req == 64 && p->CoutP % 64 == 0)) p->sbn = bn_req;
-        // 32-channel blocks: 16-row tiles while that still gives every CU two workgroups (cfg bit 23 keeps the 8-row tiles)
+        // 32-channel blocks: 16-row tiles while that still gives every CU two workgroups (UAPS_TUNE_NO_TALL_FWD keeps the 8-row tiles)
         const long tiles16 = (long)B * ((H + 15) / 16) * ((W + 31) / 32);
-        p->s32t = p->sbn == 32 && p->dil == 1 && !(cfg & (1 << 23)) && !(g_conv_tuning & UAPS_TUNE_NO_TALL_FWD) &&
+        p->s32t = p->sbn == 32 && p->dil == 1 && !(g_conv_tuning & UAPS_TUNE_NO_TALL_FWD) &&
                   tiles16 * (p->CoutP / 32) >= 512;
     } else if (p->split && bn_req) {
         if ((bn_req != 16 && bn_req != 32) || p->CoutP % bn_req) return UAPS_EINVAL;
@@ -308,6 +308,13 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     if ((x2 && (uintptr_t)x2 % 16) || (y2 && (uintptr_t)y2 % 16)) p.vec = false;
     if (!p.vec || (Csplit < Cin && Csplit % p.sck)) p.split = false;      // unaligned tensors / odd concat split: exact kernels
     if (p.dil > 1 && (!p.s32 || x2 || y2 || xf)) p.split = false;        // the dilated split form: one tensor per side, no staging BatchNorm
+    // uaps_conv_fwd_stats_parts reported the GEMM-tiled plan's parts (shape alone decides it); a call that cannot run that plan
+    // must not write another layout.  The Python layer never gets here: conv.plan_cfg hands such calls cfg bit 28.
+    if (stats) {
+        FwdPlan p0{};
+        if (plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p0)) return UAPS_EINVAL;
+        if (p0.g1 != (p.g1 && p.split && !x2 && !y2 && !xf)) return UAPS_ERANGE;
+    }
     ConvFwdArgs a{};
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats;
@@ -337,11 +344,8 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             a.err = uaps::error_word();
         }
         if (p.g1) {
-            if (x2 || y2 || xf) {                     // no two-tensor / BatchNorm-in-staging form of the GEMM-tiled kernels: the 3x3-style tiling
-                if (stats) return UAPS_ERANGE;        // (its statistics parts would not match uaps_conv_fwd_stats_parts)
-            } else {
-                return launch_g1(a, p.CoutP % 128 == 0 ? 128 : 64, s);
-            }
+            // no two-tensor / BatchNorm-in-staging form of the GEMM-tiled kernels: the 3x3-style tiling (never with statistics, see above)
+            if (!x2 && !y2 && !xf) return launch_g1(a, p.CoutP % 128 == 0 ? 128 : 64, s);
         }
         // 16 -> 32 channels on a 256-wide map without statistics (the input gradient of up4's two-tensor convolution): two output
         // tiles of the full-width-row kernel, written as one or two 16-channel tensors

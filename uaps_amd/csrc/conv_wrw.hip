@@ -209,6 +209,8 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         return (int)hipGetLastError();
     }
     if (p.g1) {
+        // single-tensor, 16-byte-aligned form only; workspace and reduce follow the same plan, so the caller chooses: cfg bit 28
+        // (exact kernels) for a two-tensor / BatchNorm-in-staging / odd-pointer call of such a layer -- uaps_amd.conv.plan_cfg does
         if (x2 || xf || !vec16) return UAPS_ERANGE;
         a.tiles_x = (H * W) / 32; a.tiles_y = 1;
         const long grid = ((long)a.nsplit * a.ncob * a.ncib + 7) / 8 * 8;

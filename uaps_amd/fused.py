@@ -197,9 +197,10 @@ class _BnActConv(torch.autograd.Function):
         xf = torch.empty((groups, Cc, 2), dtype=torch.float32, device=dev)
         wf, wb = _conv.pack_weights(weight, need_bwd=True)
         z = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        cfg = _conv.plan_cfg(ks, 0, False)          # a 1x1 here: never the GEMM-tiled plan (conv.plan_cfg)
         zstats = None
         if want_stats:
-            zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks), 2), dtype=torch.float32, device=dev)
+            zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg), 2), dtype=torch.float32, device=dev)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
             if getattr(stats_partials, "_uaps_shifted", False):
@@ -211,15 +212,15 @@ class _BnActConv(torch.autograd.Function):
                                           nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), B, Cc, H, W,
                                           groups, stats[0].data_ptr(), stats[1].data_ptr(), xf.data_ptr(), st)
             _lib.check(rc, "uaps_bn_finalize_train")
-            with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, 0, _conv._h16(xb)):
+            with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, cfg, _conv._h16(xb)):
                 if xb is not None or (want_stats and stat_shift is not None):
                     _lib.hints((xb,), None, stat_shift if want_stats else None)
                 rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
                                         bias.data_ptr() if bias is not None else None, z.data_ptr(),
-                                        zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, 0, st)
+                                        zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, cfg, st)
             _lib.check(rc, "uaps_conv_fwd_bn")
         ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
-        ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks)
+        ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
         ctx.xb = xb
         if want_stats:
@@ -234,15 +235,15 @@ class _BnActConv(torch.autograd.Function):
         if dz is None:
             return (None,) * 17
         y, gamma, beta, stats, xf, wb = ctx.saved_tensors
-        slope, groups, has_cbias, has_bias, Cout, ks = ctx.meta
+        slope, groups, has_cbias, has_bias, Cout, ks, cfg = ctx.meta
         dzb, xb = bounds.get(dz), ctx.xb
         dz = dz.contiguous()
         B, Cc, H, W = y.shape
         dev = y.device
         L = _lib.lib()
-        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, dyb=dzb)
+        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, cfg, dyb=dzb)
         n = C.c_size_t()
-        _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, 0, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
+        _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
         cws = _conv._workspace(dev, n.value)
         dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
         want_db = has_bias and ctx.needs_input_grad[13]
@@ -252,14 +253,14 @@ class _BnActConv(torch.autograd.Function):
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
-            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, 0, _conv._h16(dzb, xb)):
+            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, cfg, _conv._h16(dzb, xb)):
                 if dzb is not None and xb is not None:
                     _lib.hints((dzb, xb))
                 rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
-                                                       Cout, H, W, ks, 0, cws.data_ptr(), cws.numel(), st)
+                                                       Cout, H, W, ks, cfg, cws.data_ptr(), cws.numel(), st)
             _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
             rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
-                                               ks, 0, st)
+                                               ks, cfg, st)
             _lib.check(rc, "uaps_conv_bwd_weight_reduce")
             am = bounds.new_amax(dev) if bounds.enabled() else None
             if am is not None:

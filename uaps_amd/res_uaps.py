@@ -6,9 +6,12 @@
 for the Bottleneck nets (resnet.py:201-203: c1..c4 = 256/512/1024/2048 channels at strides 4/8/8/8).  On a ROCm
 device every stride-1 convolution (all 1x1 projections, all dilated and plain 3x3) runs on the MFMA kernels of
 csrc/conv_kernels.hpp with the BatchNorm statistics in their epilogue, BatchNorm + ReLU are the fused kernels of
-csrc/norm_act.hip (LeakyReLU slope 0 = ReLU, slope 1 = identity) and the residual joins one `relu(a + b)` kernel.  The
-three strided convolutions of the net (7x7 stem, layer2's 3x3 and its 1x1 shortcut) and the stem's 3x3 max-pool run on the
-general strided kernels of csrc/conv_strided.hip: no library convolution or pooling is left on this path.
+csrc/norm_act.hip (LeakyReLU slope 0 = ReLU, slope 1 = identity) and the residual joins one `relu(a + b)` kernel whose
+backward also sums the gradients of the join's consumers (add_relu below).  Of the three strided convolutions, layer2's 3x3
+runs as a stride-1 3x3 over the four sampling phases of its input (conv.conv3x3s2) and its 1x1 shortcut as a stride-1
+projection of every second row and column (conv.subsample2), both on the MFMA kernels; the 7x7 stem and the stem's 3x3
+max-pool run on the kernels of csrc/conv_strided.hip.  No library convolution, pooling or elementwise kernel is left on this
+path.
 
 The reference has no UAPS model on this backbone (`utilities/base.py` is abstract), so the
 decoder below is this build's design: parity is pinned for the backbone only (tests/golden/g7_resnet.npz).
