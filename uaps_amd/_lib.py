@@ -113,6 +113,7 @@ SIGNATURES = {
     "uaps_add_relu": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_relu_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_relu_bwd_sum": (C.c_int, [_PTR, C.c_int, _PTR, _PTR, C.c_long, _PTR]),
+    "uaps_cat2": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 

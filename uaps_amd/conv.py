@@ -89,11 +89,11 @@ class _timed:
                     self.name = "conv_hr16x2_kernel"       # 16 -> 16 + 16 channels: two output tiles of the full-width-row kernel
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
-                if (kind in ("wrw", "wrw_bn") and ks == 3 and W == 256 and H % 16 == 0 and Cout <= 16 and Cin in (16, 32)
-                        and (self.name.startswith("conv_hwrw") or self.name.startswith("conv_small_wrw"))
+                if (kind in ("wrw", "wrw_bn") and ks == 3 and W == 256 and H % 16 == 0 and Cout <= 16 and Cin <= 32 and not (cfg >> 24)
+                        and (self.name.startswith("conv_hwrw") or self.name.startswith("conv_small_wrw") or self.name.startswith("conv_wrw_"))
                         and not (_lib.lib().uaps_conv_get_tuning() & (256 | 2))):
-                    # the full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp)
-                    self.name = ("conv_hrwrw_bn_kernel<%d>" if "_bn_" in self.name else "conv_hrwrw_kernel<%d>") % (Cin // 16)
+                    # the full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp; csrc/conv_wrw.hip: the eligibility block)
+                    self.name = ("conv_hrwrw_bn_kernel<%d>" if "_bn_" in self.name else "conv_hrwrw_kernel<%d>") % (1 if Cin <= 16 else 2)
                 if self.name.startswith("conv_hwrw") and "_kernel<4, 1, " in self.name and H >= 8 and not (_lib.lib().uaps_conv_get_tuning() & 32):
                     self.name = self.name.replace("_kernel<4, 1, ", "_kernel<8, 1, ")      # 16 output channels: the 8-row tiles (csrc/conv_wrw.hip: launch_swrw)
                 if self.name.startswith("conv_wrw_kernel<3, 4, 32, 2, 2, 4, ") and not self.name.endswith(" 1>") and W >= 32 and Cin >= 16:

@@ -314,8 +314,38 @@ __global__ __launch_bounds__(kThreads) void relu_bwd_sum_kernel(ReluBwdIn in, co
             dx[i] = out[i] > 0.f ? g : 0.f;
         }
 }
+// out = [a ; b] along the batch axis (two tensors of n elements each), max|out| raised into the bound `amax` on the way
+__global__ __launch_bounds__(kThreads) void cat2_amax_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                             long n4, long n, float* __restrict__ amax) {
+    __shared__ float s16[16];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < 2 * n4; i += (long)gridDim.x * kThreads) {
+        const bool hi = i >= n4;
+        const float4 v = hi ? reinterpret_cast<const float4*>(b)[i - n4] : reinterpret_cast<const float4*>(a)[i];
+        reinterpret_cast<float4*>(out + (hi ? n : 0))[hi ? i - n4 : i] = v;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0)
+        for (long i = 4 * n4 + threadIdx.x; i < n; i += kThreads) {
+            const float x = a[i], y = b[i];
+            out[i] = x; out[n + i] = y;
+            m = fmaxf(m, fmaxf(fabsf(x), fabsf(y)));
+        }
+    if (amax != nullptr) uaps::block_amax_to(amax, m, s16);
+}
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 }  // namespace
+
+// The two batches of a training step as one (UAPS_train.py:177 + :185 run as one pass, unet.UNet_UAPS.forward_pair): out [2n] =
+// a [n] followed by b [n]; with uaps_call_hints::out_amax the bound of the result is raised to max|out| on the way, so the first
+// convolution's weight gradient can take the fp16 form.
+extern "C" int uaps_cat2(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
+    float* amax = uaps::take_hints().out_amax;
+    if (!a || !b || !out || n <= 0) return UAPS_EINVAL;
+    const long n4 = (al16p(a) && al16p(b) && al16p(out) && n % 4 == 0) ? n / 4 : 0;
+    hipLaunchKernelGGL(cat2_amax_kernel, dim3(grid_for(n4 > 0 ? 2 * n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, a, b, out, n4, n, amax);
+    return (int)hipGetLastError();
+}
 
 extern "C" int uaps_relu_bwd_sum(const float* const* dout_host, int k, const float* out, float* dx, long n, uaps_stream_t stream) {
     if (!dout_host || k < 1 || k > kReluBwdMax || !out || !dx || n <= 0) return UAPS_EINVAL;

@@ -361,6 +361,23 @@ def fan_out(x: torch.Tensor, n: int):
     return tuple(bounds.carry(x, h) for h in _FanOut.apply(x, n))
 
 
+def cat_batches(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=0) of the step's two input batches (forward_pair) by one kernel that also takes max|.| of the result:
+    the bound lets the first convolution's weight gradient run in the fp16 form (csrc/conv_split_wrw_row.hpp).  Inputs that
+    take part in autograd, or are not fp32 on the GPU, go through torch.cat."""
+    if not (a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.shape == b.shape) or a.requires_grad or b.requires_grad:
+        return torch.cat([a, b], dim=0)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
+    am = bounds.new_amax(a.device) if bounds.enabled() else None
+    with _lib.device_guard(a.device):
+        if am is not None:
+            _lib.hints((), am)
+        rc = _lib.lib().uaps_cat2(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
+    _lib.check(rc, "uaps_cat2")
+    return bounds.put(out, am) if am is not None else out
+
+
 _last_up2x_amax = None
 
 

@@ -331,7 +331,7 @@ class ResUAPS(nn.Module):
         if x_a.shape != x_b.shape:
             raise ValueError("forward_pair: the two batches must have the same shape")
         with fused.stat_groups(2):
-            return self.forward(torch.cat([x_a, x_b], dim=0), _groups=2)
+            return self.forward(fused.cat_batches(x_a, x_b), _groups=2)
 
     def forward(self, x, _groups: int = 1):
         if x.shape[2] % 8 or x.shape[3] % 8:

@@ -246,7 +246,7 @@ class UNet_UAPS(nn.Module):
         if x_a.shape != x_b.shape:
             raise ValueError("forward_pair: the two batches must have the same shape")
         with fused.stat_groups(2):
-            return self.forward(torch.cat([x_a, x_b], dim=0), perturbations, _groups=2)
+            return self.forward(fused.cat_batches(x_a, x_b), perturbations, _groups=2)
 
     def forward(self, x, perturbations=None, _groups: int = 1):
         """`perturbations`: optional list (one entry per auxiliary decoder) of callables
