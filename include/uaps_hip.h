@@ -404,6 +404,8 @@ typedef struct uaps_call_hints {
     float* out_amax;
     const float* stats_mean;     /* see below */
     const float* stats_bias;
+    const float* residual;       /* uaps_bn_act_fwd_train_*: out = relu(bn(y) + residual) -- a residual join (utilities/resnet.py:47-50,
+                                  * 88-91) in the BatchNorm's apply pass; slope is ignored, drop_p must be 0; out_amax is honoured */
 } uaps_call_hints;
 int uaps_next_call_hints(const uaps_call_hints* hints);
 /* Measurement aid (bench.py): `start` / `stop` are two hipEvent_t created with timing enabled.  The calling thread's next MAIN

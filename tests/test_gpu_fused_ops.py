@@ -435,3 +435,45 @@ def test_cat_batches_is_torch_cat_with_a_bound():
         assert bd is not None and float(bounds.value(bd[0])) * bd[1] == float(ref.abs().max())
     a = torch.randn(2, 3, 8, 8, device=dev, requires_grad=True)
     assert fused.cat_batches(a, a.detach()).requires_grad            # autograd inputs: torch.cat
+
+
+@pytest.mark.parametrize("groups,n", [(1, 1), (2, 2), (1, 3)])
+def test_bn_add_relu_is_relu_of_batchnorm_plus_identity(groups, n):
+    """fused.bn_add_relu (the end of a residual block, utilities/resnet.py:85-91): relu(bn_train(y) + identity) in the BatchNorm's
+    apply pass, n handles on the result; output, running statistics and every gradient against torch's own modules in float64."""
+    from uaps_amd import bounds, conv, fused
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    B, Cin, Cc, H, W = 4, 24, 40, 20, 28
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = (torch.randn(Cc, Cin, 1, 1, device=dev) / 5).requires_grad_(True)
+    idn = torch.randn(B, Cc, H, W, device=dev, requires_grad=True)
+    bn = nn.BatchNorm2d(Cc).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    ref_bn = nn.BatchNorm2d(Cc).double()
+    ref_bn.load_state_dict({k: v.detach().cpu().double() if v.is_floating_point() else v.cpu() for k, v in bn.state_dict().items()})
+    with fused.stat_groups(groups):
+        y, st = conv.conv2d_with_stats(x, w, None)
+        outs = fused.bn_add_relu(y, st, bn, idn, n)
+    outs = (outs,) if n == 1 else outs
+    gs = [torch.randn(B, Cc, H, W, device=dev) for _ in range(n)]
+    sum((o * g).sum() for o, g in zip(outs, gs)).backward()
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    bd = bounds.get(outs[0])
+    if bd is not None:
+        assert float(bounds.value(bd[0])) * bd[1] == float(outs[0].max())
+    # torch, float64, per statistics group
+    xr, wr, ir = x.cpu().double(), w.detach().cpu().double().requires_grad_(True), idn.detach().cpu().double().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
+    Bg = B // groups
+    parts = [ref_bn(yr[g * Bg:(g + 1) * Bg]) for g in range(groups)]
+    outr = torch.relu(torch.cat(parts, 0) + ir)
+    (outr * sum(g.cpu().double() for g in gs)).sum().backward()
+    assert float((outs[0].detach().cpu().double() - outr.detach()).abs().max()) < 1e-4
+    assert float((idn.grad.cpu().double() - ir.grad).abs().max()) < 1e-4
+    assert float((w.grad.cpu().double() - wr.grad).abs().max()) < 1e-3
+    assert float((bn.weight.grad.cpu().double() - ref_bn.weight.grad).abs().max()) < 1e-3
+    assert float((bn.bias.grad.cpu().double() - ref_bn.bias.grad).abs().max()) < 1e-3
+    assert torch.allclose(bn.running_mean.cpu().double(), ref_bn.running_mean, atol=1e-5)
+    assert torch.allclose(bn.running_var.cpu().double(), ref_bn.running_var, rtol=1e-4)

@@ -181,18 +181,20 @@ def _configure_from_environment(l) -> None:
 class CallHints(C.Structure):
     """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
     _fields_ = [("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
-                ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p)]
+                ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p), ("residual", C.c_void_p)]
 
 
-def hints(bounds=(), out_amax=None, stats=None) -> None:
+def hints(bounds=(), out_amax=None, stats=None, residual=None) -> None:
     """bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
-    None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about."""
+    None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about; residual: the
+    tensor a BatchNorm apply pass adds before its ReLU (residual joins)."""
     h = getattr(_tls, "hints", None)
     if h is None:
         h = _tls.hints = CallHints()
     for i in range(3):
         h.bound[i] = None
     h.out_amax = h.stats_mean = h.stats_bias = None
+    h.residual = residual.data_ptr() if residual is not None else None
     if stats is not None:
         if stats[0] is not None:
             h.stats_mean = stats[0].data_ptr()

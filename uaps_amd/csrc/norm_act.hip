@@ -162,11 +162,14 @@ __global__ __launch_bounds__(64) void bn_coef_eval(const float* __restrict__ con
 }
 
 // ---- forward pass 2: out = dropout(leaky_relu((y - mean) * scale + beta)) ---------------------------------
+// res != nullptr (uaps_call_hints::residual, the residual joins of utilities/resnet.py:47-50, 88-91): out = relu(bn(y) + res), no
+// slope, no dropout; amax != nullptr: the bound is raised to max|out|.
 template <bool VEC, bool DROP>
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ y, float* __restrict__ out, int C, long HW,
                                                             const float* __restrict__ mean, const float* __restrict__ coef,
                                                             float slope, float drop_p, float drop_scale, uint64_t seed_in,
-                                                            uint64_t offset, int Bg, const uint32_t* __restrict__ st) {
+                                                            uint64_t offset, int Bg, const uint32_t* __restrict__ st,
+                                                            const float* __restrict__ res, float* __restrict__ amax) {
     const uint64_t seed = uaps::step_key(seed_in, st);
     const int plane = blockIdx.y, chunk = blockIdx.x;
     const int b = plane / C, c = plane - b * C, g = b / Bg;
@@ -174,11 +177,15 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
     const float mu = mean[g * C + c], sc = cf[c], sh = cf[C + c];
     const long pbase = (long)plane * HW;
     const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    float m = 0.f;
     if (VEC) {
         for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
             const float4 v = *reinterpret_cast<const float4*>(y + pbase + i);
             float z[4] = {(v.x - mu) * sc + sh, (v.y - mu) * sc + sh, (v.z - mu) * sc + sh, (v.w - mu) * sc + sh};
-            if (DROP) {
+            if (res != nullptr) {                        // uniform branch
+                const float4 r = *reinterpret_cast<const float4*>(res + pbase + i);
+                z[0] = fmaxf(z[0] + r.x, 0.f); z[1] = fmaxf(z[1] + r.y, 0.f); z[2] = fmaxf(z[2] + r.z, 0.f); z[3] = fmaxf(z[3] + r.w, 0.f);
+            } else if (DROP) {
                 const U4 r = philox4x32_10(offset + (uint64_t)((pbase + i) >> 2), seed);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { z[k] = z[k] > 0.f ? z[k] : z[k] * slope; z[k] = u01(pick(r, k)) >= drop_p ? z[k] * drop_scale : 0.f; }
@@ -187,18 +194,28 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restr
                 for (int k = 0; k < 4; ++k) z[k] = z[k] > 0.f ? z[k] : z[k] * slope;
             }
             *reinterpret_cast<float4*>(out + pbase + i) = make_float4(z[0], z[1], z[2], z[3]);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))));
         }
     } else {
         for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
             float z = (y[pbase + i] - mu) * sc + sh;
-            z = z > 0.f ? z : z * slope;
-            if (DROP) {
-                const long e = pbase + i;
-                const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
-                z = u01(pick(r, (int)(e & 3))) >= drop_p ? z * drop_scale : 0.f;
+            if (res != nullptr) {
+                z = fmaxf(z + res[pbase + i], 0.f);
+            } else {
+                z = z > 0.f ? z : z * slope;
+                if (DROP) {
+                    const long e = pbase + i;
+                    const U4 r = philox4x32_10(offset + (uint64_t)(e >> 2), seed);
+                    z = u01(pick(r, (int)(e & 3))) >= drop_p ? z * drop_scale : 0.f;
+                }
             }
             out[pbase + i] = z;
+            m = fmaxf(m, fabsf(z));
         }
+    }
+    if (amax != nullptr) {                               // uniform branch
+        __shared__ float sm[16];
+        uaps::block_amax_to(amax, m, sm);
     }
 }
 
@@ -409,7 +426,9 @@ static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_i
                        given_partials ? given_parts_per_image : nch, (double)HW, conv_bias, gamma, beta, running_mean,
                        running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, w.coef, C, (float2*)nullptr, shm, shb);
     const float dscale = 1.f / (1.f - drop_p);
-#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state())
+    const float* res = hints.residual;
+    if (res && (drop_p > 0.f || !al16(res))) return UAPS_EINVAL;      // the join has no dropout; the residual is a tensor like y
+#define UAPS_APPLY(V, D) hipLaunchKernelGGL((bn_apply_kernel<V, D>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, drop_p, dscale, seed, offset, Bg, (const uint32_t*)uaps_get_step_state(), res, hints.out_amax)
     if (vec) { if (drop_p > 0.f) UAPS_APPLY(true, true); else UAPS_APPLY(true, false); }
     else { if (drop_p > 0.f) UAPS_APPLY(false, true); else UAPS_APPLY(false, false); }
 #undef UAPS_APPLY
@@ -477,9 +496,9 @@ extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, cons
     hipLaunchKernelGGL(bn_coef_eval, dim3((C + 63) / 64), dim3(64), 0, s, conv_bias, gamma, beta, running_mean, running_var, eps, w.coef, save_mean, C);
     const dim3 grid(nchunks_for(HW), B * C);
     if ((HW % 4 == 0) && al16(y) && al16(out))
-        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B, (const uint32_t*)nullptr, (const float*)nullptr, (float*)nullptr);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(kThreads), 0, s, y, out, C, HW, save_mean, w.coef, slope, 0.f, 1.f, 0ull, 0ull, B, (const uint32_t*)nullptr, (const float*)nullptr, (float*)nullptr);
     return (int)hipGetLastError();
 }
 

@@ -114,6 +114,80 @@ class _BnActTrain(torch.autograd.Function):
         return dy, (dgb[2] if has_bias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None, None
 
 
+class _BnAddRelu(torch.autograd.Function):
+    """relu(batch_norm_train(y) + identity) -- the end of a residual block (utilities/resnet.py:44-50, 85-91) -- in the BatchNorm's
+    apply pass, handed out as `n` handles on one tensor (one per consumer, see res_uaps.add_relu).  The backward sums the consumers'
+    gradients behind the ReLU mask in one pass (uaps_relu_bwd_sum); that sum is the identity's gradient and, through the usual
+    BatchNorm backward with an identity activation, y's."""
+
+    @staticmethod
+    def forward(ctx, y, identity, gamma, beta, running_mean, running_var, nbt, momentum, eps, groups, stats_partials, n, am):
+        _lib.require_device(y, "bn_add_relu")
+        ctx.set_materialize_grads(False)
+        y, identity = y.contiguous(), identity.contiguous()
+        B, Cc, H, W = y.shape
+        if identity.shape != y.shape or B % groups:
+            raise ValueError(f"bn_add_relu: y {tuple(y.shape)}, identity {tuple(identity.shape)}, {groups} statistics groups")
+        if stats_partials.shape[:2] != (Cc, B) or stats_partials.shape[-1] != 2 or not stats_partials.is_contiguous():
+            raise ValueError("bn_add_relu: stats must be the [C, B, parts, 2] tensor conv2d_with_stats returned for this y")
+        dev = y.device
+        out = torch.empty_like(y)
+        stats = torch.empty((2, groups * Cc), dtype=torch.float32, device=dev)
+        ws = _bn_ws(dev, B, Cc, H, W)
+        with _lib.device_guard(dev):
+            shifted = getattr(stats_partials, "_uaps_shifted", False)
+            _lib.hints((), am, (running_mean, None) if shifted else None, residual=identity)
+            rc = _lib.lib().uaps_bn_act_fwd_train_partials(
+                stats_partials.data_ptr(), int(stats_partials.shape[2]), y.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(),
+                running_mean.data_ptr() if running_mean is not None else None,
+                running_var.data_ptr() if running_var is not None else None, nbt.data_ptr() if nbt is not None else None,
+                float(momentum), float(eps), 1.0, 0.0, 0, 0, B, Cc, H, W, groups, out.data_ptr(), stats[0].data_ptr(),
+                stats[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_bn_act_fwd_train_partials")
+        ctx.save_for_backward(y, gamma, beta, stats, out)
+        ctx.groups = groups
+        ctx.keys = (id(gamma), id(beta))
+        return tuple(out.view_as(out) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        y, gamma, beta, stats, out = ctx.saved_tensors
+        gs = [g.contiguous() for g in douts if g is not None]
+        if not gs:
+            return (None,) * 13
+        B, Cc, H, W = y.shape
+        dev = y.device
+        d = torch.empty_like(y)
+        dy = torch.empty_like(y)
+        dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys]
+        ws = _bn_ws(dev, B, Cc, H, W)
+        am = bounds.new_amax(dev) if bounds.enabled() else None
+        L = _lib.lib()
+        with _lib.device_guard(dev):
+            st = _lib.current_stream(dev)
+            arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
+            _lib.check(L.uaps_relu_bwd_sum(arr, len(gs), out.data_ptr(), d.data_ptr(), out.numel(), st), "uaps_relu_bwd_sum")
+            if am is not None:
+                _lib.hints((), am)
+            rc = L.uaps_bn_act_bwd_grouped(d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                                           stats[1].data_ptr(), 1.0, 0.0, 0, 0, B, Cc, H, W, ctx.groups, dy.data_ptr(), dgb[0].data_ptr(),
+                                           dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), st)
+        _lib.check(rc, "uaps_bn_act_bwd_grouped")
+        bounds.put(dy, am)
+        return dy, d, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+
+
+def bn_add_relu(y: torch.Tensor, stats: torch.Tensor, bn: nn.BatchNorm2d, identity: torch.Tensor, n: int = 1):
+    """relu(bn_train(y) + identity) with `y`, `stats` from conv2d_with_stats; n > 1: a tuple of n handles on the result."""
+    if not 1 <= n <= 4:
+        raise ValueError("bn_add_relu: 1..4 consumers")
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    am = bounds.new_amax(y.device) if bounds.enabled() else None      # max(out), raised by the apply pass: the join feeds the next block's convolutions
+    outs = tuple(bounds.put(o, am) for o in _BnAddRelu.apply(y, identity, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                            bn.num_batches_tracked, mom, bn.eps, STAT_GROUPS, stats, n, am))
+    return outs[0] if n == 1 else outs
+
+
 class _BnActEval(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, conv_bias, gamma, beta, running_mean, running_var, eps, slope):

@@ -111,6 +111,19 @@ def conv_bn_act(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, 
     return fused.bn_act(y, None, bn, slope, 0.0, training)
 
 
+def conv_bn_add_relu(x: torch.Tensor, cv: nn.Conv2d, bn: nn.BatchNorm2d, identity: torch.Tensor, n: int, training: bool):
+    """relu(bn(conv(x)) + identity), the end of a residual block (resnet.py:44-50, 85-91).  Training on the GPU with a stride-1
+    convolution of the tiled kernels: the join happens in the BatchNorm's apply pass (fused.bn_add_relu) -- the normalised tensor is
+    never written; otherwise the separate kernels."""
+    k, d = cv.kernel_size[0], cv.dilation[0]
+    own = cv.stride == (1, 1) and cv.groups == 1 and cv.bias is None and ((k == 1 and d == 1) or (k == 3 and d in (1, 2, 4) and cv.padding == (d, d))) \
+        and not (k == 3 and d > 1 and cv.in_channels <= 4)
+    if x.is_cuda and training and own and torch.is_grad_enabled():
+        y, st = conv.conv2d_with_stats(x, cv.weight, None, dilation=d)
+        return fused.bn_add_relu(y, st, bn, identity, n)
+    return add_relu(conv_bn_act(x, cv, bn, False, training), identity, n)
+
+
 def _conv3x3(inp, out, stride=1, dilation=1):
     return nn.Conv2d(inp, out, 3, stride=stride, padding=dilation, bias=False, dilation=dilation)      # resnet.py:8-10
 
@@ -137,9 +150,8 @@ class BasicBlock(nn.Module):
         """x_id: a second handle on the input for the shortcut, n_out: handles wanted on the output (add_relu)."""
         x_id = x if x_id is None else x_id
         out = conv_bn_act(x, self.conv1, self.bn1, True, self.training)
-        out = conv_bn_act(out, self.conv2, self.bn2, False, self.training)
         identity = x_id if self.downsample is None else conv_bn_act(x_id, self.downsample[0], self.downsample[1], False, self.training)
-        return add_relu(out, identity, n_out)
+        return conv_bn_add_relu(out, self.conv2, self.bn2, identity, n_out, self.training)
 
 
 class Bottleneck(nn.Module):
@@ -163,9 +175,8 @@ class Bottleneck(nn.Module):
         x_id = x if x_id is None else x_id
         out = conv_bn_act(x, self.conv1, self.bn1, True, self.training)
         out = conv_bn_act(out, self.conv2, self.bn2, True, self.training)
-        out = conv_bn_act(out, self.conv3, self.bn3, False, self.training)
         identity = x_id if self.downsample is None else conv_bn_act(x_id, self.downsample[0], self.downsample[1], False, self.training)
-        return add_relu(out, identity, n_out)
+        return conv_bn_add_relu(out, self.conv3, self.bn3, identity, n_out, self.training)
 
 
 class ResNet(nn.Module):
