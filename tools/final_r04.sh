@@ -1,14 +1,21 @@
 #!/bin/bash
-# Round-4 closing artifacts from ONE gpurun call on one box: the two PMC passes (their summary feeds the bench line's `traffic` and
-# `step_hbm_bytes`), the default bench line, single-stream kernel stats, and the kernel stats of the ResNet-50 configuration.
-# Copy gpurun_out/r04/* into profiles/ afterwards.
+# Round-4 closing artifacts from ONE gpurun call on one box: the PMC passes of the headline configuration and of the two other
+# configurations (their summaries feed the bench line's `traffic` / `step_hbm_bytes`), the default bench line, single-stream
+# kernel stats, and the kernel stats of the ResNet-50 configuration.  Copy gpurun_out/r04/* into profiles/ afterwards.
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r04
 cd $R
 bash tools/gpu_pmc.sh > gpurun_out/r04/pmc.log 2>&1
 cp gpurun_out/pmc/summary.txt gpurun_out/r04/pmc_traffic_summary.txt
 cp gpurun_out/pmc/pmc_traffic.json gpurun_out/r04/pmc_traffic.json
-cp gpurun_out/pmc/pmc_traffic.json profiles/pmc_traffic.json        # the box's copy: the bench line below reads it
+bash tools/gpu_pmc_cfg.sh configs3 --net unet_uaps --in-chns 1 --classes 2 --aux 5 --batch 8 --size 512 > gpurun_out/r04/pmc_configs3.log 2>&1
+bash tools/gpu_pmc_cfg.sh configs4 --net resnet50_uaps --in-chns 3 --classes 2 --aux 3 --batch 8 --size 640 > gpurun_out/r04/pmc_configs4.log 2>&1
+for t in configs3 configs4; do
+  cp gpurun_out/pmc_$t/summary.txt gpurun_out/r04/pmc_traffic_summary_$t.txt
+  cp gpurun_out/pmc_$t/pmc_traffic.json gpurun_out/r04/pmc_traffic_$t.json
+  cp gpurun_out/pmc_$t/pmc_traffic.json profiles/pmc_traffic_$t.json      # the box's copy: the bench line below reads these
+done
+cp gpurun_out/pmc/pmc_traffic.json profiles/pmc_traffic.json
 timeout 1500 python bench.py > gpurun_out/r04/bench.json 2> gpurun_out/r04/bench.err
 tail -c 400 gpurun_out/r04/bench.err
 bash tools/gpu_prof.sh > gpurun_out/r04/prof.log 2>&1
