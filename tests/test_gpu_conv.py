@@ -62,6 +62,11 @@ SHAPES = [
     (2, 32, 12, 16, 256, 3),
     (3, 3, 16, 32, 256, 3),     # the first layer: its weight gradient rides in the 16-channel row kernel, absent channels never fetched
     (2, 20, 12, 16, 256, 3),    # ... and 20 of 32 channels
+    # wider than 256 pixels: the same kernels on 256-wide column strips, one real neighbour pixel either side of a strip
+    (2, 16, 16, 32, 512, 3),
+    (1, 32, 16, 16, 768, 3),
+    (2, 16, 4, 16, 512, 3),
+    (2, 3, 16, 16, 512, 3),
     (2, 32, 16, 32, 256, 3),    # its input gradient (16 -> 32 channels) takes two output tiles of the row kernel
     (40, 16, 16, 256, 256, 3),
 ]
@@ -154,7 +159,8 @@ def test_conv_refuses_cpu_tensors():
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(4, 16, 16, 64, 64), (2, 8, 40, 24, 36), (2, 32, 128, 16, 16),
                                             (4, 32, 32, 256, 256), (4, 16, 64, 252, 256),           # these two: persistent slice kernels
                                             (6, 24, 32, 200, 264),          # 32-channel block on 16-row tiles, the last one half outside: parts stay per 8 rows
-                                            (4, 16, 16, 64, 256), (4, 32, 16, 32, 256), (2, 16, 10, 48, 256)])     # full-width-row kernels: parts stay 8 x 32 tiles
+                                            (4, 16, 16, 64, 256), (4, 32, 16, 32, 256), (2, 16, 10, 48, 256),      # full-width-row kernels: parts stay 8 x 32 tiles
+                                            (2, 16, 16, 32, 512), (2, 32, 16, 16, 768)])     # ... on column strips
 def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
     """conv2d_with_stats: the per-tile (sum, sum of squares) written by the conv epilogue must add up to the
     statistics of y, and bn_act fed with them must equal bn_act running its own statistics pass."""
@@ -182,7 +188,8 @@ def test_conv_epilogue_statistics_feed_batchnorm(B, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("B,C1,C2,Cout,H,W,ks", [(2, 16, 16, 16, 64, 64, 3), (2, 32, 32, 32, 32, 32, 3), (1, 128, 128, 128, 16, 16, 3),
                                                   (2, 16, 24, 20, 24, 40, 3), (2, 32, 16, 8, 16, 16, 1), (4, 16, 16, 32, 256, 256, 3),
-                                                  (3, 16, 16, 16, 32, 256, 3)])      # two tensors into the full-width-row kernels
+                                                  (3, 16, 16, 16, 32, 256, 3),       # two tensors into the full-width-row kernels
+                                                  (2, 16, 16, 16, 16, 512, 3), (2, 16, 16, 32, 32, 512, 3)])      # ... on column strips (the second: 16 + 16 output channels)
 def test_conv_cat_equals_conv_of_concatenation(B, C1, C2, Cout, H, W, ks):
     """conv2d_cat(x1, x2, w) must be conv2d(cat([x1, x2]), w) bit for bit (same kernels, same order of operations),
     and so must its three gradients."""

@@ -273,7 +273,9 @@ def test_hip_adam_matches_torch_adam_and_shares_its_state_dict():
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ks,groups", [(4, 16, 16, 64, 64, 3, 2), (2, 32, 24, 16, 32, 3, 1), (4, 64, 32, 8, 8, 1, 2),
                                                       (2, 16, 4, 48, 80, 3, 1), (6, 40, 48, 20, 12, 3, 3), (2, 128, 64, 32, 32, 1, 1),
-                                                      (4, 32, 32, 256, 256, 3, 2)])
+                                                      (4, 32, 32, 256, 256, 3, 2),
+                                                      # the full-width-row kernels with the staging-time BatchNorm: 256 wide, and column strips
+                                                      (2, 16, 16, 32, 256, 3, 2), (2, 16, 16, 32, 512, 3, 2), (2, 16, 4, 16, 512, 3, 1)])
 def test_bn_act_conv_equals_bn_act_then_conv_and_torch(B, Cin, Cout, H, W, ks, groups):
     """conv2(leaky_relu(bn_train(conv1(x)))) with the normalisation applied while conv2 stages its input
     (fused.bn_act_conv: uaps_bn_finalize_train + uaps_conv_fwd_bn + uaps_conv_bwd_weight_partial_bn) against

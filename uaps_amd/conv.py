@@ -76,24 +76,25 @@ class _timed:
                 self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg | (1 << 28))
             if h16:                   # every tensor operand carried a bound: the fp16 two-piece instantiation of the same plan ran
                 kin = Cout if kind == "bwd_data" else Cin
-                if (self.name.startswith("conv_small_") and "wrw" not in self.name and W == 256 and H % 16 == 0 and kin in (16, 24, 32)
+                if (self.name.startswith("conv_small_") and "wrw" not in self.name and W % 256 == 0 and H % 16 == 0 and kin in (16, 24, 32)
                         and not (_lib.lib().uaps_conv_get_tuning() & (128 | 8))):
                     # <= 4 output channels on a 256-wide map: the full-width-row kernel (csrc/conv_fwd.hip: row16)
-                    self.name = ("conv_hr16_bn_kernel" if "_bn_" in self.name else "conv_hr16_kernel") + ("<2>" if kin <= 16 else "<4>")
+                    self.name = ("conv_hr16%s_bn_kernel" if "_bn_" in self.name else "conv_hr16%s_kernel") % ("w" if W > 256 else "") + ("<2>" if kin <= 16 else "<4>")
                 if self.name.startswith("conv_sfwd") and "<3, 8, 32, 16," in self.name and 8 < kin <= 32:
                     # <= 16 output channels on a wide map: the persistent kernels of csrc/conv_split_n16.hpp
-                    row = W == 256 and H % 16 == 0 and not (_lib.lib().uaps_conv_get_tuning() & 128)      # csrc/conv_fwd.hip: launch_hr16
-                    self.name = ("conv_h%s16_bn_kernel" if "_bn_" in self.name else "conv_h%s16_kernel") % ("r" if row else "p") + ("<2>" if kin <= 16 else "<4>")
-                if (kind == "bwd_data" and ks == 3 and kin == 16 and Cin == 32 and W == 256 and H % 16 == 0 and self.name.startswith("conv_s32")
+                    row = W % 256 == 0 and H % 16 == 0 and not (_lib.lib().uaps_conv_get_tuning() & 128)      # csrc/conv_fwd.hip: launch_hr16
+                    fam = ("r16w" if W > 256 else "r16") if row else "p16"      # wider than 256: the column-strip instantiations
+                    self.name = ("conv_h%s_bn_kernel" if "_bn_" in self.name else "conv_h%s_kernel") % fam + ("<2>" if kin <= 16 else "<4>")
+                if (kind == "bwd_data" and ks == 3 and kin == 16 and Cin == 32 and W % 256 == 0 and H % 16 == 0 and self.name.startswith("conv_s32")
                         and not (_lib.lib().uaps_conv_get_tuning() & (128 | 8))):
-                    self.name = "conv_hr16x2_kernel"       # 16 -> 16 + 16 channels: two output tiles of the full-width-row kernel
+                    self.name = "conv_hr16wx2_kernel" if W > 256 else "conv_hr16x2_kernel"       # 16 -> 16 + 16 channels: two output tiles of the full-width-row kernel
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
-                if (kind in ("wrw", "wrw_bn") and ks == 3 and W == 256 and H % 16 == 0 and Cout <= 16 and Cin <= 32 and not (cfg >> 24)
+                if (kind in ("wrw", "wrw_bn") and ks == 3 and W % 256 == 0 and H % 16 == 0 and Cout <= 16 and Cin <= 32 and not (cfg >> 24)
                         and (self.name.startswith("conv_hwrw") or self.name.startswith("conv_small_wrw") or self.name.startswith("conv_wrw_"))
                         and not (_lib.lib().uaps_conv_get_tuning() & (256 | 2))):
                     # the full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp; csrc/conv_wrw.hip: the eligibility block)
-                    self.name = ("conv_hrwrw_bn_kernel<%d>" if "_bn_" in self.name else "conv_hrwrw_kernel<%d>") % (1 if Cin <= 16 else 2)
+                    self.name = ("conv_hrwrw%s_bn_kernel<%d>" if "_bn_" in self.name else "conv_hrwrw%s_kernel<%d>") % ("w" if W > 256 else "", 1 if Cin <= 16 else 2)
                 if self.name.startswith("conv_hwrw") and "_kernel<4, 1, " in self.name and H >= 8 and not (_lib.lib().uaps_conv_get_tuning() & 32):
                     self.name = self.name.replace("_kernel<4, 1, ", "_kernel<8, 1, ")      # 16 output channels: the 8-row tiles (csrc/conv_wrw.hip: launch_swrw)
                 if self.name.startswith("conv_wrw_kernel<3, 4, 32, 2, 2, 4, ") and not self.name.endswith(" 1>") and W >= 32 and Cin >= 16:

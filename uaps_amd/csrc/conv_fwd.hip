@@ -120,28 +120,40 @@ int launch_hp16(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// full-width-row kernels of conv_split_row16.hpp (fp16 form, 256-pixel-wide maps, H % 16 == 0): runs of 16 rows, 2 workgroups of
+// full-width-row kernels of conv_split_row16.hpp (fp16 form, maps of 256 pixels width -- or a multiple: 256-wide column strips --, H % 16 == 0): runs of 16 rows, 2 workgroups of
 // 256 threads per CU for 16 input channels, 1 workgroup of 512 threads (135 KB of LDS) for 32
 int launch_hr16(ConvFwdArgs a, hipStream_t s) {
-    const long nruns = (long)a.B * (a.H / 16);
+    const long nruns = (long)a.B * (a.H / 16) * (a.W / 256);      // a run: 16 rows of one 256-wide column strip
     if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
     const long want = a.Cin <= 16 ? 512 : 256;
     const unsigned grid = (unsigned)(((nruns < want ? nruns : want) + 7) / 8 * 8);
+    const bool strips = a.W > 256;
     if (a.Cin <= 16) {
-        if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16_bn_kernel<2>), dim3(grid), dim3(256), 0, s, a);
-        else UAPS_LAUNCH_MAIN((conv_hr16_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+        if (strips) {
+            if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16w_bn_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+            else UAPS_LAUNCH_MAIN((conv_hr16w_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+        } else {
+            if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16_bn_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+            else UAPS_LAUNCH_MAIN((conv_hr16_kernel<2>), dim3(grid), dim3(256), 0, s, a);
+        }
     } else {
-        if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16_bn_kernel<4>), dim3(grid), dim3(512), 0, s, a);
-        else UAPS_LAUNCH_MAIN((conv_hr16_kernel<4>), dim3(grid), dim3(512), 0, s, a);
+        if (strips) {
+            if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16w_bn_kernel<4>), dim3(grid), dim3(512), 0, s, a);
+            else UAPS_LAUNCH_MAIN((conv_hr16w_kernel<4>), dim3(grid), dim3(512), 0, s, a);
+        } else {
+            if (a.xf) UAPS_LAUNCH_MAIN((conv_hr16_bn_kernel<4>), dim3(grid), dim3(512), 0, s, a);
+            else UAPS_LAUNCH_MAIN((conv_hr16_kernel<4>), dim3(grid), dim3(512), 0, s, a);
+        }
     }
     return (int)hipGetLastError();
 }
 
 int launch_hr16x2(ConvFwdArgs a, hipStream_t s) {
-    const long nruns = (long)a.B * (a.H / 16);
+    const long nruns = (long)a.B * (a.H / 16) * (a.W / 256);
     if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
     const unsigned grid = (unsigned)(((nruns < 512 ? nruns : 512) + 7) / 8 * 8);
-    UAPS_LAUNCH_MAIN(conv_hr16x2_kernel, dim3(grid), dim3(256), 0, s, a);
+    if (a.W > 256) UAPS_LAUNCH_MAIN(conv_hr16wx2_kernel, dim3(grid), dim3(256), 0, s, a);
+    else UAPS_LAUNCH_MAIN(conv_hr16x2_kernel, dim3(grid), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -326,7 +338,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     const bool no_small = (g_conv_tuning & UAPS_TUNE_NO_SMALL) != 0;
     // (on 256-wide maps with bounded operands the full-width-row kernel serves <= 4 output channels too: padded to one 16-channel
     // MFMA tile it streams at the HBM rate of a 16 -> 16 layer, which the 16 x 64-tile VALU kernel does not reach)
-    const bool row16 = p.split && conv_mode() == 2 && hints.bound[0] && ks == 3 && p.dil == 1 && W == 256 && H % 16 == 0 && p.CoutP == 16 &&
+    const bool row16 = p.split && conv_mode() == 2 && hints.bound[0] && ks == 3 && p.dil == 1 && W % 256 == 0 && H % 16 == 0 && p.CoutP == 16 &&
                        Cin > 8 && Cin <= 32 && Cin % 8 == 0 && !y2 && (!x2 || Csplit >= Cin || hints.bound[1]) &&
                        !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16));
     if (!no_small && !row16 && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
@@ -350,13 +362,13 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         // 16 -> 32 channels on a 256-wide map without statistics (the input gradient of up4's two-tensor convolution): two output
         // tiles of the full-width-row kernel, written as one or two 16-channel tensors
         if (a.wscale && ks == 3 && p.dil == 1 && Cin == 16 && Cout == 32 && !stats && !xf && !x2 && (Osplit == Cout || Osplit == 16) &&
-            W == 256 && H % 16 == 0 && !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16))) return launch_hr16x2(a, s);
+            W % 256 == 0 && H % 16 == 0 && !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16))) return launch_hr16x2(a, s);
         if (p.dil > 1) return p.sbn == 64 ? launch_s32d<64>(a, p.dil, s) : launch_s32d<32>(a, p.dil, s);
         if (p.s32 && p.s32t) return launch_s32t(a, s);
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
         if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) {
-            if (W == 256 && H % 16 == 0 && !(g_conv_tuning & UAPS_TUNE_NO_ROW16)) return launch_hr16(a, s);
+            if (W % 256 == 0 && H % 16 == 0 && !(g_conv_tuning & UAPS_TUNE_NO_ROW16)) return launch_hr16(a, s);
             return launch_hp16(a, s);
         }
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);

@@ -26,7 +26,9 @@ namespace uaps {
 // NCG = input channels / 8 (2 or 4); threads = 128 * NCG (one wave per (row of the pair, channel group)); XF as in conv_fwd_body;
 // NT = 16-channel output tiles (2: the input gradient of the two-tensor convolution of up4, 16 -> 16 + 16 channels written as two
 // tensors, a.out / a.out2 with Osplit = 16; no statistics epilogue in that form)
-template <int NCG, bool XF, int NT = 1>
+// STRIP: maps wider than 256 pixels (W % 256 == 0) as 256-wide column strips: a run is 16 rows of one strip, and the one real pixel
+// either side of a strip (zero at the image edge) is fetched per row into the margin units that the 256-wide form leaves zero
+template <int NCG, bool XF, int NT = 1, bool STRIP = false>
 __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     constexpr int WIDTH = 256, IW = WIDTH + 8, NSLOT = 4, ROWS = 16, XS = 3;
     constexpr int NWV = 2 * NCG, NTHR = 64 * NWV, HALF = NWV / 2;
@@ -50,7 +52,8 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     const f32x2 sc = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
     const float in_scale = sc.x, out_scale_a = sc.y, out_scale_w = a.wscale[1];
 
-    const int rpi = a.H / ROWS, nruns = a.B * rpi;    // runs per image (H % 16 == 0: the launcher checks)
+    const int rps = a.H / ROWS;                       // runs per strip (H % 16 == 0: the launcher checks)
+    const int nstrips = STRIP ? a.W / WIDTH : 1, rpi = rps * nstrips, nruns = a.B * rpi;      // run -> (image, strip, 16-row band): a strip's bands are consecutive
     const int nblk = gridDim.x;
     int run = xcd_swizzle(blockIdx.x, gridDim.x);     // consecutive runs share their two boundary rows: one XCD's L2
     if (run >= nruns) return;
@@ -89,21 +92,29 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     // ---- staging: this wave stages channel group scg of row (pair base + srr); lane = pixels 4 lane .. 4 lane + 3 ----
     const int scg = wave_u % NCG, srr = wave_u / NCG;
     float rin[8][4];
+    float rh[1] = {0.f};                              // STRIP: lanes 0..7 the pixel left of the strip, lanes 8..15 the pixel right of it, channel lane & 7
     f32x2 rxf[XF ? 8 : 1];
-    bool uin = false;
+    f32x2 rxf_h = f32x2{0.f, 0.f};                    // STRIP && XF: the coefficients of channel lane & 7
+    bool uin = false, hin = false;                    // hin (per lane): rh holds a pixel of the image
     int urow = 0;                                     // the row the registers hold
     const int c0 = scg * 8;
     const bool second = c0 >= a.Csplit;               // wave-uniform: a channel group lies in one source (Csplit % 8 == 0)
 
-    auto load_pair = [&](int b, int y1) {             // rows y1 and y1 + 1 of image b
+    auto load_pair = [&](int b, int y1, int x0) {     // rows y1 and y1 + 1 of image b, columns x0 .. x0 + 255
         const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
                                                  : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
         const int gy = y1 + srr;
         urow = gy;
         uin = (unsigned)gy < (unsigned)a.H && c0 < a.Cin;
-        const uint32_t off = (uint32_t)((second ? c0 - a.Csplit : c0) * HW + gy * a.W + lane * 4) * 4u;
+        const uint32_t off = (uint32_t)((second ? c0 - a.Csplit : c0) * HW + gy * a.W + x0 + lane * 4) * 4u;
 #pragma unroll
         for (int c = 0; c < 8; ++c) buf_load<4>(rs, uin ? off + (uint32_t)c * HW4 : kOob, rin[c]);
+        if constexpr (STRIP) {
+            const int hx = lane < 8 ? x0 - 1 : x0 + WIDTH;
+            const bool hok = uin && lane < 16 && (unsigned)hx < (unsigned)a.W && c0 + (lane & 7) < a.Cin;
+            hin = hok;
+            buf_load<1>(rs, hok ? (uint32_t)(((second ? c0 - a.Csplit : c0) + (lane & 7)) * HW + gy * a.W + hx) * 4u : kOob, rh);
+        }
     };
     auto load_xf = [&](int b) {
         if constexpr (XF) {
@@ -111,6 +122,8 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)               // channels past Cin read (0, 0)
                 rxf[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, (int)((uint32_t)(c0 + c) * 8u), 0, 0));
+            if constexpr (STRIP)
+                rxf_h = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_xf, (int)((uint32_t)(c0 + (lane & 7)) * 8u), 0, 0));
         }
     };
     // fetched row -> two fp16 pieces per element (XF: leaky_relu(fma(y, scale, shift)) first; rows outside the image stay zero), into its slot
@@ -137,6 +150,22 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
             sIn[base + p] = p0;
             sIn[PIECE + base + p] = p1;
         }
+        if constexpr (STRIP) {                        // the strip's two neighbour pixels: channel pair (lane & 6, + 1) -> one dword of the margin unit
+            asm volatile("" : "+v"(rh[0]));
+            float v = rh[0];
+            if constexpr (XF) {
+                const float z = __builtin_fmaf(v, rxf_h.x, rxf_h.y);
+                v = hin ? __builtin_fmaxf(z, z * a.xf_slope) : 0.f;      // pixels outside the image stay zero
+            }
+            const float vo = __shfl_xor(v, 1, 64);
+            unsigned q0, q1;
+            conv_split2h(v * in_scale, vo * in_scale, q0, q1);
+            if (lane < 16 && !(lane & 1)) {
+                const int unit = (scg * NSLOT + ((urow + 1) & 3)) * IW + (lane < 8 ? 3 : 4 + WIDTH);
+                reinterpret_cast<unsigned*>(&sIn[unit])[(lane & 7) >> 1] = q0;
+                reinterpret_cast<unsigned*>(&sIn[PIECE + unit])[(lane & 7) >> 1] = q1;
+            }
+        }
     };
 
     // ---- matrix work: this wave's output row orr of the pair and its M tiles [tb, tb + MW) ----
@@ -152,18 +181,19 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     float st_s[NTC], st_q[NTC];
 #pragma unroll
     for (int i = 0; i < NTC; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
-    const int tiles8 = a.H / 8, tpi = tiles8 * 8;     // statistics parts per image: 8-row x 32-pixel tiles, as the tile kernels write them
+    const int tiles8 = a.H / 8;                       // statistics parts per image: 8-row x 32-pixel tiles, as the tile kernels write them
 
+    const int txs = a.W / 32;                         // statistics tiles per tile row
     {
-        const int b = run / rpi, r0 = (run % rpi) * ROWS;
-        load_pair(b, r0 - 1);
+        const int b = run / rpi, rr = run % rpi;
+        load_pair(b, (rr % rps) * ROWS - 1, (rr / rps) * WIDTH);
     }
     for (; run < nruns; run += nblk) {
-        const int b = run / rpi, r0 = (run % rpi) * ROWS;
+        const int b = run / rpi, rr = run % rpi, r0 = (rr % rps) * ROWS, x0 = (rr / rps) * WIDTH;
         const bool next_run = run + nblk < nruns;
         load_xf(b);
         store_pair();                                 // rows r0 - 1, r0
-        load_pair(b, r0 + 1);
+        load_pair(b, r0 + 1, x0);
         store_pair();                                 // rows r0 + 1, r0 + 2
         __syncthreads();
         // branch-free output stores (lanes of padded channels store out of range): a store inside a branch makes the compiler's
@@ -181,8 +211,8 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
 #pragma unroll 1
         for (int k = 0; k < ROWS / 2; ++k) {
             const int y = r0 + 2 * k;                 // output rows y, y + 1 from input rows y - 1 .. y + 2
-            if (k + 1 < ROWS / 2) load_pair(b, y + 3);
-            else if (next_run) { const int nr = run + nblk; load_pair(nr / rpi, (nr % rpi) * ROWS - 1); }
+            if (k + 1 < ROWS / 2) load_pair(b, y + 3, x0);
+            else if (next_run) { const int nr = run + nblk, nrr = nr % rpi; load_pair(nr / rpi, (nrr % rps) * ROWS - 1, (nrr / rps) * WIDTH); }
 
             int aoff[NSTEP];
 #pragma unroll
@@ -222,7 +252,7 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
             float chk = 0.f;
 #pragma unroll
             for (int m = 0; m < MW; ++m) {
-                const int gx = (tb + m) * 16 + kq * 4;
+                const int gx = x0 + (tb + m) * 16 + kq * 4;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     f32x4 v = acc[m][n];
@@ -262,7 +292,7 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
                         const int e = ((((o * HALF + wv) * 4 + g) * NTC + i) * 16 + ch) * 2;
                         s0 += sRed[e]; q0 += sRed[e + 1];
                     }
-                a.stats[((size_t)ch * a.B + b) * tpi + ((r0 + 2 * k) / 8) * 8 + tc] = make_float2(s0, q0);
+                a.stats[((size_t)ch * a.B + b) * (tiles8 * txs) + ((r0 + 2 * k) / 8) * txs + x0 / 32 + tc] = make_float2(s0, q0);
             }
             __syncthreads();
         }
@@ -275,5 +305,11 @@ template <int NCG>
 __global__ __launch_bounds__(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
 // 16 -> 32 channels (two 16-channel output tiles, one or two output tensors), no statistics
 __global__ __launch_bounds__(256) void conv_hr16x2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2>(a); }
+// the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
+template <int NCG>
+__global__ __launch_bounds__(128 * NCG) void conv_hr16w_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false, 1, true>(a); }
+template <int NCG>
+__global__ __launch_bounds__(128 * NCG) void conv_hr16w_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true, 1, true>(a); }
+__global__ __launch_bounds__(256) void conv_hr16wx2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2, true>(a); }
 
 }  // namespace uaps

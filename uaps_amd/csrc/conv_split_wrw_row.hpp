@@ -19,7 +19,9 @@
 namespace uaps {
 
 // WCI = input channels / 16 (1 or 2); threads = 256 * WCI; XF: the input is a raw conv output, BatchNorm + LeakyReLU applied while staging
-template <int WCI, bool XF>
+// STRIP: maps wider than 256 pixels (W % 256 == 0) as 256-wide column strips (conv_hr16_body): a run is 16 rows of one strip; the one
+// real pixel either side of a strip goes into the boundary dwords of the two margin groups, which the 256-wide form leaves zero
+template <int WCI, bool XF, bool STRIP = false>
 __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     constexpr int WIDTH = 256, NG = WIDTH / 8, XG = NG + 2, NSLOT = 3, ROWS = 16;
     constexpr int CI = 16 * WCI, NWV = 4 * WCI, NTHR = 64 * NWV;
@@ -46,7 +48,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 
     const int split = xcd_swizzle(blockIdx.x, gridDim.x);
     if (split >= a.nsplit) return;
-    const int rpi = a.H / ROWS, nruns = a.B * rpi;
+    const int rps = a.H / ROWS, rpi = rps * (STRIP ? a.W / WIDTH : 1), nruns = a.B * rpi;      // run -> (image, strip, 16-row band)
     const int run_begin = (int)((long)nruns * split / a.nsplit), run_end = (int)((long)nruns * (split + 1) / a.nsplit);
     const bool want_bias = a.bslab != nullptr;
 
@@ -55,17 +57,25 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 
     // ---- staging: lane = pixels 4 lane .. 4 lane + 3 (half of an 8-pixel unit) of NXL input channels and NDL dy channels ----
     float rx[NXL][4], rd[NDL][4];
+    float rhx[1] = {0.f};                                // STRIP: lanes 0 .. NXL - 1 the pixel left of the strip, NXL .. 2 NXL - 1 the pixel right of it
     f32x2 cf[XF ? NXL : 1];
-    bool x_in = false, d_in = false;
+    f32x2 cf_h = f32x2{0.f, 0.f};                        // STRIP && XF: the coefficients of this lane's margin channel
+    bool x_in = false, d_in = false, h_in = false;
     const int xc0 = wave_u * NXL;                        // this wave's input channels xc0 .. xc0 + NXL - 1 lie in one source (Csplit % 4 == 0)
     const bool second = xc0 >= a.Csplit;
-    auto load_x = [&](int b, int gy, float (&dst)[NXL][4], bool& ok) {
+    int x0 = 0;                                          // first column of the run's strip
+    auto load_x = [&](int b, int gy, float (&dst)[NXL][4], bool& ok, float (&hdst)[1], bool& hok) {
         ok = (unsigned)gy < (unsigned)a.H;
         const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
                                                  : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
-        const uint32_t off = (uint32_t)((second ? xc0 - a.Csplit : xc0) * HW + gy * a.W + lane * 4) * 4u;
+        const uint32_t off = (uint32_t)((second ? xc0 - a.Csplit : xc0) * HW + gy * a.W + x0 + lane * 4) * 4u;
 #pragma unroll
         for (int i = 0; i < NXL; ++i) buf_load<4>(rs, (ok && xc0 + i < a.Cin) ? off + (uint32_t)i * HW4 : kOob, dst[i]);
+        if constexpr (STRIP) {
+            const int hc = lane % NXL, hx = lane < NXL ? x0 - 1 : x0 + WIDTH;
+            hok = ok && lane < 2 * NXL && (unsigned)hx < (unsigned)a.W && xc0 + hc < a.Cin;
+            buf_load<1>(rs, hok ? (uint32_t)(((second ? xc0 - a.Csplit : xc0) + hc) * HW + gy * a.W + hx) * 4u : kOob, hdst);
+        }
     };
     auto load_d = [&](int b, int gy, float (&dst)[NDL][4], bool& ok) {
         ok = (unsigned)gy < (unsigned)a.H;
@@ -73,10 +83,10 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
             const int c = wave_u * NDL + i;
-            buf_load<4>(rs, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + lane * 4) * 4u : kOob, dst[i]);
+            buf_load<4>(rs, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob, dst[i]);
         }
     };
-    auto store_x = [&](float (&src)[NXL][4], bool ok, int slot) {
+    auto store_x = [&](float (&src)[NXL][4], bool ok, int slot, float (&hsrc)[1], bool hok) {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             asm volatile("" : "+v"(src[i][0]), "+v"(src[i][1]), "+v"(src[i][2]), "+v"(src[i][3]));      // first touch (conv_hp16_body)
@@ -97,6 +107,23 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
             unsigned* p1 = reinterpret_cast<unsigned*>(&sX[((CI + c) * NSLOT + slot) * XG + 1]) + lane * 2;
             *reinterpret_cast<uint2*>(p0) = make_uint2(a0, b0);
             *reinterpret_cast<uint2*>(p1) = make_uint2(a1, b1);
+        }
+        if constexpr (STRIP) {                         // pixel x0 - 1 -> high half of the left margin group's last dword, x0 + 256 -> low half of the right one's first
+            asm volatile("" : "+v"(hsrc[0]));
+            float v = hsrc[0];
+            if constexpr (XF) {
+                const float z = __builtin_fmaf(v, cf_h.x, cf_h.y);
+                v = hok ? __builtin_fmaxf(z, z * a.xf_slope) : 0.f;
+            }
+            const bool left = lane < NXL;
+            unsigned q0, q1;
+            conv_split2h(left ? 0.f : v * sc_x, left ? v * sc_x : 0.f, q0, q1);
+            if (lane < 2 * NXL) {
+                const int c = wave_u * NXL + lane % NXL;
+                const int g = (c * NSLOT + slot) * XG + (left ? 0 : XG - 1), d = left ? 3 : 0;
+                reinterpret_cast<unsigned*>(&sX[g])[d] = q0;
+                reinterpret_cast<unsigned*>(&sX[g + CI * NSLOT * XG])[d] = q1;
+            }
         }
     };
     auto store_d = [&](float (&src)[NDL][4]) {
@@ -122,7 +149,13 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{kOnes, kOnes, kOnes, kOnes});
 
     for (int run = run_begin; run < run_end; ++run) {
-        const int b = run / rpi, r0 = (run % rpi) * ROWS;
+        const int b = run / rpi, rr = run % rpi, r0 = (rr % rps) * ROWS;
+        x0 = (rr / rps) * WIDTH;
+        if constexpr (XF && STRIP) {
+            const int c = wave_u * NXL + lane % NXL;
+            cf_h = f32x2{0.f, 0.f};
+            if (c < a.Cin) { const float2 t = a.xf[(size_t)(b / a.xf_Bg) * a.Cin + c]; cf_h = f32x2{t.x, t.y}; }
+        }
         if constexpr (XF) {
 #pragma unroll
             for (int i = 0; i < NXL; ++i) {
@@ -134,16 +167,16 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
         }
         // rows r0 - 1 and r0 into slots 0 and 1, then row r0 + 1 (slot 2) and dy row r0: two fetch rounds, both in flight together
         {
-            float ra[NXL][4], rb[NXL][4];
-            bool oka, okb;
-            load_x(b, r0 - 1, ra, oka);
-            load_x(b, r0, rb, okb);
-            load_x(b, r0 + 1, rx, x_in);
+            float ra[NXL][4], rb[NXL][4], ha[1] = {0.f}, hb[1] = {0.f};
+            bool oka, okb, hoka = false, hokb = false;
+            load_x(b, r0 - 1, ra, oka, ha, hoka);
+            load_x(b, r0, rb, okb, hb, hokb);
+            load_x(b, r0 + 1, rx, x_in, rhx, h_in);
             load_d(b, r0, rd, d_in);
             __builtin_amdgcn_sched_barrier(0);
-            store_x(ra, oka, 0);
-            store_x(rb, okb, 1);
-            store_x(rx, x_in, 2);
+            store_x(ra, oka, 0, ha, hoka);
+            store_x(rb, okb, 1, hb, hokb);
+            store_x(rx, x_in, 2, rhx, h_in);
             store_d(rd);
         }
         __syncthreads();
@@ -151,7 +184,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 #pragma unroll 1
         for (int y = r0; y < r0 + ROWS; ++y) {
             const bool more = y + 1 < r0 + ROWS;
-            if (more) { load_x(b, y + 2, rx, x_in); load_d(b, y + 1, rd, d_in); }
+            if (more) { load_x(b, y + 2, rx, x_in, rhx, h_in); load_d(b, y + 1, rd, d_in); }
 
 #pragma unroll
             for (int sgi = 0; sgi < 2; ++sgi) {
@@ -191,7 +224,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
                 }
             }
             __syncthreads();                              // every wave is done with input row y - 1 and dy row y
-            if (more) { store_x(rx, x_in, s0); store_d(rd); }
+            if (more) { store_x(rx, x_in, s0, rhx, h_in); store_d(rd); }
             s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
             __syncthreads();
         }
@@ -249,5 +282,10 @@ template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrw_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false>(a); }
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true>(a); }
+// the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true>(a); }
 
 }  // namespace uaps

@@ -188,11 +188,11 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
-    // full-width-row kernels (conv_split_wrw_row.hpp): 256-wide maps, <= 16 output and 16 / 32 input channels, every operand bounded;
+    // full-width-row kernels (conv_split_wrw_row.hpp): maps of 256 pixels width or a multiple (256-wide column strips), <= 16 output and 16 / 32 input channels, every operand bounded;
     // they write the slabs of the plan above (split or exact-N), so workspace and reduction do not change
     // (fewer than 16 input channels -- the first layer's 3 -- ride in the 16-channel form: the absent channels are never fetched)
     const bool force_exact = (cfg >> 28) & 1;
-    if (ks == 3 && p.dil == 1 && !force_exact && vec16 && W == 256 && H % 16 == 0 && Cout <= 16 && Cin <= 32 &&
+    if (ks == 3 && p.dil == 1 && !force_exact && vec16 && W % 256 == 0 && H % 16 == 0 && Cout <= 16 && Cin <= 32 &&
         p.CoutS <= 16 && p.CinS == (Cin > 16 ? 32 : 16) && p.ncob == 1 && p.ncib == 1 && uaps_conv_get_mode() == 2 && hints.bound[0] && hints.bound[1] &&
         (!x2 || Csplit >= Cin || (hints.bound[2] && Csplit % 4 == 0)) &&
         !(uaps_conv_get_tuning() & (UAPS_TUNE_NO_ROW_WRW | UAPS_TUNE_NO_SPLIT_WRW))) {
@@ -201,7 +201,15 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
         a.err = uaps::error_word();
         const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
-        if (Cin <= 16) {
+        if (W > 256) {                                 // 256-wide column strips
+            if (Cin <= 16) {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrww_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+            } else {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrww_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+            }
+        } else if (Cin <= 16) {
             if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw_bn_kernel<1>), dim3(grid), dim3(256), 0, s, a);
             else UAPS_LAUNCH_MAIN((conv_hrwrw_kernel<1>), dim3(grid), dim3(256), 0, s, a);
         } else {

@@ -350,7 +350,7 @@ class _PairLoss(torch.autograd.Function):
         # tracking costs the backward kernel 17 us of VALU work (53 -> 70 us at 16 + 16 images of 256 x 256).  On 256-wide maps the
         # bound is wanted again: out_conv's weight gradient then runs the full-width-row kernel (csrc/conv_split_wrw_row.hpp,
         # 4 x ~25 us less than the exact-N kernel at that size)
-        row_wrw = W == 256 and H % 16 == 0
+        row_wrw = W % 256 == 0 and H % 16 == 0
         am = bounds.new_amax(dev) if bounds.enabled() and (row_wrw or not (Cc <= 4 and W >= 64 and W % 4 == 0)) else None
         with _lib.device_guard(dev), _timed("uaps_pair_bwd"):
             if am is not None:
