@@ -406,6 +406,16 @@ typedef struct uaps_call_hints {
     const float* stats_bias;
     const float* residual;       /* uaps_bn_act_fwd_train_*: out = relu(bn(y) + residual) -- a residual join (utilities/resnet.py:47-50,
                                   * 88-91) in the BatchNorm's apply pass; slope is ignored, drop_p must be 0; out_amax is honoured */
+    /* uaps_conv_bwd_weight_partial*: the `dy` argument is the gradient BEHIND the BatchNorm + LeakyReLU that follows the
+     * convolution (d(activation)); the kernel forms dy = BatchNorm backward of it while staging -- from dyt_y (the convolution's
+     * raw output), dyt_coef (uaps_bn_act_bwd_prepare) -- and writes it to dyt_out for the input-gradient call.  bound[0] must
+     * then be the bound uaps_bn_act_bwd_prepare raised.  UAPS_ERANGE (nothing launched) when the layer's kernel has no such
+     * form: run uaps_bn_act_bwd_apply and call again without these. */
+    const float* dyt_y;
+    const float* dyt_coef;
+    float* dyt_out;
+    float dyt_slope;
+    int dyt_groups;
 } uaps_call_hints;
 int uaps_next_call_hints(const uaps_call_hints* hints);
 /* Measurement aid (bench.py): `start` / `stop` are two hipEvent_t created with timing enabled.  The calling thread's next MAIN
@@ -515,6 +525,18 @@ int uaps_entropy_map(const float* p, int B, int C, int H, int W, float* ent_map,
  * backward of both addends is dx = dout * (out > 0). */
 int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream);
 int uaps_relu_bwd(const float* dout, const float* out, float* dx, long n, uaps_stream_t stream);
+/* BatchNorm(train) + LeakyReLU backward in two halves (no dropout).  `prepare`: the reductions -- coef [groups][C][8] floats =
+ * (mean, invstd, gamma invstd, beta, mean(d), mean(d x_hat), 0, 0), dgamma, dbeta, the zero gradient of a conv bias in front
+ * (dconv_bias may be NULL) -- and the zeroed bound dy_bound raised to an upper bound of |dy|.  dy itself is then formed by the
+ * weight-gradient kernel of the convolution in front (uaps_call_hints::dyt_*) or by `apply` (uaps_call_hints::out_amax
+ * honoured); both give what uaps_bn_act_bwd_grouped writes.  Workspace: uaps_bn_workspace_bytes. */
+int uaps_bn_act_bwd_prepare(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                            const float* save_invstd, float slope, int B, int C, int H, int W, int groups, float* coef,
+                            float* dgamma, float* dbeta, float* dconv_bias, float* dy_bound, void* workspace, size_t workspace_bytes,
+                            uaps_stream_t stream);
+int uaps_bn_act_bwd_apply(const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W, int groups,
+                          float* dy, uaps_stream_t stream);
+
 /* The same when the join's output had k <= 4 consumers: dx = (dout[0] + ... + dout[k-1]) * (out > 0), the k gradients (host
  * array of device pointers) summed in order by this pass instead of by k - 1 accumulation passes in front of it. */
 int uaps_relu_bwd_sum(const float* const* dout_host, int k, const float* out, float* dx, long n, uaps_stream_t stream);

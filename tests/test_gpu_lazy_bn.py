@@ -1,0 +1,108 @@
+"""-m gpu: the BatchNorm backward in two halves (uaps_amd/lazybn.py; include/uaps_hip.h: uaps_bn_act_bwd_prepare / _apply,
+uaps_call_hints::dyt_*): the reductions in the node that owns the BatchNorm, dy formed by the weight-gradient kernel of the
+convolution in front while it stages that operand (UAPS_unet.py:36-44 under autograd)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bn_state(C, groups, B, H, W, seed):
+    from uaps_amd import fused
+    g = torch.Generator().manual_seed(seed)
+    y = (torch.randn(B, C, H, W, generator=g) * 2 + 0.3).to(DEV)
+    dout = torch.randn(B, C, H, W, generator=g).to(DEV)
+    bn = nn.BatchNorm2d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+    yr = y.clone().requires_grad_(True)
+    with fused.stat_groups(groups):
+        out = fused.bn_act(yr, None, bn, 0.01, 0.0, True)
+    out.backward(dout)
+    return y, dout, bn, yr.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()
+
+
+@pytest.mark.parametrize("B,C,H,W,groups", [(4, 16, 32, 256, 2), (2, 24, 20, 36, 1), (6, 8, 7, 9, 3)])
+def test_prepare_and_apply_equal_the_one_piece_backward(B, C, H, W, groups):
+    """uaps_bn_act_bwd_prepare + uaps_bn_act_bwd_apply against uaps_bn_act_bwd_grouped (through fused.bn_act): dy, dgamma, dbeta bit
+    for bit (the same arithmetic in the same order), and the bound `prepare` raises is an upper bound of max|dy|."""
+    from uaps_amd import _lib, bounds, fused, lazybn
+    y, dout, bn, dy_ref, dg_ref, db_ref = _bn_state(C, groups, B, H, W, 3)
+    Bg = B // groups
+    mean = torch.stack([y[g * Bg:(g + 1) * Bg].double().mean((0, 2, 3)) for g in range(groups)]).float()
+    # the saved statistics of the forward: recompute through the library for bit equality
+    from uaps_amd.fused import _bn_ws
+    bn2 = nn.BatchNorm2d(C).to(DEV)
+    bn2.load_state_dict(bn.state_dict())
+    stats = torch.empty((2, groups * C), dtype=torch.float32, device=DEV)
+    out = torch.empty_like(y)
+    ws = _bn_ws(torch.device(DEV), B, C, H, W)
+    L = _lib.lib()
+    with _lib.device_guard(torch.device(DEV)):
+        rc = L.uaps_bn_act_fwd_train_grouped(y.data_ptr(), None, bn2.weight.data_ptr(), bn2.bias.data_ptr(), None, None, None, 0.1, bn2.eps,
+                                             0.01, 0.0, 0, 0, B, C, H, W, groups, out.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _lib.current_stream(torch.device(DEV)))
+    _lib.check(rc, "fwd")
+    dgamma, dbeta, dcb = (torch.empty(C, device=DEV) for _ in range(3))
+    lz = lazybn.prepare(dout, y, bn2.weight, bn2.bias, stats[0], stats[1], 0.01, groups, dgamma, dbeta, dcb, ws)
+    assert lazybn.take(dout) is lz and lazybn.take(dout) is None
+    dy = lazybn.materialize(dout, lz)
+    assert torch.equal(dy, dy_ref) and torch.equal(dgamma, dg_ref) and torch.equal(dbeta, db_ref)
+    assert float(dcb.abs().max()) == 0.0
+    upper = float(bounds.value(lz.bound[0])) * lz.bound[1]
+    assert float(dy.abs().max()) <= upper <= 64.0 * float(dy.abs().max())
+    assert abs(float(mean.abs().max())) >= 0.0          # (the statistics groups were exercised)
+
+
+def _block(seed, C0, C1, H, W, B, lazy, cat):
+    """conv1 (one or two tensors) -> BatchNorm -> LeakyReLU -> conv2 -> BatchNorm -> LeakyReLU -> 3x3 to 4 classes, the decoder's chain of
+    nodes (ConvBlock + out_conv); returns the loss-free gradients of everything."""
+    from uaps_amd import bounds, conv, fused, lazybn
+    lazybn._ON = lazy
+    torch.manual_seed(seed)
+    xs = [torch.randn(B, C0, H, W, device=DEV, requires_grad=True) for _ in range(2 if cat else 1)]
+    w1 = (torch.randn(C1, C0 * len(xs), 3, 3, device=DEV) / 10).requires_grad_(True)
+    w2 = (torch.randn(C1, C1, 3, 3, device=DEV) / 10).requires_grad_(True)
+    w3 = (torch.randn(4, C1, 3, 3, device=DEV) / 10).requires_grad_(True)
+    bn1, bn2 = nn.BatchNorm2d(C1).to(DEV), nn.BatchNorm2d(C1).to(DEV)
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    bounds.refresh([bn1, bn2])
+    xin = [bounds.put(x, bounds.from_value(x.detach().abs().max())) for x in xs]
+    with fused.stat_groups(2):
+        if cat:
+            y1, st1 = conv.conv2d_cat(xin[0], xin[1], w1, None, with_stats=True)
+        else:
+            y1, st1 = conv.conv2d_with_stats(xin[0], w1, None)
+        y2, st2 = fused.bn_act_conv(y1, st1, None, bn1, 0.01, w2, None, want_stats=True)
+        z = fused.bn_act_conv(y2, st2, None, bn2, 0.01, w3, None)
+    g = torch.randn(z.shape, generator=torch.Generator().manual_seed(seed + 1)).to(DEV)
+    z.backward(bounds.put(g, bounds.from_value(g.abs().max())))
+    lazybn.assert_none_pending()
+    lazybn._ON = True
+    return [x.grad for x in xs] + [w1.grad, w2.grad, w3.grad, bn1.weight.grad, bn1.bias.grad, bn2.weight.grad, bn2.bias.grad]
+
+
+@pytest.mark.parametrize("C0,C1,H,W,B,cat", [(16, 16, 32, 256, 4, True), (16, 16, 16, 256, 2, False), (32, 32, 32, 64, 4, True),
+                                             (16, 32, 16, 16, 2, False), (16, 16, 16, 512, 2, True)])
+def test_chain_gradients_with_and_without_the_pending_transform(C0, C1, H, W, B, cat):
+    """The same chain of nodes with UAPS_LAZY_BN_BWD on and off: every gradient agrees to the rounding of the fp16-split weight
+    gradient (dy formed in the kernel's staging is the same fp32 values; its operand bound is an upper bound instead of the exact
+    maximum, so the power-of-two scale may differ)."""
+    a = _block(7, C0, C1, H, W, B, True, cat)
+    b = _block(7, C0, C1, H, W, B, False, cat)
+    for u, v in zip(a, b):
+        scale = float(v.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 2e-5 * scale, float((u - v).abs().max()) / scale
+
+
+def test_a_pending_transform_that_nobody_applies_is_an_error():
+    from uaps_amd import lazybn
+    lazybn._pending[12345] = object()
+    with pytest.raises(RuntimeError, match="pending BatchNorm transform"):
+        lazybn.assert_none_pending()
+    lazybn.assert_none_pending()

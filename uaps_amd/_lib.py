@@ -114,6 +114,8 @@ SIGNATURES = {
     "uaps_relu_bwd": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_relu_bwd_sum": (C.c_int, [_PTR, C.c_int, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_cat2": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
+    "uaps_bn_act_bwd_prepare": (C.c_int, [_PTR] * 6 + [C.c_float] + [C.c_int] * 5 + [_PTR] * 6 + [C.c_size_t, _PTR]),
+    "uaps_bn_act_bwd_apply": (C.c_int, [_PTR] * 3 + [C.c_float] + [C.c_int] * 5 + [_PTR, _PTR]),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 
@@ -181,10 +183,11 @@ def _configure_from_environment(l) -> None:
 class CallHints(C.Structure):
     """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
     _fields_ = [("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
-                ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p), ("residual", C.c_void_p)]
+                ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p), ("residual", C.c_void_p),
+                ("dyt_y", C.c_void_p), ("dyt_coef", C.c_void_p), ("dyt_out", C.c_void_p), ("dyt_slope", C.c_float), ("dyt_groups", C.c_int)]
 
 
-def hints(bounds=(), out_amax=None, stats=None, residual=None) -> None:
+def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None) -> None:
     """bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
     None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about; residual: the
     tensor a BatchNorm apply pass adds before its ReLU (residual joins)."""
@@ -195,6 +198,11 @@ def hints(bounds=(), out_amax=None, stats=None, residual=None) -> None:
         h.bound[i] = None
     h.out_amax = h.stats_mean = h.stats_bias = None
     h.residual = residual.data_ptr() if residual is not None else None
+    if dyt is not None:                       # (y, coef, out, slope, groups): uaps_call_hints::dyt_* (uaps_bn_act_bwd_prepare)
+        h.dyt_y, h.dyt_coef, h.dyt_out, h.dyt_slope, h.dyt_groups = dyt[0].data_ptr(), dyt[1].data_ptr(), dyt[2].data_ptr(), float(dyt[3]), int(dyt[4])
+    else:
+        h.dyt_y = h.dyt_coef = h.dyt_out = None
+        h.dyt_slope, h.dyt_groups = 0.0, 0
     if stats is not None:
         if stats[0] is not None:
             h.stats_mean = stats[0].data_ptr()

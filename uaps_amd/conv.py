@@ -15,7 +15,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
-from . import _graddest, _lib, bounds
+from . import _graddest, lazybn, _lib, bounds
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 # packed weights per parameter: id(weight) -> (weakref, version, generation, wf, wb)
@@ -68,7 +68,7 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
 
 
 class _timed:
-    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False, stats=False):
+    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False, stats=False, dt=False):
         self.on = False
         if KERNEL_EVENTS is not None:
             self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg)
@@ -99,6 +99,8 @@ class _timed:
                     self.name = self.name.replace("_kernel<4, 1, ", "_kernel<8, 1, ")      # 16 output channels: the 8-row tiles (csrc/conv_wrw.hip: launch_swrw)
                 if self.name.startswith("conv_wrw_kernel<3, 4, 32, 2, 2, 4, ") and not self.name.endswith(" 1>") and W >= 32 and Cin >= 16:
                     self.name = "conv_hwrw_d_kernel<4, 2, 2, " + self.name.split(",")[-1].strip()      # the dilated fp16 form (csrc/conv_wrw.hip)
+            if dt:                    # the forms that turn d(activation) into dy while staging (uaps_call_hints::dyt_*)
+                self.name = self.name.replace("_kernel", "_dt_kernel", 1)
             self.on = EVENT_FILTER is None or self.name in EVENT_FILTER
             self.flops = 2.0 * B * H * W * Cin * Cout * ks * ks
 
@@ -305,8 +307,11 @@ def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg
 
 
 def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None,
-                        dyb=None, xb=None):
-    """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest)."""
+                        dyb=None, xb=None, lz=None):
+    """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest).
+    lz (lazybn.Lazy): `dy` is d(activation) behind the BatchNorm that follows this convolution; the kernel forms the true dy while
+    staging and writes it through -- returned as a third value (with its bound) -- or the stand-alone pass does, where the layer's
+    kernel has no such form."""
     B, Cout, H, W = dy.shape
     Cin = x.shape[1]
     dev = dy.device
@@ -317,17 +322,34 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     ws = _workspace(dev, n.value)
     dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
     db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
+    dy_true = None
     with _lib.device_guard(dev):
         st = _lib.current_stream(dev)
-        with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, _h16(dyb, xb)):
-            if dyb is not None and xb is not None:
-                _lib.hints((dyb, xb))
-            rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
-                                                ws.data_ptr(), ws.numel(), st)
+        rc = lazybn.ERANGE
+        if lz is not None and xb is not None:
+            dy_true = torch.empty_like(dy)
+            with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, True, dt=True) as tm:
+                _lib.hints((lz.bound, xb), dyt=(lz.y, lz.coef, dy_true, lz.slope, lz.groups))
+                rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
+                                                    ws.data_ptr(), ws.numel(), st)
+                tm.on = tm.on and rc != lazybn.ERANGE
+            if rc != lazybn.ERANGE:
+                bounds.put(dy_true, *lz.bound)
+        if lz is not None and rc == lazybn.ERANGE:
+            dy_true = dy = lazybn.materialize(dy, lz)
+            dyb = bounds.get(dy)
+        if lz is None or rc == lazybn.ERANGE:
+            with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, _h16(dyb, xb)):
+                if dyb is not None and xb is not None:
+                    _lib.hints((dyb, xb))
+                rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
+                                                    ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "uaps_conv_bwd_weight_partial")
         rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_bias else None, B, Cin, Cout, H, W,
                                            ks, cfg, st)
     _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+    if lz is not None:
+        return dw, db, dy_true
     return dw, db
 
 
@@ -368,11 +390,15 @@ class _Conv2d(torch.autograd.Function):
             return None, None, None, None, None, None
         x, wb = ctx.saved_tensors
         Cin, Cout, ks, has_bias, cfg = ctx.meta
+        lz = lazybn.take(dy)                   # dy is d(activation) behind the BatchNorm that follows: the weight gradient runs first
         dyb = bounds.get(dy)
         dy = dy.contiguous()
-        dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        if lz is not None:
+            dw, db, dy = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, xb=ctx.xb, lz=lz)
+            dyb = bounds.get(dy)
+        dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb) if ctx.needs_input_grad[0] else None
+        if lz is None and (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])):
             dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb)
         return dx, dw, db, None, None, None
 
@@ -384,8 +410,10 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def _mark(res, shifted):
-    # the statistics tensor remembers whether its sums are taken about a shift (fused.bn_act / bn_act_conv must tell the finalize)
+    # the statistics tensor remembers whether its sums are taken about a shift (fused.bn_act / bn_act_conv must tell the finalize);
+    # the raw output is marked as one whose gradient may arrive with a pending BatchNorm transform (lazybn)
     res[1]._uaps_shifted = shifted
+    lazybn.mark(res[0])
     return res
 
 
@@ -445,6 +473,7 @@ class _Conv2dCat(torch.autograd.Function):
             return None, None, None, None, None, None
         x1, x2, wb = ctx.saved_tensors
         C1, C2, Cout, ks, has_bias, cfg = ctx.meta
+        lz = lazybn.take(dy)                   # dy is d(activation) behind the BatchNorm that follows: the weight gradient runs first
         dyb = bounds.get(dy)
         b1, b2 = ctx.xb
         dy = dy.contiguous()
@@ -453,7 +482,45 @@ class _Conv2dCat(torch.autograd.Function):
         L = _lib.lib()
         st = _lib.current_stream(dev)
         dx1 = dx2 = dw = db = None
+        want_db = has_bias and ctx.needs_input_grad[3]
+        want_w = ctx.needs_input_grad[2] or want_db or lz is not None
+
+        def weight_gradient(dy, dyb, lz):
+            """(dw, db, dy): with a pending transform the kernel writes the true dy through (None: it has no such form here)"""
+            n = C.c_size_t()
+            _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
+            ws = _workspace(dev, n.value)
+            dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
+            db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
+            out = torch.empty_like(dy) if lz is not None else None
+            with _timed("wrw", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb, b1, b2), dt=lz is not None) as tm:
+                if lz is not None:
+                    _lib.hints((dyb, b1, b2), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
+                elif dyb is not None and b1 is not None and b2 is not None:
+                    _lib.hints((dyb, b1, b2))
+                rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
+                                                        H, W, ks, cfg, ws.data_ptr(), ws.numel(), st)
+                if lz is not None and rc == lazybn.ERANGE:
+                    tm.on = False
+            if lz is not None and rc == lazybn.ERANGE:
+                return None, None, None
+            _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
+            rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
+                                               H, W, ks, cfg, st)
+            _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+            return dw, db, (bounds.put(out, *lz.bound) if lz is not None else dy)
+
         with _lib.device_guard(dev):
+            done_w = False
+            if lz is not None:
+                if b1 is not None and b2 is not None:
+                    dw, db, out = weight_gradient(dy, lz.bound, lz)
+                    done_w = out is not None
+                if done_w:
+                    dy = out
+                else:
+                    dy = lazybn.materialize(dy, lz)
+                dyb = bounds.get(dy)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx1 = torch.empty_like(x1)
                 dx2 = torch.empty_like(x2)
@@ -463,22 +530,8 @@ class _Conv2dCat(torch.autograd.Function):
                     rc = L.uaps_conv_bwd_data_cat(dy.data_ptr(), wb.data_ptr(), dx1.data_ptr(), C1, dx2.data_ptr(), C2, B, Cout, H, W,
                                                   ks, cfg, st)
                 _lib.check(rc, "uaps_conv_bwd_data_cat")
-            want_db = has_bias and ctx.needs_input_grad[3]
-            if ctx.needs_input_grad[2] or want_db:
-                n = C.c_size_t()
-                _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-                ws = _workspace(dev, n.value)
-                dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
-                db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
-                with _timed("wrw", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb, b1, b2)):
-                    if dyb is not None and b1 is not None and b2 is not None:
-                        _lib.hints((dyb, b1, b2))
-                    rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
-                                                            H, W, ks, cfg, ws.data_ptr(), ws.numel(), st)
-                _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
-                rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
-                                                   H, W, ks, cfg, st)
-                _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+            if want_w and not done_w:
+                dw, db, _ = weight_gradient(dy, dyb, None)
         return dx1, dx2, dw, db, None, None
 
 

@@ -439,6 +439,11 @@ struct ConvWrwArgs {
     float xf_slope;
     int xf_Bg;
     unsigned* err;      // fp16-split kernels: sticky device error word (uaps_set_error_word) or nullptr
+    // DT forms (uaps_call_hints::dyt_*): `dout` is the gradient behind the BatchNorm + LeakyReLU that follows this convolution; dy is
+    // formed from it, dt_y (the raw conv output) and dt_coef [group][Cout][8] while staging and written through to dt_out
+    const float* dt_y; const float* dt_coef; float* dt_out;
+    float dt_slope;
+    int dt_Bg;
 };
 constexpr int kWrwMaxGroups = 8;     // statistics groups a conv_wrw_bn_kernel keeps coefficients for (norm_act.hip kMaxGroups)
 

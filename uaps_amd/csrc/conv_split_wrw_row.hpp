@@ -21,7 +21,10 @@ namespace uaps {
 // WCI = input channels / 16 (1 or 2); threads = 256 * WCI; XF: the input is a raw conv output, BatchNorm + LeakyReLU applied while staging
 // STRIP: maps wider than 256 pixels (W % 256 == 0) as 256-wide column strips (conv_hr16_body): a run is 16 rows of one strip; the one
 // real pixel either side of a strip goes into the boundary dwords of the two margin groups, which the 256-wide form leaves zero
-template <int WCI, bool XF, bool STRIP = false>
+// DT: a.dout is the gradient behind the BatchNorm + LeakyReLU that follows this convolution; the dy row is formed from it and the
+// convolution's raw output (a.dt_y, a.dt_coef: uaps_bn_act_bwd_prepare) while it is staged, and written through to a.dt_out --
+// every dy row is fetched exactly once, by one wave
+template <int WCI, bool XF, bool STRIP = false, bool DT = false>
 __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     constexpr int WIDTH = 256, NG = WIDTH / 8, XG = NG + 2, NSLOT = 3, ROWS = 16;
     constexpr int CI = 16 * WCI, NWV = 4 * WCI, NTHR = 64 * NWV;
@@ -57,6 +60,8 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 
     // ---- staging: lane = pixels 4 lane .. 4 lane + 3 (half of an 8-pixel unit) of NXL input channels and NDL dy channels ----
     float rx[NXL][4], rd[NDL][4];
+    float ry[DT ? NDL : 1][4];                           // DT: the raw conv output beside the gradient row
+    float dtc[DT ? NDL : 1][6];                          // DT: (mean, invstd, gamma invstd, beta, mean(d), mean(d x_hat)) of this wave's dy channels
     float rhx[1] = {0.f};                                // STRIP: lanes 0 .. NXL - 1 the pixel left of the strip, NXL .. 2 NXL - 1 the pixel right of it
     f32x2 cf[XF ? NXL : 1];
     f32x2 cf_h = f32x2{0.f, 0.f};                        // STRIP && XF: the coefficients of this lane's margin channel
@@ -77,13 +82,23 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
             buf_load<1>(rs, hok ? (uint32_t)(((second ? xc0 - a.Csplit : xc0) + hc) * HW + gy * a.W + hx) * 4u : kOob, hdst);
         }
     };
+    int d_b = 0, d_gy = 0;                               // image and row of the dy row the registers hold (DT: where it is written through)
     auto load_d = [&](int b, int gy, float (&dst)[NDL][4], bool& ok) {
         ok = (unsigned)gy < (unsigned)a.H;
+        d_b = b; d_gy = gy;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dout + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
             const int c = wave_u * NDL + i;
             buf_load<4>(rs, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob, dst[i]);
+        }
+        if constexpr (DT) {
+            const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dt_y + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
+#pragma unroll
+            for (int i = 0; i < NDL; ++i) {
+                const int c = wave_u * NDL + i;
+                buf_load<4>(rsy, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob, ry[i]);
+            }
         }
     };
     auto store_x = [&](float (&src)[NXL][4], bool ok, int slot, float (&hsrc)[1], bool hok) {
@@ -130,9 +145,24 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
             asm volatile("" : "+v"(src[i][0]), "+v"(src[i][1]), "+v"(src[i][2]), "+v"(src[i][3]));
+            float v[4] = {src[i][0], src[i][1], src[i][2], src[i][3]};
+            if constexpr (DT) {                        // dy = sc (d - k2 - x_hat k3), d = g or slope g by the sign of the BatchNorm output (norm_act.hip: dpre)
+                asm volatile("" : "+v"(ry[i][0]), "+v"(ry[i][1]), "+v"(ry[i][2]), "+v"(ry[i][3]));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yc = ry[i][k] - dtc[i][0];
+                    const float z = yc * dtc[i][2] + dtc[i][3];
+                    const float d = z > 0.f ? v[k] : v[k] * a.dt_slope;
+                    v[k] = dtc[i][2] * (d - dtc[i][4] - (yc * dtc[i][1]) * dtc[i][5]);
+                }
+                const int c = wave_u * NDL + i;
+                const __amdgpu_buffer_rsrc_t rso = make_rsrc(a.dt_out + (size_t)d_b * a.Cout * HW, (uint32_t)a.Cout * HW4);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rso,
+                                                       (int)(c < a.Cout ? (uint32_t)(c * HW + d_gy * a.W + x0 + lane * 4) * 4u : kOob), 0, 0);
+            }
             unsigned a0, a1, b0, b1;
-            conv_split2h(src[i][0] * sc_d, src[i][1] * sc_d, a0, a1);
-            conv_split2h(src[i][2] * sc_d, src[i][3] * sc_d, b0, b1);
+            conv_split2h(v[0] * sc_d, v[1] * sc_d, a0, a1);
+            conv_split2h(v[2] * sc_d, v[3] * sc_d, b0, b1);
             const int c = wave_u * NDL + i;
             unsigned* p0 = reinterpret_cast<unsigned*>(&sD[c * NG]) + lane * 2;
             unsigned* p1 = reinterpret_cast<unsigned*>(&sD[(16 + c) * NG]) + lane * 2;
@@ -151,6 +181,14 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     for (int run = run_begin; run < run_end; ++run) {
         const int b = run / rpi, rr = run % rpi, r0 = (rr % rps) * ROWS;
         x0 = (rr / rps) * WIDTH;
+        if constexpr (DT) {
+#pragma unroll
+            for (int i = 0; i < NDL; ++i) {
+                const int c = wave_u * NDL + i;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dtc[i][k] = c < a.Cout ? a.dt_coef[((size_t)(b / a.dt_Bg) * a.Cout + c) * 8 + k] : 0.f;
+            }
+        }
         if constexpr (XF && STRIP) {
             const int c = wave_u * NXL + lane % NXL;
             cf_h = f32x2{0.f, 0.f};
@@ -282,6 +320,11 @@ template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrw_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false>(a); }
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true>(a); }
+// the forms that turn d(activation) into dy while staging (DT, uaps_call_hints::dyt_*)
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, false, true>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, false, true>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrww_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true>(a); }

@@ -188,6 +188,14 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
+    // DT (uaps_call_hints::dyt_*): `dy` is d(activation) behind the BatchNorm that follows this convolution; only some kernels can
+    // turn it into dy while staging -- every other path returns UAPS_ERANGE before anything is launched
+    const bool dyt = hints.dyt_y != nullptr;
+    if (dyt) {
+        if (!hints.dyt_coef || !hints.dyt_out || hints.dyt_groups < 1 || hints.dyt_groups > kWrwMaxGroups || B % hints.dyt_groups) return UAPS_EINVAL;
+        if (((uintptr_t)hints.dyt_y | (uintptr_t)hints.dyt_out) % 16 || !(hints.dyt_slope >= 0.f && hints.dyt_slope <= 1.f)) return UAPS_ERANGE;
+        a.dt_y = hints.dyt_y; a.dt_coef = hints.dyt_coef; a.dt_out = hints.dyt_out; a.dt_slope = hints.dyt_slope; a.dt_Bg = B / hints.dyt_groups;
+    }
     // full-width-row kernels (conv_split_wrw_row.hpp): maps of 256 pixels width or a multiple (256-wide column strips), <= 16 output and 16 / 32 input channels, every operand bounded;
     // they write the slabs of the plan above (split or exact-N), so workspace and reduction do not change
     // (fewer than 16 input channels -- the first layer's 3 -- ride in the 16-channel form: the absent channels are never fetched)
@@ -201,6 +209,17 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
         a.err = uaps::error_word();
         const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
+        if (dyt) {
+            if (W > 256) return UAPS_ERANGE;           // no DT form of the column-strip kernels
+            if (Cin <= 16) {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw_bn_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrw_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+            } else {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw_bn_dt_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrw_dt_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+            }
+            return (int)hipGetLastError();
+        }
         if (W > 256) {                                 // 256-wide column strips
             if (Cin <= 16) {
                 if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_kernel<1>), dim3(grid), dim3(256), 0, s, a);
@@ -218,6 +237,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         }
         return (int)hipGetLastError();
     }
+    if (dyt) return UAPS_ERANGE;                       // (the tile kernels' DT forms: below, once built)
     if (p.g1) {
         // single-tensor, 16-byte-aligned form only; workspace and reduce follow the same plan, so the caller chooses: cfg bit 28
         // (exact kernels) for a two-tensor / BatchNorm-in-staging / odd-pointer call of such a layer -- uaps_amd.conv.plan_cfg does

@@ -28,11 +28,15 @@ inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 constexpr int kMaxGroups = 8;
-struct BnWs { float2* partials; float* coef; };   // coef: [groups][4][C] floats
-inline size_t bn_ws_bytes(int B, int C, long HW) { return align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)) + (size_t)4 * C * kMaxGroups * sizeof(float); }
+struct BnWs { float2* partials; float* coef; float* maxes; };   // coef: [groups][4][C] floats; maxes: two bounds (uaps_bn_act_bwd_prepare)
+inline size_t bn_ws_bytes(int B, int C, long HW) {
+    return align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)) + align256((size_t)4 * C * kMaxGroups * sizeof(float)) +
+           (size_t)2 * UAPS_BOUND_FLOATS * sizeof(float);
+}
 inline BnWs carve(void* ws, int B, int C, long HW) {
     BnWs w; w.partials = (float2*)ws;
     w.coef = (float*)((char*)ws + align256((size_t)C * B * nchunks_for(HW) * sizeof(float2)));
+    w.maxes = (float*)((char*)w.coef + align256((size_t)4 * C * kMaxGroups * sizeof(float)));
     return w;
 }
 
@@ -360,6 +364,134 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_dx_kernel(const float* __rest
     }
 }
 
+// ---- the backward in two halves (round 4): the reductions now, dy where it is consumed -----------------------------------
+// uaps_bn_act_bwd_prepare = this sums pass (no dropout) + bn_bwd_finalize_kernel; the weight-gradient kernel of the convolution in
+// front of the BatchNorm then forms dy = sc (d - k2 - x_hat k3) while it stages its dy operand and writes it through for the
+// input-gradient kernel (uaps_call_hints::dyt_*), or bn_bwd_dx_coef_kernel does (uaps_bn_act_bwd_apply) where no such kernel runs.
+// The sums pass also raises two bounds, max|d| and max|x_hat|, from which the finalize derives an upper bound of |dy| -- the
+// fp16 form of the weight gradient needs its operand's bound before the operand exists.
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_sums_max_kernel(const float* __restrict__ dout, const float* __restrict__ y, int C,
+                                                                   long HW, int nchunks, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float slope,
+                                                                   float2* __restrict__ partials, int Bg, int B,
+                                                                   float* __restrict__ gmax, float* __restrict__ xmax) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int b = plane / C, c = plane - b * C, g = b / Bg;
+    const float mu = mean[g * C + c], is = invstd[g * C + c], sc = gamma[c] * is, sh = beta[c];
+    const long pbase = (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    float s1 = 0.f, s2 = 0.f, md = 0.f, mx = 0.f;
+    if (VEC) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + pbase + i);
+            const float4 y4 = *reinterpret_cast<const float4*>(y + pbase + i);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = dpre(gg[k], yy[k], mu, sc, sh, slope), xh = (yy[k] - mu) * is;
+                s1 += d; s2 += d * xh;
+                md = fmaxf(md, fabsf(d)); mx = fmaxf(mx, fabsf(xh));
+            }
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const float yv = y[pbase + i];
+            const float d = dpre(dout[pbase + i], yv, mu, sc, sh, slope), xh = (yv - mu) * is;
+            s1 += d; s2 += d * xh;
+            md = fmaxf(md, fabsf(d)); mx = fmaxf(mx, fabsf(xh));
+        }
+    }
+    const float2 r = block_sum2(s1, s2);
+    if (threadIdx.x == 0) partials[((long)c * B + b) * nchunks + chunk] = r;
+    __shared__ float sm[2][16];
+    uaps::block_amax_to(gmax, md, sm[0]);
+    uaps::block_amax_to(xmax, mx, sm[1]);
+}
+
+// one wave per channel: the two means of every statistics group (the arithmetic of bn_bwd_dx_kernel's first wave, bit for bit),
+// coef [groups][C][8] = (mean, invstd, gamma invstd, beta, mean(d), mean(d x_hat), 0, 0), dgamma / dbeta over all groups, the zero
+// gradient of a conv bias in front, and |dy| <= |gamma| invstd (max|d| + |k2| + max|x_hat| |k3|) raised into dy_bound
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float2* __restrict__ partials, int nch_p, int B, int Bg, int C, long HW,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ gmax, const float* __restrict__ xmax,
+                                                             float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ dconv_bias, float* __restrict__ dy_bound) {
+    const int c = blockIdx.x, lane = threadIdx.x, nparts = Bg * nch_p, G = B / Bg;
+    const double M = (double)Bg * (double)HW;
+    const float Gm = uaps::bound_max(gmax), Xm = uaps::bound_max(xmax);
+    double t1 = 0.0, t2 = 0.0;
+    float bnd = 0.f;
+    for (int gg = 0; gg < G; ++gg) {
+        const float2* pp = partials + ((long)c * B + (long)gg * Bg) * nch_p;
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = lane; i < nparts; i += 64) { const float2 v = pp[i]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float k2 = (float)(s1 / M), k3 = (float)(s2 / M);
+        const float mu = mean[gg * C + c], is = invstd[gg * C + c], sc = gamma[c] * is;
+        if (lane == 0) {
+            float* q = coef + ((long)gg * C + c) * 8;
+            q[0] = mu; q[1] = is; q[2] = sc; q[3] = beta[c]; q[4] = k2; q[5] = k3; q[6] = 0.f; q[7] = 0.f;
+        }
+        bnd = fmaxf(bnd, fabsf(sc) * (Gm + fabsf(k2) + Xm * fabsf(k3)));
+        t1 += s1; t2 += s2;
+    }
+    if (lane == 0) {
+        dbeta[c] = (float)t1; dgamma[c] = (float)t2;
+        if (dconv_bias) dconv_bias[c] = 0.f;
+        if (dy_bound && bnd == bnd) {
+            unsigned* slot = reinterpret_cast<unsigned*>(dy_bound) + (c % UAPS_BOUND_SLOTS) * UAPS_BOUND_STRIDE;
+            atomicMax(slot, __builtin_bit_cast(unsigned, bnd));
+        }
+    }
+}
+
+// dy from the coefficients of bn_bwd_finalize_kernel (the arithmetic of bn_bwd_dx_kernel)
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_dx_coef_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                                  float* __restrict__ dy, int C, long HW, const float* __restrict__ coef,
+                                                                  float slope, int Bg, float* __restrict__ amax_out) {
+    const int plane = blockIdx.y, chunk = blockIdx.x;
+    const int b = plane / C, c = plane - b * C, g = b / Bg;
+    const float* q = coef + ((long)g * C + c) * 8;
+    const float mu = q[0], is = q[1], sc = q[2], sh = q[3], k2 = q[4], k3 = q[5];
+    const long pbase = (long)plane * HW;
+    const long lo = (long)chunk * kChunk, hi = min(HW, lo + (long)kChunk);
+    float amax = 0.f;
+    if (VEC) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * kThreads) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dout + pbase + i);
+            const float4 y4 = *reinterpret_cast<const float4*>(y + pbase + i);
+            const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = dpre(gg[k], yy[k], mu, sc, sh, slope);
+                o[k] = sc * (d - k2 - ((yy[k] - mu) * is) * k3);
+            }
+            *reinterpret_cast<float4*>(dy + pbase + i) = make_float4(o[0], o[1], o[2], o[3]);
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3]))));
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const float yv = y[pbase + i];
+            const float d = dpre(dout[pbase + i], yv, mu, sc, sh, slope);
+            const float o = sc * (d - k2 - ((yv - mu) * is) * k3);
+            dy[pbase + i] = o;
+            amax = fmaxf(amax, fabsf(o));
+        }
+    }
+    if (amax_out) {                              // uniform branch
+        __shared__ float sm[16];
+        uaps::block_amax_to(amax_out, amax, sm);
+    }
+}
+
 // eval-mode backward (running statistics are constants): dy = scale * dpre ; used only if someone
 // differentiates through an eval() forward.
 template <bool VEC>
@@ -556,6 +688,51 @@ extern "C" int uaps_bn_act_bwd(const float* dout, const float* y, const float* g
                                uaps_stream_t stream) {
     return uaps_bn_act_bwd_grouped(dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, 1, dy,
                                    dgamma, dbeta, ws, ws_bytes, stream);
+}
+
+// The BatchNorm(train) + LeakyReLU backward in two halves (no dropout): `prepare` runs the reductions -- coef [groups][C][8] floats
+// = (mean, invstd, gamma invstd, beta, mean(d), mean(d x_hat), 0, 0), dgamma, dbeta, the zero gradient of a conv bias in front
+// (may be NULL) -- and raises the zeroed bound `dy_bound` to an upper bound of |dy|; dy itself is then formed either by the
+// weight-gradient kernel of the convolution in front (uaps_call_hints::dyt_*: while it stages its dy operand, written through to
+// dyt_out for the input-gradient kernel) or by `apply` (uaps_call_hints::out_amax honoured).
+extern "C" int uaps_bn_act_bwd_prepare(const float* dout, const float* y, const float* gamma, const float* beta, const float* save_mean,
+                                       const float* save_invstd, float slope, int B, int C, int H, int W, int groups, float* coef,
+                                       float* dgamma, float* dbeta, float* dconv_bias, float* dy_bound, void* ws, size_t ws_bytes,
+                                       uaps_stream_t stream) {
+    if (!dout || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (!gamma || !beta || !save_mean || !save_invstd || !coef || !dgamma || !dbeta || !dy_bound || !ws) return UAPS_EINVAL;
+    if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const BnWs w = carve(ws, B, C, HW);
+    const int nch = nchunks_for(HW), Bg = B / groups;
+    int rc = uaps_zero_bounds(w.maxes, 2 * UAPS_BOUND_FLOATS, stream);
+    if (rc) return rc;
+    const dim3 grid(nch, B * C);
+    float* gmax = w.maxes; float* xmax = w.maxes + UAPS_BOUND_FLOATS;
+    if ((HW % 4 == 0) && al16(y) && al16(dout))
+        hipLaunchKernelGGL(bn_bwd_sums_max_kernel<true>, grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, w.partials, Bg, B, gmax, xmax);
+    else
+        hipLaunchKernelGGL(bn_bwd_sums_max_kernel<false>, grid, dim3(kThreads), 0, s, dout, y, C, HW, nch, save_mean, save_invstd, gamma, beta, slope, w.partials, Bg, B, gmax, xmax);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const float2*)w.partials, nch, B, Bg, C, HW, save_mean, save_invstd, gamma, beta,
+                       (const float*)gmax, (const float*)xmax, coef, dgamma, dbeta, dconv_bias, dy_bound);
+    return (int)hipGetLastError();
+}
+
+extern "C" int uaps_bn_act_bwd_apply(const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W,
+                                     int groups, float* dy, uaps_stream_t stream) {
+    float* amax_out = uaps::take_hints().out_amax;
+    int rc = check(dout, dy, B, C, H, W);
+    if (rc) return rc;
+    if (!y || !coef || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    const long HW = (long)H * W;
+    const dim3 grid(nchunks_for(HW), B * C);
+    if ((HW % 4 == 0) && al16(y) && al16(dout) && al16(dy))
+        hipLaunchKernelGGL(bn_bwd_dx_coef_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, dout, y, dy, C, HW, coef, slope, B / groups, amax_out);
+    else
+        hipLaunchKernelGGL(bn_bwd_dx_coef_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, dout, y, dy, C, HW, coef, slope, B / groups, amax_out);
+    return (int)hipGetLastError();
 }
 
 extern "C" int uaps_bn_act_bwd_eval(const float* dout, const float* y, const float* gamma, const float* beta,

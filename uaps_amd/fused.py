@@ -9,7 +9,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import _graddest, _lib, bounds
+from . import _graddest, lazybn, _lib, bounds
 from .perturb import _RngState
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
@@ -297,6 +297,7 @@ class _BnActConv(torch.autograd.Function):
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
         ctx.xb = xb
+        ctx.lazy_up = lazybn.marked(y)          # y's producer applies a pending BatchNorm transform: the backward hands d(activation) up
         if want_stats:
             zstats._uaps_shifted = stat_shift is not None
             ctx.mark_non_differentiable(zstats)
@@ -310,40 +311,68 @@ class _BnActConv(torch.autograd.Function):
             return (None,) * 17
         y, gamma, beta, stats, xf, wb = ctx.saved_tensors
         slope, groups, has_cbias, has_bias, Cout, ks, cfg = ctx.meta
+        lz_in = lazybn.take(dz)                 # dz is d(activation) behind the BatchNorm that follows conv2: its weight gradient runs first
         dzb, xb = bounds.get(dz), ctx.xb
         dz = dz.contiguous()
         B, Cc, H, W = y.shape
         dev = y.device
         L = _lib.lib()
-        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, cfg, dyb=dzb)
         n = C.c_size_t()
         _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
         cws = _conv._workspace(dev, n.value)
         dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
         want_db = has_bias and ctx.needs_input_grad[13]
         db = _graddest.take(ctx.keys[4], (Cout,), dev) if want_db else None
-        dy = torch.empty_like(y)
+
+        def weight_gradient(dz, dzb, lz):
+            """conv2's weight gradient; with a pending transform the kernel writes the true dz through (None: no such form here)"""
+            out = torch.empty_like(dz) if lz is not None else None
+            with _lib.device_guard(dev):
+                st = _lib.current_stream(dev)
+                with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, cfg, _conv._h16(dzb, xb), dt=lz is not None) as tm:
+                    if lz is not None:
+                        _lib.hints((dzb, xb), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
+                    elif dzb is not None and xb is not None:
+                        _lib.hints((dzb, xb))
+                    rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
+                                                           Cout, H, W, ks, cfg, cws.data_ptr(), cws.numel(), st)
+                    if lz is not None and rc == lazybn.ERANGE:
+                        tm.on = False
+                if lz is not None and rc == lazybn.ERANGE:
+                    return None
+                _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
+                rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
+                                                   ks, cfg, st)
+                _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+            return bounds.put(out, *lz.bound) if lz is not None else dz
+
+        done_w = False
+        if lz_in is not None:
+            out = weight_gradient(dz, lz_in.bound, lz_in) if xb is not None else None
+            done_w = out is not None
+            dz = out if done_w else lazybn.materialize(dz, lz_in)
+            dzb = bounds.get(dz)
+        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, cfg, dyb=dzb)
+        if not done_w:
+            weight_gradient(dz, dzb, None)
         dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys[:3]]      # dgamma, dbeta, d(conv bias) = 0
         ws = _bn_ws(dev, B, Cc, H, W)
-        with _lib.device_guard(dev):
-            st = _lib.current_stream(dev)
-            with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, cfg, _conv._h16(dzb, xb)):
-                if dzb is not None and xb is not None:
-                    _lib.hints((dzb, xb))
-                rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
-                                                       Cout, H, W, ks, cfg, cws.data_ptr(), cws.numel(), st)
-            _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
-            rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
-                                               ks, cfg, st)
-            _lib.check(rc, "uaps_conv_bwd_weight_reduce")
-            am = bounds.new_amax(dev) if bounds.enabled() else None
-            if am is not None:
-                _lib.hints((), am)
-            rc = L.uaps_bn_act_bwd_grouped_bias(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
-                                                stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
-                                                dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), st)
-            _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
-        bounds.put(dy, am)
+        if ctx.lazy_up:
+            # the reductions only; d(activation) goes up as it is, its transform pending (lazybn): y's producer forms dy in its weight gradient
+            lazybn.prepare(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], ws)
+            dy = da
+        else:
+            dy = torch.empty_like(y)
+            with _lib.device_guard(dev):
+                st = _lib.current_stream(dev)
+                am = bounds.new_amax(dev) if bounds.enabled() else None
+                if am is not None:
+                    _lib.hints((), am)
+                rc = L.uaps_bn_act_bwd_grouped_bias(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                                                    stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
+                                                    dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), st)
+                _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
+            bounds.put(dy, am)
         return dy, None, (dgb[2] if has_cbias else None), dgb[0], dgb[1], None, None, None, None, None, None, None, dw, db, None, None, None
 
 
@@ -362,6 +391,7 @@ def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.
                            mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats, xb, stat_shift)
     if want_stats:
         res[1]._uaps_shifted = stat_shift is not None
+        lazybn.mark(res[0])                # z feeds a BatchNorm of its own: its gradient may arrive with that transform pending
     return res
 
 

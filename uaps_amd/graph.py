@@ -25,7 +25,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib, bounds, conv, losses, metrics, perturb
+from . import _lib, bounds, conv, losses, metrics, perturb, lazybn
 
 _KEY_STEP = 0x9E3779B97F4A7C15
 NAN = float("nan")
@@ -126,6 +126,7 @@ class StepGraph:
         out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
         tr.optimizer.zero_grad(set_to_none=True)
         out.loss.backward()
+        lazybn.assert_none_pending()
         return out, both
 
     def _tail(self, both, x_l, y_l):

@@ -14,7 +14,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, lazybn
 from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
@@ -129,6 +129,7 @@ class UAPSTrainer:
                 out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
         self.optimizer.zero_grad(set_to_none=True)                                # :285
         out.loss.backward()                                                       # :287
+        lazybn.assert_none_pending()
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :292
@@ -308,6 +309,7 @@ class BaselineTrainer(UAPSTrainer):
         s = losses.uaps_sup_loss((main,), y_l)                                    # :161-164, 0.5 * (dice + CE)
         self.optimizer.zero_grad(set_to_none=True)                                # :166
         s.loss.backward()                                                         # :168
+        lazybn.assert_none_pending()
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :173
