@@ -105,14 +105,16 @@ class _timed:
             self.flops = 2.0 * B * H * W * Cin * Cout * ks * ks
 
     def __enter__(self):
+        self.armed = self.on
         if self.on:
             self.t = _lib.LaunchTimer().__enter__()
         return self
 
     def __exit__(self, *a):
-        if self.on:
+        if self.armed:                # (a caller clears `on` when the entry point launched nothing: disarm, record nothing)
             self.t.__exit__()
-            KERNEL_EVENTS.setdefault(self.name, []).append((self.t.start, self.t.stop, self.flops))
+            if self.on:
+                KERNEL_EVENTS.setdefault(self.name, []).append((self.t.start, self.t.stop, self.flops))
         return False
 
 
@@ -409,11 +411,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _Conv2d.apply(x, weight, bias, False, dilation)
 
 
-def _mark(res, shifted):
+def _mark(res, shifted, weight):
     # the statistics tensor remembers whether its sums are taken about a shift (fused.bn_act / bn_act_conv must tell the finalize);
     # the raw output is marked as one whose gradient may arrive with a pending BatchNorm transform (lazybn)
     res[1]._uaps_shifted = shifted
-    lazybn.mark(res[0])
+    lazybn.mark(res[0], weight)
     return res
 
 
@@ -424,7 +426,7 @@ def conv2d_with_stats(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torc
     stat_shift = (bn.running_mean or None, the conv bias that BatchNorm will add or None): the sums are then taken about
     running_mean - bias per channel (no cancellation in the variance of channels with |mean| >> std); hand the result to
     bn_act / bn_act_conv of that same BatchNorm."""
-    return _mark(_Conv2d.apply(x, weight, bias, True, dilation, stat_shift), stat_shift is not None)
+    return _mark(_Conv2d.apply(x, weight, bias, True, dilation, stat_shift), stat_shift is not None, weight)
 
 
 class _Conv2dCat(torch.autograd.Function):
@@ -540,7 +542,7 @@ def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: O
     """F.conv2d(torch.cat([x1, x2], 1), weight, bias, padding=k//2) reading the two tensors in place (stat_shift: see
     conv2d_with_stats)."""
     res = _Conv2dCat.apply(x1, x2, weight, bias, with_stats, stat_shift)
-    return _mark(res, stat_shift is not None) if with_stats else res
+    return _mark(res, stat_shift is not None, weight) if with_stats else res
 
 
 # ---- general strided convolutions + the stem max-pool (csrc/conv_strided.hip) --------------------------------------------------

@@ -237,7 +237,9 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         }
         return (int)hipGetLastError();
     }
-    if (dyt) return UAPS_ERANGE;                       // (the tile kernels' DT forms: below, once built)
+    // (the tile kernels have no DT form: built and measured late in round 4 -- 32 x 32 channel blocks, bit-identical dy -- the extra
+    // staging work cost them more than the stand-alone pass it replaced: 12 launches +314 us against 224 us saved)
+    if (dyt) return UAPS_ERANGE;
     if (p.g1) {
         // single-tensor, 16-byte-aligned form only; workspace and reduce follow the same plan, so the caller chooses: cfg bit 28
         // (exact kernels) for a two-tensor / BatchNorm-in-staging / odd-pointer call of such a layer -- uaps_amd.conv.plan_cfg does

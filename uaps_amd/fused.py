@@ -391,7 +391,7 @@ def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.
                            mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats, xb, stat_shift)
     if want_stats:
         res[1]._uaps_shifted = stat_shift is not None
-        lazybn.mark(res[0])                # z feeds a BatchNorm of its own: its gradient may arrive with that transform pending
+        lazybn.mark(res[0], weight)        # z feeds a BatchNorm of its own: its gradient may arrive with that transform pending
     return res
 
 

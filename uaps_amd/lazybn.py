@@ -37,9 +37,14 @@ def enabled() -> bool:
     return _ON and bounds.enabled()
 
 
-def mark(y: torch.Tensor) -> torch.Tensor:
-    """y is the raw output of a convolution node that understands a pending transform on y's gradient."""
-    setattr(y, _OK, True)
+def mark(y: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """y = conv(., weight) is the raw output of a convolution node that understands a pending transform on y's gradient -- marked
+    only where that node's weight-gradient kernel has the in-staging form (csrc/conv_wrw.hip: the full-width-row kernels on
+    256-wide maps), because the two-halves backward costs two small launches more than the one-piece one when the stand-alone
+    pass has to run after all."""
+    Cout, Cin, ks, _ = weight.shape
+    if ks == 3 and y.shape[3] == 256 and y.shape[2] % 16 == 0 and Cout <= 16 and Cin <= 32:
+        setattr(y, _OK, True)
     return y
 
 
