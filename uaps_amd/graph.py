@@ -125,6 +125,7 @@ class StepGraph:
         both = tr.model.forward_pair(x_l, x_u)
         out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
         tr.optimizer.zero_grad(set_to_none=True)
+        lazybn.reset()
         out.loss.backward()
         lazybn.assert_none_pending()
         return out, both

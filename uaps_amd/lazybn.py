@@ -74,7 +74,10 @@ def take(dz: Optional[torch.Tensor]) -> Optional[Lazy]:
     """The pending transform of the gradient tensor dz (call before anything that could copy it), or None."""
     if dz is None or not _pending:
         return None
-    return _pending.pop(dz.data_ptr(), None)
+    lz = _pending.pop(dz.data_ptr(), None)
+    if lz is not None and (lz.y.shape != dz.shape or lz.y.device != dz.device):      # a stale record of an abandoned backward
+        return None
+    return lz
 
 
 def materialize(dz: torch.Tensor, lz: Lazy) -> torch.Tensor:
@@ -90,6 +93,12 @@ def materialize(dz: torch.Tensor, lz: Lazy) -> torch.Tensor:
                                               dy.data_ptr(), _lib.current_stream(dz.device))
     _lib.check(rc, "uaps_bn_act_bwd_apply")
     return bounds.put(dy, am)
+
+
+def reset() -> None:
+    """Forget records a failed backward may have left behind (call in front of a backward: a stale record could meet a new tensor
+    at the same address)."""
+    _pending.clear()
 
 
 def assert_none_pending() -> None:

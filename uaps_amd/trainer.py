@@ -128,6 +128,7 @@ class UAPSTrainer:
             else:
                 out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
         self.optimizer.zero_grad(set_to_none=True)                                # :285
+        lazybn.reset()
         out.loss.backward()                                                       # :287
         lazybn.assert_none_pending()
         if self.buckets is not None:
@@ -308,6 +309,7 @@ class BaselineTrainer(UAPSTrainer):
         main = out[0] if isinstance(out, (tuple, list)) else out
         s = losses.uaps_sup_loss((main,), y_l)                                    # :161-164, 0.5 * (dice + CE)
         self.optimizer.zero_grad(set_to_none=True)                                # :166
+        lazybn.reset()
         s.loss.backward()                                                         # :168
         lazybn.assert_none_pending()
         if self.buckets is not None:
