@@ -67,3 +67,48 @@ def test_packed_fp32_kernels_repeat_bit_for_bit_beside_16x16x32_matrix_kernels()
             bad[k] += (g.view(torch.int32) != r.view(torch.int32)).any()
     torch.cuda.synchronize()
     assert bad.tolist() == [0] * len(ref), f"launches (of {n}) whose [logits, out_conv weight gradient, loss, input gradient] deviated: {bad.tolist()}"
+
+
+def test_column_strip_kernels_repeat_bit_for_bit_beside_other_launches():
+    """The full-width-row kernels on 256-wide column strips (W = 512) write a strip's neighbour pixels into margin units that the
+    kernel zeroes at its start.  The first build had no barrier between the zeroing and the first such store: a late zero wiped
+    a neighbour pixel now and then -- never in single-stream runs here, a few times per hundred steps beside other streams'
+    launches (seen as a final loss that differed from run to run at BASELINE.json configs[3]).  Forward with statistics, input
+    gradient and weight gradient of a 512-wide layer, a few hundred times beside a second stream: every result equals the first."""
+    from uaps_amd import bounds, conv
+    assert conv.get_mode() == "h16"
+    torch.manual_seed(5)
+    dev = torch.device(DEV)
+    xb_ = torch.randn(8, 64, 64, 64, device=dev)
+    wb_ = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+    wfb, _ = conv.pack_weights(wb_)
+    bb = (bounds.from_value(xb_.abs().max()), 1.0)
+    B, Cin, Cout, H, W = 2, 16, 16, 64, 512
+    x = torch.randn(B, Cin, H, W, device=dev)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.1
+    dy = torch.randn(B, Cout, H, W, device=dev)
+    wf, wbk = conv.pack_weights(w)
+    xbd, dyb = (bounds.from_value(x.abs().max()), 1.0), (bounds.from_value(dy.abs().max()), 1.0)
+    conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, None
+    conv.conv_fwd_raw(x, wf, None, Cout, 3, 0, want_stats=True, xb=xbd)
+    conv.conv_bwd_weight_raw(dy, x, 3, False, 0, dyb=dyb, xb=xbd)
+    names, conv.KERNEL_EVENTS = set(conv.KERNEL_EVENTS), None
+    assert {"conv_hr16w_kernel<2>", "conv_hrwrww_kernel<1>"} <= names, names
+
+    def once():
+        y, st, _ = conv.conv_fwd_raw(x, wf, None, Cout, 3, 0, want_stats=True, xb=xbd)
+        dx = conv.conv_bwd_data_raw(dy, wbk, Cin, 3, 0, dyb=dyb)
+        dw, _ = conv.conv_bwd_weight_raw(dy, x, 3, False, 0, dyb=dyb, xb=xbd)
+        return [y, st, dx, dw.clone()]
+
+    ref = [t.clone() for t in once()]
+    side = torch.cuda.Stream(device=dev)
+    bad = torch.zeros(len(ref), dtype=torch.int64, device=dev)
+    n = 400
+    for i in range(n):
+        with torch.cuda.stream(side):
+            conv.conv_fwd_raw(xb_, wfb, None, 64, 3, 0, xb=bb)
+        for k, (g, r) in enumerate(zip(once(), ref)):
+            bad[k] += (g.view(torch.int32) != r.view(torch.int32)).any()
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0] * len(ref), f"launches (of {n}) whose [output, statistics, input gradient, weight gradient] deviated: {bad.tolist()}"

@@ -88,6 +88,7 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
         const int rowslot = e / 8, c = e % 8;
         sIn[rowslot * IW + (c < 4 ? c : IW - 8 + c)] = u32x4{0u, 0u, 0u, 0u};
     }
+    if constexpr (STRIP) __syncthreads();             // the strips' neighbour pixels go into margin units: not before the zeros are in
 
     // ---- staging: this wave stages channel group scg of row (pair base + srr); lane = pixels 4 lane .. 4 lane + 3 ----
     const int scg = wave_u % NCG, srr = wave_u / NCG;

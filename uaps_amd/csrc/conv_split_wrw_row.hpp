@@ -57,6 +57,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 
     // zero halo groups (image columns -8 .. -1 and 256 .. 263) of every (piece, channel, slot)
     for (int e = tid; e < 2 * CI * NSLOT * 2; e += NTHR) sX[(e / 2) * XG + (e % 2) * (XG - 1)] = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (STRIP) __syncthreads();                // the strips' neighbour pixels go into the margin groups: not before the zeros are in
 
     // ---- staging: lane = pixels 4 lane .. 4 lane + 3 (half of an 8-pixel unit) of NXL input channels and NDL dy channels ----
     float rx[NXL][4], rd[NDL][4];
@@ -325,6 +326,10 @@ template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrw_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, false, true>(a); }
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, false, true>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true, true>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true, true>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI) void conv_hrwrww_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true>(a); }

@@ -209,8 +209,17 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
         a.err = uaps::error_word();
         const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
+        if (dyt && W > 256) {                          // column strips
+            if (Cin <= 16) {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrww_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+            } else {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_dt_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrww_dt_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+            }
+            return (int)hipGetLastError();
+        }
         if (dyt) {
-            if (W > 256) return UAPS_ERANGE;           // no DT form of the column-strip kernels
             if (Cin <= 16) {
                 if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw_bn_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);
                 else UAPS_LAUNCH_MAIN((conv_hrwrw_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);

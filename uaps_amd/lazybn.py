@@ -40,10 +40,10 @@ def enabled() -> bool:
 def mark(y: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """y = conv(., weight) is the raw output of a convolution node that understands a pending transform on y's gradient -- marked
     only where that node's weight-gradient kernel has the in-staging form (csrc/conv_wrw.hip: the full-width-row kernels on
-    256-wide maps), because the two-halves backward costs two small launches more than the one-piece one when the stand-alone
+    maps of 256 pixels width or a multiple), because the two-halves backward costs two small launches more than the one-piece one when the stand-alone
     pass has to run after all."""
     Cout, Cin, ks, _ = weight.shape
-    if ks == 3 and y.shape[3] == 256 and y.shape[2] % 16 == 0 and Cout <= 16 and Cin <= 32:
+    if ks == 3 and y.shape[3] % 256 == 0 and y.shape[2] % 16 == 0 and Cout <= 16 and Cin <= 32:
         setattr(y, _OK, True)
     return y
 
