@@ -24,7 +24,7 @@ WrwPlan plan_wrw(int B, int Cin, int Cout, int H, int W, int cfg, int ks = 3) {
     p.dil = ((cfg >> 24) & 0xf) ? ((cfg >> 24) & 0xf) : 1;       // bits 24-27: dilation; bit 28: exact kernels; bit 29: split kernels; low bits: pixel splits override
     const bool force_exact = (cfg >> 28) & 1, force_split = (cfg >> 29) & 1;
     cfg &= 0xffffff;
-    p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() >= 1 && Cin >= 16 && W >= 32));      // 32-pixel row tiles: half empty on 16-wide maps
+    p.split = ks == 3 && p.dil == 1 && W % 4 == 0 && !force_exact && (force_split || (uaps_conv_get_mode() >= 1 && Cin >= 16 && W >= 16));      // 32-pixel row tiles: half empty on 16-wide maps, still 1.2x the fp32 kernel there (256 -> 256 @16^2, B = 32: 97 -> 79 us)
     if (uaps_conv_get_tuning() & UAPS_TUNE_NO_SPLIT_WRW) p.split = false;
     // <= 4 output channels x 16 input channels on a wide map: the exact-N VALU kernel (conv_small.hpp), slabs [tap][4][16]
     p.small = ks == 3 && p.dil == 1 && W % 4 == 0 && W >= 64 && Cout <= 4 && Cin == 16 && !force_exact && !force_split;
