@@ -297,7 +297,7 @@ class _BnActConv(torch.autograd.Function):
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
         ctx.xb = xb
-        ctx.lazy_up = lazybn.marked(y)          # y's producer applies a pending BatchNorm transform: the backward hands d(activation) up
+        ctx.lazy_up = lazybn.marked(y) and y.requires_grad      # y's producer applies a pending BatchNorm transform (and will run): the backward hands d(activation) up
         if want_stats:
             zstats._uaps_shifted = stat_shift is not None
             ctx.mark_non_differentiable(zstats)
