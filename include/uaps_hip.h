@@ -41,6 +41,10 @@ typedef void* uaps_stream_t; /* hipStream_t */
 #define UAPS_EINVAL (-1)     /* null pointer, non-positive dimension                       */
 #define UAPS_ERANGE (-2)     /* D, C, kernel size, dilation or alignment outside what is built */
 #define UAPS_EWORKSPACE (-3) /* workspace smaller than uaps_loss_workspace_bytes() reports */
+#define UAPS_ENOFORM (-4)    /* a hint that changes what the call computes (uaps_call_hints::dyt_*) has no form in the kernel this
+                              * layer runs on: nothing was launched, nothing is wrong with the arguments -- do the work the hint
+                              * stood for yourself (uaps_bn_act_bwd_apply) and call again without it.  (Until round 5 this case
+                              * shared UAPS_ERANGE with real range errors.) */
 
 int uaps_abi_version(void);
 const char* uaps_error_string(int code);
@@ -355,6 +359,7 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above (default 2); proces
 #define UAPS_TUNE_NO_TALL_FWD 64u     /* forward / input gradient of 32-channel blocks: 8-row tiles instead of 16-row ones */
 #define UAPS_TUNE_NO_ROW16 128u       /* no full-width-row kernels (csrc/conv_split_row16.hpp): the 8 x 32-tile persistent kernels instead */
 #define UAPS_TUNE_NO_ROW_WRW 256u     /* no full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp) */
+#define UAPS_TUNE_DEEP_ROWS 512u      /* diagnostic: the full-width-row kernels with two row sets in flight (round 5: measured slower) */
 int uaps_conv_set_tuning(unsigned flags);
 unsigned uaps_conv_get_tuning(void);
 
@@ -399,6 +404,9 @@ int uaps_set_error_word(unsigned* device_word);
 #define UAPS_BOUND_STRIDE 64
 #define UAPS_BOUND_FLOATS (UAPS_BOUND_SLOTS * UAPS_BOUND_STRIDE)
 typedef struct uaps_call_hints {
+    unsigned struct_size;        /* sizeof(uaps_call_hints) of the header the CALLER was built against (round 5).  A shorter struct of
+                                  * an older client is accepted and its missing tail reads as zero; 0 or a size beyond this library's
+                                  * struct is UAPS_EINVAL -- fields are only ever appended */
     const float* bound[3];
     float mul[3];
     float* out_amax;
@@ -409,7 +417,7 @@ typedef struct uaps_call_hints {
     /* uaps_conv_bwd_weight_partial*: the `dy` argument is the gradient BEHIND the BatchNorm + LeakyReLU that follows the
      * convolution (d(activation)); the kernel forms dy = BatchNorm backward of it while staging -- from dyt_y (the convolution's
      * raw output), dyt_coef (uaps_bn_act_bwd_prepare) -- and writes it to dyt_out for the input-gradient call.  bound[0] must
-     * then be the bound uaps_bn_act_bwd_prepare raised.  UAPS_ERANGE (nothing launched) when the layer's kernel has no such
+     * then be the bound uaps_bn_act_bwd_prepare raised.  UAPS_ENOFORM (nothing launched) when the layer's kernel has no such
      * form: run uaps_bn_act_bwd_apply and call again without these. */
     const float* dyt_y;
     const float* dyt_coef;
@@ -486,6 +494,41 @@ int uaps_conv_fwd_bn(const float* x_raw, const void* xf, float slope, int groups
 int uaps_conv_bwd_weight_partial_bn(const float* dy, const float* x_raw, const void* xf, float slope, int groups,
                                     int want_bias, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
                                     void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+/* ---- Explicit form of the convolution calls (round 5): ONE size-versioned argument struct per call, no side channel -------------
+ * The entry points above take their optional operands (magnitude bounds, statistics shift, the pending BatchNorm transform of
+ * dy) from uaps_next_call_hints, a one-shot thread-local record: a binding has to know which call consumes it.  uaps_conv_ex
+ * carries everything in the struct; nothing set before the call is looked at (pending hints of the thread are dropped) and
+ * nothing survives it, so it is re-entrant per call and a foreign-language binding sees every operand in one place.  Same
+ * kernels, same results, same return codes (UAPS_ENOFORM for a dyt_* request the layer's kernel cannot honour).
+ *   op = UAPS_CONV_FWD            y (and y's BatchNorm partials into `stats` when non-NULL) = conv(x [, x2]); with `xf` non-NULL the
+ *                                 input is a raw conv output and leaky_relu(fma(x, scale, shift)) is applied while staging
+ *        UAPS_CONV_BWD_DATA       dx (= y [, y2 for a two-tensor input]) = conv_transpose(dy = x)
+ *        UAPS_CONV_BWD_WEIGHT     per-split partials into `workspace` from (dy = y_grad, x [, x2]); finish with uaps_conv_bwd_weight_reduce
+ *   Fields that an op does not use must be zero.  struct_size = sizeof(uaps_conv_call) of the caller's header; fields are only
+ *   appended, a shorter struct of an older client reads as zero beyond its size. */
+#define UAPS_CONV_FWD 0
+#define UAPS_CONV_BWD_DATA 1
+#define UAPS_CONV_BWD_WEIGHT 2
+typedef struct uaps_conv_call {
+    unsigned struct_size;
+    int op;
+    int B, Cin, Cout, H, W, ks, cfg;     /* Cin = C1 + C2 for a two-tensor input */
+    const float* x;  int C1;             /* first input tensor [B,C1,H,W] (C1 = Cin without x2); BWD_DATA: dy [B,Cout,H,W] */
+    const float* x2;                     /* second input tensor [B,Cin-C1,H,W] or NULL */
+    const float* w_packed;               /* uaps_conv_pack_weights: wf (FWD), wb (BWD_DATA); unused by BWD_WEIGHT */
+    const float* bias;                   /* FWD: [Cout] or NULL */
+    float* y;                            /* FWD: output; BWD_DATA: dx (first tensor) */
+    float* y2;                           /* BWD_DATA of a two-tensor input: dx of the second tensor */
+    const float* y_grad;                 /* BWD_WEIGHT: dy [B,Cout,H,W] */
+    void* stats;                         /* FWD: float2 [Cout][B][parts] or NULL (uaps_conv_fwd_stats_parts) */
+    const void* xf; float xf_slope; int xf_groups;      /* staging-time BatchNorm + LeakyReLU of x (uaps_bn_finalize_train) or NULL */
+    int want_bias;                       /* BWD_WEIGHT: also the bias gradient's partials */
+    void* workspace; size_t workspace_bytes;            /* BWD_WEIGHT (uaps_conv_wrw_workspace_bytes) */
+    uaps_call_hints hints;               /* the operands' bounds, statistics shift, dyt_* ...; hints.struct_size may be 0 = none */
+    uaps_stream_t stream;
+} uaps_conv_call;
+int uaps_conv_ex(const uaps_conv_call* call);
+
 /* Name (as rocprofv3 prints it, without namespace) of the kernel instantiation the calls above launch
  * for these dimensions; buf_host needs >= 64 bytes.  For uaps_conv_bwd_data pass Cin and Cout swapped
  * to uaps_conv_fwd_variant.  Used by bench.py to group its per-launch HIP-event timings. */

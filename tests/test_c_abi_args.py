@@ -89,6 +89,14 @@ def test_kernel_plan_names_and_statistics_tiles(L):
 
 def test_call_hints_are_validated_and_one_shot(L):
     h = _lib.CallHints()
+    assert L.uaps_next_call_hints(C.byref(h)) == EINVAL                                  # struct_size 0: not a versioned struct
+    h.struct_size = C.sizeof(_lib.CallHints) + 8
+    assert L.uaps_next_call_hints(C.byref(h)) == EINVAL                                  # a client newer than the library
+    h.struct_size = _lib.CallHints.out_amax.offset                                       # an old client's shorter struct: the tail reads as zero
+    h.dyt_y = 1 << 20                                                                    # (garbage beyond its size is never looked at)
+    assert L.uaps_next_call_hints(C.byref(h)) == OK
+    h.dyt_y = None
+    h.struct_size = C.sizeof(_lib.CallHints)
     assert L.uaps_next_call_hints(C.byref(h)) == OK
     h.bound[0], h.mul[0] = 1 << 20, 0.0                                                  # a bound needs a positive finite factor
     assert L.uaps_next_call_hints(C.byref(h)) == EINVAL
@@ -126,7 +134,7 @@ def test_process_wide_switches_and_the_round3_plans(L):
     import re, os
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "uaps_hip.h")).read()
     tune = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(UAPS_TUNE_\w+)\s+\(?(\d+)u?\)?", hdr)}
-    assert tune["UAPS_TUNE_NO_SPLIT_FWD"] == 1 and tune["UAPS_TUNE_NO_SPLIT_WRW"] == 2 and len(tune) == 9
+    assert tune["UAPS_TUNE_NO_SPLIT_FWD"] == 1 and tune["UAPS_TUNE_NO_SPLIT_WRW"] == 2 and tune["UAPS_TUNE_DEEP_ROWS"] == 512 and len(tune) == 10
     L.uaps_conv_get_tuning.restype = C.c_uint
     buf, parts, n = C.create_string_buffer(96), C.c_int(), C.c_size_t()
     prev_mode, prev_tune = L.uaps_conv_get_mode(), L.uaps_conv_get_tuning()

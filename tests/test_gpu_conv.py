@@ -400,3 +400,71 @@ def test_launch_timer_reads_the_kernel_dispatch(conv_mode):
         pass
     torch.cuda.synchronize()
     assert not t.dispatch and t.elapsed_ms() >= 0.0
+
+
+def test_the_explicit_conv_call_equals_the_hinted_entry_points():
+    """uaps_conv_ex (one size-versioned struct per call, include/uaps_hip.h) against uaps_conv_fwd / uaps_conv_bwd_data /
+    uaps_conv_bwd_weight_partial behind uaps_next_call_hints: the same kernels, bit-identical results; pending thread-local
+    hints are dropped, not consumed by it; an old client's shorter struct is accepted."""
+    import ctypes as C
+    from uaps_amd import _lib, bounds, conv
+    DEV = "cuda:0"
+    if conv.get_mode() != "h16":
+        pytest.skip("one arithmetic mode is enough for the ABI form")
+    torch.manual_seed(4)
+    B, Cin, Cout, H, W, ks = 2, 32, 32, 64, 64, 3
+    x = torch.randn(B, Cin, H, W, device=DEV)
+    dy = torch.randn(B, Cout, H, W, device=DEV)
+    w = torch.randn(Cout, Cin, ks, ks, device=DEV) * 0.1
+    wf, wb = conv.pack_weights(w)
+    xb, dyb = (bounds.from_value(x.abs().max()), 1.0), (bounds.from_value(dy.abs().max()), 1.0)
+    y_ref = conv.conv_fwd_raw(x, wf, None, Cout, ks, xb=xb)
+    dx_ref = conv.conv_bwd_data_raw(dy, wb, Cin, ks, dyb=dyb)
+    L = _lib.lib()
+    st = _lib.current_stream(x.device)
+
+    def call(op, **kw):
+        c = _lib.ConvCall()
+        c.struct_size = C.sizeof(_lib.ConvCall)
+        c.op, c.B, c.Cin, c.Cout, c.H, c.W, c.ks, c.cfg, c.C1, c.stream = op, B, Cin, Cout, H, W, ks, 0, Cin, st
+        for k, v in kw.items():
+            setattr(c, k, v)
+        return c
+
+    def with_bound(c, *bs):
+        c.hints.struct_size = C.sizeof(_lib.CallHints)
+        for i, b in enumerate(bs):
+            c.hints.bound[i], c.hints.mul[i] = b[0].data_ptr(), b[1]
+        return c
+
+    y = torch.empty_like(y_ref)
+    _lib.hints((None,))                                   # a pending record of the classic protocol: uaps_conv_ex must not use it
+    with _lib.device_guard(x.device):
+        rc = L.uaps_conv_ex(C.byref(with_bound(call(0, x=x.data_ptr(), w_packed=wf.data_ptr(), y=y.data_ptr()), xb)))
+    _lib.check(rc, "uaps_conv_ex fwd")
+    assert torch.equal(y, y_ref)
+    dx = torch.empty_like(dx_ref)
+    with _lib.device_guard(x.device):
+        rc = L.uaps_conv_ex(C.byref(with_bound(call(1, x=dy.data_ptr(), w_packed=wb.data_ptr(), y=dx.data_ptr()), dyb)))
+    _lib.check(rc, "uaps_conv_ex bwd_data")
+    assert torch.equal(dx, dx_ref)
+    # weight gradient partials + the classic reduce, against the classic pair
+    dw_ref, _ = conv.conv_bwd_weight_raw(dy, x, ks, False, dyb=dyb, xb=xb)
+    n = C.c_size_t()
+    _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, 0, C.byref(n)), "ws")
+    ws = torch.empty(n.value // 4 + 16, dtype=torch.float32, device=DEV)
+    dw = torch.empty_like(w)
+    with _lib.device_guard(x.device):
+        c = with_bound(call(2, x=x.data_ptr(), y_grad=dy.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4), dyb, xb)
+        _lib.check(L.uaps_conv_ex(C.byref(c)), "uaps_conv_ex bwd_weight")
+        _lib.check(L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), None, B, Cin, Cout, H, W, ks, 0, st), "reduce")
+    assert torch.equal(dw, dw_ref)
+    # an older client's struct that ends in front of `hints`: accepted, runs without bounds (the exact three-piece form)
+    y2 = torch.empty_like(y_ref)
+    c = call(0, x=x.data_ptr(), w_packed=wf.data_ptr(), y=y2.data_ptr())
+    c.struct_size = _lib.ConvCall.hints.offset
+    with _lib.device_guard(x.device):
+        _lib.check(L.uaps_conv_ex(C.byref(c)), "uaps_conv_ex short struct")
+    assert float((y2 - y_ref).abs().max()) <= 2e-5 * float(y_ref.abs().max())
+    c.struct_size = 8
+    assert L.uaps_conv_ex(C.byref(c)) == -1 and L.uaps_conv_ex(None) == -1

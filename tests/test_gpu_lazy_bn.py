@@ -57,9 +57,12 @@ def test_prepare_and_apply_equal_the_one_piece_backward(B, C, H, W, groups):
     assert abs(float(mean.abs().max())) >= 0.0          # (the statistics groups were exercised)
 
 
-def _block(seed, C0, C1, H, W, B, lazy, cat):
+def _block(seed, C0, C1, H, W, B, lazy, cat, scope=True, hook=None, second_consumer=False, fail_in_backward=False):
     """conv1 (one or two tensors) -> BatchNorm -> LeakyReLU -> conv2 -> BatchNorm -> LeakyReLU -> 3x3 to 4 classes, the decoder's chain of
-    nodes (ConvBlock + out_conv); returns the loss-free gradients of everything."""
+    nodes (ConvBlock + out_conv); returns the loss-free gradients of everything.  scope: forward + backward inside lazybn.scope()
+    (what the trainers do); hook: called on the gradient of conv1's raw output; second_consumer: that output also feeds a plain
+    sum; fail_in_backward: conv2's input gradient raises."""
+    import contextlib
     from uaps_amd import bounds, conv, fused, lazybn
     lazybn._ON = lazy
     torch.manual_seed(seed)
@@ -73,17 +76,35 @@ def _block(seed, C0, C1, H, W, B, lazy, cat):
             bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
     bounds.refresh([bn1, bn2])
     xin = [bounds.put(x, bounds.from_value(x.detach().abs().max())) for x in xs]
-    with fused.stat_groups(2):
-        if cat:
-            y1, st1 = conv.conv2d_cat(xin[0], xin[1], w1, None, with_stats=True)
-        else:
-            y1, st1 = conv.conv2d_with_stats(xin[0], w1, None)
-        y2, st2 = fused.bn_act_conv(y1, st1, None, bn1, 0.01, w2, None, want_stats=True)
-        z = fused.bn_act_conv(y2, st2, None, bn2, 0.01, w3, None)
-    g = torch.randn(z.shape, generator=torch.Generator().manual_seed(seed + 1)).to(DEV)
-    z.backward(bounds.put(g, bounds.from_value(g.abs().max())))
-    lazybn.assert_none_pending()
-    lazybn._ON = True
+    real_bwd_data, calls = conv.conv_bwd_data_raw, [0]
+
+    def failing(*a, **k):
+        calls[0] += 1
+        if calls[0] == 2:
+            raise RuntimeError("injected failure in the middle of a backward")
+        return real_bwd_data(*a, **k)
+
+    try:
+        with (lazybn.scope() if scope else contextlib.nullcontext()):
+            with fused.stat_groups(2):
+                if cat:
+                    y1, st1 = conv.conv2d_cat(xin[0], xin[1], w1, None, with_stats=True)
+                else:
+                    y1, st1 = conv.conv2d_with_stats(xin[0], w1, None)
+                if hook is not None:
+                    y1.register_hook(hook)
+                y2, st2 = fused.bn_act_conv(y1, st1, None, bn1, 0.01, w2, None, want_stats=True)
+                z = fused.bn_act_conv(y2, st2, None, bn2, 0.01, w3, None)
+            g = torch.randn(z.shape, generator=torch.Generator().manual_seed(seed + 1)).to(DEV)
+            if fail_in_backward:
+                conv.conv_bwd_data_raw = failing
+            if second_consumer:
+                torch.autograd.backward([z, (y1 * 0.5).sum()], [bounds.put(g, bounds.from_value(g.abs().max())), None])
+            else:
+                z.backward(bounds.put(g, bounds.from_value(g.abs().max())))
+    finally:
+        conv.conv_bwd_data_raw = real_bwd_data
+        lazybn._ON = True
     return [x.grad for x in xs] + [w1.grad, w2.grad, w3.grad, bn1.weight.grad, bn1.bias.grad, bn2.weight.grad, bn2.bias.grad]
 
 
@@ -102,9 +123,61 @@ def test_chain_gradients_with_and_without_the_pending_transform(C0, C1, H, W, B,
 
 def test_a_pending_transform_that_nobody_applies_is_an_error():
     from uaps_amd import lazybn
-    lazybn._pending[12345] = object()
+    lazybn._outstanding = 1
     with pytest.raises(RuntimeError, match="pending BatchNorm transform"):
         lazybn.assert_none_pending()
+    lazybn.assert_none_pending()
+
+
+def test_the_two_halves_backward_runs_only_inside_a_scope():
+    """A user-driven forward / loss.backward() (UAPS_train.py:177-292 on this package) never sees an
+    untransformed gradient: outside lazybn.scope() nothing is handed up, and the gradients are the one-piece ones bit for bit."""
+    from uaps_amd import lazybn
+    n0 = lazybn.prepared_total()
+    a = _block(11, 16, 16, 32, 256, 4, True, True, scope=False)
+    assert lazybn.prepared_total() == n0
+    b = _block(11, 16, 16, 32, 256, 4, False, True, scope=False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    _block(11, 16, 16, 32, 256, 4, True, True, scope=True)
+    assert lazybn.prepared_total() > n0              # (and inside a scope it does run at this shape)
+
+
+def test_a_hook_on_a_marked_conv_output_sees_the_true_gradient():
+    """register_hook on the raw output of a convolution whose gradient would be handed up untransformed: the observer gets dy itself
+    (the node falls back to the one-piece backward for that tensor), bit for bit what it gets with the mechanism off."""
+    from uaps_amd import lazybn
+    seen = {}
+    a = _block(5, 16, 16, 32, 256, 4, True, False, hook=lambda g: seen.__setitem__("lazy", g.detach().clone()))
+    b = _block(5, 16, 16, 32, 256, 4, False, False, hook=lambda g: seen.__setitem__("plain", g.detach().clone()))
+    assert torch.equal(seen["lazy"], seen["plain"])
+    for u, v in zip(a, b):
+        scale = float(v.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 2e-5 * scale
+    lazybn.assert_none_pending()
+
+
+def test_a_second_consumer_of_a_marked_output_fails_the_step_instead_of_training_on_a_wrong_gradient():
+    """The raw conv output also feeds a plain sum: autograd adds that gradient to the untransformed d(activation).  In place (same
+    tensor, higher version) the producer refuses it; out of place the record is lost and the scope's exit check fails the step."""
+    from uaps_amd import lazybn
+    with pytest.raises(RuntimeError, match="pending BatchNorm transform"):
+        _block(9, 16, 16, 32, 256, 4, True, False, second_consumer=True)
+    lazybn.reset()
+    lazybn.assert_none_pending()
+
+
+def test_a_failed_backward_leaves_nothing_behind_for_a_plain_user_backward():
+    """A backward that throws midway inside a trainer step, then the reference's own loop on the
+    same process -- forward, loss.backward() outside any scope: the one-piece gradients bit for bit."""
+    from uaps_amd import lazybn
+    ref = _block(13, 16, 16, 32, 256, 4, False, True, scope=False)
+    with pytest.raises(RuntimeError, match="injected failure"):
+        _block(13, 16, 16, 32, 256, 4, True, True, scope=True, fail_in_backward=True)
+    assert lazybn._depth == 0
+    got = _block(13, 16, 16, 32, 256, 4, True, True, scope=False)
+    for u, v in zip(got, ref):
+        assert torch.equal(u, v)
     lazybn.assert_none_pending()
 
 

@@ -25,8 +25,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in uaps_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()
-    assert L.uaps_abi_version() == 1
-    assert b"range" in L.uaps_error_string(-2)
+    assert L.uaps_abi_version() == 2
+    assert b"range" in L.uaps_error_string(-2) and b"no form" in L.uaps_error_string(-4)
 
 
 def test_argument_validation_without_gpu():

@@ -30,9 +30,19 @@ def per_kernel(root, counter):
 
 
 def short(name):
-    m = re.search(r"((conv_\w+_kernel|uaps::\w+|\w+_kernel)<[^>]*>)", name)
-    s = m.group(1) if m else name.split("(")[0]
-    return s.replace("uaps::", "").replace("void ", "").strip()
+    """`void uaps::conv_h32_kernel<64>(uaps::ConvFwdArgs)` -> `conv_h32_kernel<64>`; `(anonymous namespace)::fanin_perturbed_kernel((anonymous
+    namespace)::FanInArgs, ...)` -> `fanin_perturbed_kernel` (round 4 returned '' for these: the name starts with a parenthesis)."""
+    s = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("uaps::", "").strip()
+    depth, end = 0, len(s)
+    for i, ch in enumerate(s):                 # cut at the argument list: the first '(' outside the template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            end = i
+            break
+    return s[:end].strip()
 
 
 def main():

@@ -81,6 +81,7 @@ SIGNATURES = {
     "uaps_conv_bwd_weight": (C.c_int, [_PTR] * 4 + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
     "uaps_set_step_state": (C.c_int, [_PTR]),
     "uaps_next_call_hints": (C.c_int, [_PTR]),
+    "uaps_conv_ex": (C.c_int, [_PTR]),
     "uaps_next_launch_events": (C.c_int, [_PTR, _PTR]),
     "uaps_zero_bounds": (C.c_int, [_PTR, C.c_long, _PTR]),
     "uaps_bn_param_bounds": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, _PTR]),
@@ -163,7 +164,7 @@ def lib() -> C.CDLL:
 # diagnosis scripts set; the library itself reads no environment
 _TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, None), ("UAPS_DIAG_NO_SMALL", 4, None),
              ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"), ("UAPS_FWD_TALL", 64, "0"),
-             ("UAPS_DIAG_NO_ROW16", 128, None), ("UAPS_DIAG_NO_ROW_WRW", 256, None))
+             ("UAPS_DIAG_NO_ROW16", 128, None), ("UAPS_DIAG_NO_ROW_WRW", 256, None), ("UAPS_DIAG_DEEP_ROWS", 512, None))
 
 
 def _configure_from_environment(l) -> None:
@@ -182,9 +183,18 @@ def _configure_from_environment(l) -> None:
 
 class CallHints(C.Structure):
     """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
-    _fields_ = [("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
+    _fields_ = [("struct_size", C.c_uint), ("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
                 ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p), ("residual", C.c_void_p),
                 ("dyt_y", C.c_void_p), ("dyt_coef", C.c_void_p), ("dyt_out", C.c_void_p), ("dyt_slope", C.c_float), ("dyt_groups", C.c_int)]
+
+
+class ConvCall(C.Structure):
+    """uaps_conv_call (include/uaps_hip.h): the explicit, size-versioned form of the convolution entry points (uaps_conv_ex)."""
+    _fields_ = [("struct_size", C.c_uint), ("op", C.c_int), ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("ks", C.c_int), ("cfg", C.c_int), ("x", C.c_void_p), ("C1", C.c_int), ("x2", C.c_void_p),
+                ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("y2", C.c_void_p), ("y_grad", C.c_void_p),
+                ("stats", C.c_void_p), ("xf", C.c_void_p), ("xf_slope", C.c_float), ("xf_groups", C.c_int), ("want_bias", C.c_int),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("hints", CallHints), ("stream", C.c_void_p)]
 
 
 def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None) -> None:
@@ -194,6 +204,7 @@ def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None) -> None
     h = getattr(_tls, "hints", None)
     if h is None:
         h = _tls.hints = CallHints()
+        h.struct_size = C.sizeof(CallHints)
     for i in range(3):
         h.bound[i] = None
     h.out_amax = h.stats_mean = h.stats_bias = None

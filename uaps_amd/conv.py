@@ -327,20 +327,20 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     dy_true = None
     with _lib.device_guard(dev):
         st = _lib.current_stream(dev)
-        rc = lazybn.ERANGE
+        rc = lazybn.ENOFORM
         if lz is not None and xb is not None:
             dy_true = torch.empty_like(dy)
             with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, True, dt=True) as tm:
                 _lib.hints((lz.bound, xb), dyt=(lz.y, lz.coef, dy_true, lz.slope, lz.groups))
                 rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
                                                     ws.data_ptr(), ws.numel(), st)
-                tm.on = tm.on and rc != lazybn.ERANGE
-            if rc != lazybn.ERANGE:
+                tm.on = tm.on and rc != lazybn.ENOFORM
+            if rc != lazybn.ENOFORM:
                 bounds.put(dy_true, *lz.bound)
-        if lz is not None and rc == lazybn.ERANGE:
+        if lz is not None and rc == lazybn.ENOFORM:
             dy_true = dy = lazybn.materialize(dy, lz)
             dyb = bounds.get(dy)
-        if lz is None or rc == lazybn.ERANGE:
+        if lz is None or rc == lazybn.ENOFORM:
             with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, _h16(dyb, xb)):
                 if dyb is not None and xb is not None:
                     _lib.hints((dyb, xb))
@@ -396,11 +396,15 @@ class _Conv2d(torch.autograd.Function):
         dyb = bounds.get(dy)
         dy = dy.contiguous()
         dw = db = None
+        want_w = ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        if lz is not None and not want_w:       # frozen weight and bias: no weight-gradient launch, no bucket slice taken
+            dy, lz = lazybn.materialize(dy, lz), None
+            dyb = bounds.get(dy)
         if lz is not None:
             dw, db, dy = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, xb=ctx.xb, lz=lz)
             dyb = bounds.get(dy)
         dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb) if ctx.needs_input_grad[0] else None
-        if lz is None and (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])):
+        if lz is None and want_w:
             dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb)
         return dx, dw, db, None, None, None
 
@@ -485,7 +489,7 @@ class _Conv2dCat(torch.autograd.Function):
         st = _lib.current_stream(dev)
         dx1 = dx2 = dw = db = None
         want_db = has_bias and ctx.needs_input_grad[3]
-        want_w = ctx.needs_input_grad[2] or want_db or lz is not None
+        want_w = ctx.needs_input_grad[2] or want_db
 
         def weight_gradient(dy, dyb, lz):
             """(dw, db, dy): with a pending transform the kernel writes the true dy through (None: it has no such form here)"""
@@ -502,9 +506,9 @@ class _Conv2dCat(torch.autograd.Function):
                     _lib.hints((dyb, b1, b2))
                 rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
                                                         H, W, ks, cfg, ws.data_ptr(), ws.numel(), st)
-                if lz is not None and rc == lazybn.ERANGE:
+                if lz is not None and rc == lazybn.ENOFORM:
                     tm.on = False
-            if lz is not None and rc == lazybn.ERANGE:
+            if lz is not None and rc == lazybn.ENOFORM:
                 return None, None, None
             _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
             rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
@@ -515,7 +519,7 @@ class _Conv2dCat(torch.autograd.Function):
         with _lib.device_guard(dev):
             done_w = False
             if lz is not None:
-                if b1 is not None and b2 is not None:
+                if want_w and b1 is not None and b2 is not None:      # (frozen weight and bias: the stand-alone pass, no weight gradient)
                     dw, db, out = weight_gradient(dy, lz.bound, lz)
                     done_w = out is not None
                 if done_w:

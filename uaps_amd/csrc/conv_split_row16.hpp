@@ -300,17 +300,20 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     }
 }
 
+// Two waves per SIMD for every form: left unbounded the two-output-tile and column-strip forms took 300-400 registers, i.e. ONE
+// workgroup per CU where LDS allows two (round 5: conv_hr16x2_kernel 376 -> 228 registers, 113.5 -> 95.3 us in the step).
+#define UAPS_HR16_BOUNDS(n) __launch_bounds__(n, 2)
 template <int NCG>
-__global__ __launch_bounds__(128 * NCG) void conv_hr16_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false>(a); }
+__global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false>(a); }
 template <int NCG>
-__global__ __launch_bounds__(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
+__global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
 // 16 -> 32 channels (two 16-channel output tiles, one or two output tensors), no statistics
-__global__ __launch_bounds__(256) void conv_hr16x2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2>(a); }
+__global__ UAPS_HR16_BOUNDS(256) void conv_hr16x2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
 template <int NCG>
-__global__ __launch_bounds__(128 * NCG) void conv_hr16w_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false, 1, true>(a); }
+__global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16w_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false, 1, true>(a); }
 template <int NCG>
-__global__ __launch_bounds__(128 * NCG) void conv_hr16w_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true, 1, true>(a); }
-__global__ __launch_bounds__(256) void conv_hr16wx2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2, true>(a); }
+__global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16w_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true, 1, true>(a); }
+__global__ UAPS_HR16_BOUNDS(256) void conv_hr16wx2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2, true>(a); }
 
 }  // namespace uaps

@@ -24,7 +24,11 @@ namespace uaps {
 // DT: a.dout is the gradient behind the BatchNorm + LeakyReLU that follows this convolution; the dy row is formed from it and the
 // convolution's raw output (a.dt_y, a.dt_coef: uaps_bn_act_bwd_prepare) while it is staged, and written through to a.dt_out --
 // every dy row is fetched exactly once, by one wave
-template <int WCI, bool XF, bool STRIP = false, bool DT = false>
+// DEPTH: rows in flight ahead of the row being contracted (round 5).  1: the rows step y's end needs are fetched at its start
+// (one register set; the load latency is exposed behind the step's ~0.5 us of matrix work).  2: they were fetched a step earlier
+// (two alternating register sets, the row loop unrolled by two so that every set has ONE issue point and ONE consumption point):
+// twice the bytes in flight per CU.  Same arithmetic and summation order, bit-identical slabs.  Not with DT (register budget).
+template <int WCI, bool XF, bool STRIP = false, bool DT = false, int DEPTH = 1>
 __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     constexpr int WIDTH = 256, NG = WIDTH / 8, XG = NG + 2, NSLOT = 3, ROWS = 16;
     constexpr int CI = 16 * WCI, NWV = 4 * WCI, NTHR = 64 * NWV;
@@ -34,6 +38,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     constexpr int RED_FLOATS = 2 * WCI * 10 * 256;        // cross-wave reduction scratch (aliases the staging image)
     static_assert(RED_FLOATS / 4 <= X_UNITS, "the reduction scratch fits the input image");
     static_assert(WCI == 1 || WCI == 2, "16 or 32 input channels");
+    static_assert(DEPTH == 1 || (DEPTH == 2 && !DT && ROWS % DEPTH == 0), "two rows ahead: plain dy only");
 
     __shared__ __attribute__((aligned(16))) u32x4 sX[X_UNITS];      // [piece][ci][slot][group]
     __shared__ __attribute__((aligned(16))) u32x4 sD[D_UNITS];      // [piece][co][group]
@@ -60,8 +65,13 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     if constexpr (STRIP) __syncthreads();                // the strips' neighbour pixels go into the margin groups: not before the zeros are in
 
     // ---- staging: lane = pixels 4 lane .. 4 lane + 3 (half of an 8-pixel unit) of NXL input channels and NDL dy channels ----
-    float rx[NXL][4], rd[NDL][4];
-    float ry[DT ? NDL : 1][4];                           // DT: the raw conv output beside the gradient row
+    // (fetched rows live in 128-bit vector variables: a set that crosses the row loop's back edge is then ONE loop-carried value per
+    // load, which the register allocator keeps in place; as scalars it copied them behind the loads, i.e. waited for them at once)
+    f32x4 rx[NXL], rd[NDL];
+    f32x4 rx2[DEPTH > 1 ? NXL : 1], rd2[DEPTH > 1 ? NDL : 1];      // DEPTH 2: the second set
+    float rhx2[1] = {0.f};
+    bool x_in2 = false, d_in2 = false, h_in2 = false;
+    f32x4 ry[DT ? NDL : 1];                              // DT: the raw conv output beside the gradient row
     float dtc[DT ? NDL : 1][6];                          // DT: (mean, invstd, gamma invstd, beta, mean(d), mean(d x_hat)) of this wave's dy channels
     float rhx[1] = {0.f};                                // STRIP: lanes 0 .. NXL - 1 the pixel left of the strip, NXL .. 2 NXL - 1 the pixel right of it
     f32x2 cf[XF ? NXL : 1];
@@ -70,13 +80,14 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     const int xc0 = wave_u * NXL;                        // this wave's input channels xc0 .. xc0 + NXL - 1 lie in one source (Csplit % 4 == 0)
     const bool second = xc0 >= a.Csplit;
     int x0 = 0;                                          // first column of the run's strip
-    auto load_x = [&](int b, int gy, float (&dst)[NXL][4], bool& ok, float (&hdst)[1], bool& hok) {
+    auto ld4 = [](__amdgpu_buffer_rsrc_t rs, uint32_t off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0)); };
+    auto load_x = [&](int b, int gy, f32x4 (&dst)[NXL], bool& ok, float (&hdst)[1], bool& hok) {
         ok = (unsigned)gy < (unsigned)a.H;
         const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
                                                  : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
         const uint32_t off = (uint32_t)((second ? xc0 - a.Csplit : xc0) * HW + gy * a.W + x0 + lane * 4) * 4u;
 #pragma unroll
-        for (int i = 0; i < NXL; ++i) buf_load<4>(rs, (ok && xc0 + i < a.Cin) ? off + (uint32_t)i * HW4 : kOob, dst[i]);
+        for (int i = 0; i < NXL; ++i) dst[i] = ld4(rs, (ok && xc0 + i < a.Cin) ? off + (uint32_t)i * HW4 : kOob);
         if constexpr (STRIP) {
             const int hc = lane % NXL, hx = lane < NXL ? x0 - 1 : x0 + WIDTH;
             hok = ok && lane < 2 * NXL && (unsigned)hx < (unsigned)a.W && xc0 + hc < a.Cin;
@@ -84,28 +95,28 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
         }
     };
     int d_b = 0, d_gy = 0;                               // image and row of the dy row the registers hold (DT: where it is written through)
-    auto load_d = [&](int b, int gy, float (&dst)[NDL][4], bool& ok) {
+    auto load_d = [&](int b, int gy, f32x4 (&dst)[NDL], bool& ok) {
         ok = (unsigned)gy < (unsigned)a.H;
         d_b = b; d_gy = gy;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dout + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
             const int c = wave_u * NDL + i;
-            buf_load<4>(rs, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob, dst[i]);
+            dst[i] = ld4(rs, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob);
         }
         if constexpr (DT) {
             const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.dt_y + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
 #pragma unroll
             for (int i = 0; i < NDL; ++i) {
                 const int c = wave_u * NDL + i;
-                buf_load<4>(rsy, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob, ry[i]);
+                ry[i] = ld4(rsy, (ok && c < a.Cout) ? (uint32_t)(c * HW + gy * a.W + x0 + lane * 4) * 4u : kOob);
             }
         }
     };
-    auto store_x = [&](float (&src)[NXL][4], bool ok, int slot, float (&hsrc)[1], bool hok) {
+    auto store_x = [&](f32x4 (&src)[NXL], bool ok, int slot, float (&hsrc)[1], bool hok) {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
-            asm volatile("" : "+v"(src[i][0]), "+v"(src[i][1]), "+v"(src[i][2]), "+v"(src[i][3]));      // first touch (conv_hp16_body)
+            asm volatile("" : "+v"(src[i]));          // first touch (conv_hp16_body)
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -142,13 +153,13 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
             }
         }
     };
-    auto store_d = [&](float (&src)[NDL][4]) {
+    auto store_d = [&](f32x4 (&src)[NDL]) {
 #pragma unroll
         for (int i = 0; i < NDL; ++i) {
-            asm volatile("" : "+v"(src[i][0]), "+v"(src[i][1]), "+v"(src[i][2]), "+v"(src[i][3]));
+            asm volatile("" : "+v"(src[i]));
             float v[4] = {src[i][0], src[i][1], src[i][2], src[i][3]};
             if constexpr (DT) {                        // dy = sc (d - k2 - x_hat k3), d = g or slope g by the sign of the BatchNorm output (norm_act.hip: dpre)
-                asm volatile("" : "+v"(ry[i][0]), "+v"(ry[i][1]), "+v"(ry[i][2]), "+v"(ry[i][3]));
+                asm volatile("" : "+v"(ry[i]));
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float yc = ry[i][k] - dtc[i][0];
@@ -206,7 +217,8 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
         }
         // rows r0 - 1 and r0 into slots 0 and 1, then row r0 + 1 (slot 2) and dy row r0: two fetch rounds, both in flight together
         {
-            float ra[NXL][4], rb[NXL][4], ha[1] = {0.f}, hb[1] = {0.f};
+            f32x4 ra[NXL], rb[NXL];
+            float ha[1] = {0.f}, hb[1] = {0.f};
             bool oka, okb, hoka = false, hokb = false;
             load_x(b, r0 - 1, ra, oka, ha, hoka);
             load_x(b, r0, rb, okb, hb, hokb);
@@ -220,11 +232,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
         }
         __syncthreads();
         int s0 = 0;                                       // slot of input row y - 1; rows y, y + 1 follow cyclically
-#pragma unroll 1
-        for (int y = r0; y < r0 + ROWS; ++y) {
-            const bool more = y + 1 < r0 + ROWS;
-            if (more) { load_x(b, y + 2, rx, x_in, rhx, h_in); load_d(b, y + 1, rd, d_in); }
-
+        auto contract = [&]() {                           // dy row (sD) against the three live input rows
 #pragma unroll
             for (int sgi = 0; sgi < 2; ++sgi) {
                 const int gq = (sp * 2 + sgi) * 4 + kq;  // this lane's 8-pixel group of the row
@@ -262,10 +270,42 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
                     }
                 }
             }
-            __syncthreads();                              // every wave is done with input row y - 1 and dy row y
-            if (more) { store_x(rx, x_in, s0, rhx, h_in); store_d(rd); }
-            s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
-            __syncthreads();
+        };
+        if constexpr (DEPTH == 1) {
+#pragma unroll 1
+            for (int y = r0; y < r0 + ROWS; ++y) {
+                const bool more = y + 1 < r0 + ROWS;
+                if (more) { load_x(b, y + 2, rx, x_in, rhx, h_in); load_d(b, y + 1, rd, d_in); }
+                contract();
+                __syncthreads();                          // every wave is done with input row y - 1 and dy row y
+                if (more) { store_x(rx, x_in, s0, rhx, h_in); store_d(rd); }
+                s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
+                __syncthreads();
+            }
+        } else {
+            // set 1 (rx, rd) serves the even steps of the run, set 2 the odd ones; a set is fetched right behind its own consumption, two
+            // steps ahead of the step whose end needs it.  BRANCH-FREE: a row the run does not need is fetched from row -1 (out of
+            // range: zeros, no memory access) and stored all the same -- with a load or a store inside a branch the compiler's vmcnt
+            // bookkeeping merges the paths and waits for BOTH sets in front of the first store (ISA: tools/diag/isa_outline.py).
+            const int rend = r0 + ROWS;
+            load_x(b, r0 + 2, rx, x_in, rhx, h_in); load_d(b, r0 + 1, rd, d_in);
+            __builtin_amdgcn_sched_barrier(0);            // (the two sets' loads stay in this order)
+            load_x(b, r0 + 3, rx2, x_in2, rhx2, h_in2); load_d(b, r0 + 2, rd2, d_in2);
+#pragma unroll 1
+            for (int y = r0; y < rend; y += 2) {
+                contract();
+                __syncthreads();
+                store_x(rx, x_in, s0, rhx, h_in); store_d(rd);          // input row y + 2, dy row y + 1
+                s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
+                __syncthreads();
+                { const bool v = y + 3 < rend; load_x(b, v ? y + 4 : -1, rx, x_in, rhx, h_in); load_d(b, v ? y + 3 : -1, rd, d_in); }
+                contract();
+                __syncthreads();
+                store_x(rx2, x_in2, s0, rhx2, h_in2); store_d(rd2);     // input row y + 3, dy row y + 2 (zeros behind the run's last step)
+                s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
+                __syncthreads();
+                { const bool v = y + 4 < rend; load_x(b, v ? y + 5 : -1, rx2, x_in2, rhx2, h_in2); load_d(b, v ? y + 4 : -1, rd2, d_in2); }
+            }
         }
     }
 
@@ -317,23 +357,29 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     }
 }
 
+// (the *2 kernels keep two rows in flight ahead of the contraction, DEPTH 2: measured SLOWER in the step -- hrwrw<1> 60.0 -> 71.2 us,
+// hrwrw_bn<1> 62.6 -> 68.1 us, profiles/r05_row_kernels_ab.txt -- and launched only under UAPS_TUNE_DEEP_ROWS; bit-identical slabs)
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrw_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false>(a); }
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrw_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrw2_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, false, false, 2>(a); }
+template <int WCI>
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrw2_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, false, false, 2>(a); }
 // the forms that turn d(activation) into dy while staging (DT, uaps_call_hints::dyt_*)
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, false, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrw_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, false, true>(a); }
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrw_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, false, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrw_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, false, true>(a); }
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true, true>(a); }
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true, true>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true>(a); }
 template <int WCI>
-__global__ __launch_bounds__(256 * WCI) void conv_hrwrww_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true>(a); }
+__global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_bn_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true>(a); }
 
 }  // namespace uaps

@@ -189,11 +189,12 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     const bool vec = vec16;
     hipStream_t s = (hipStream_t)stream;
     // DT (uaps_call_hints::dyt_*): `dy` is d(activation) behind the BatchNorm that follows this convolution; only some kernels can
-    // turn it into dy while staging -- every other path returns UAPS_ERANGE before anything is launched
+    // turn it into dy while staging -- every other path returns UAPS_ENOFORM before anything is launched
     const bool dyt = hints.dyt_y != nullptr;
     if (dyt) {
         if (!hints.dyt_coef || !hints.dyt_out || hints.dyt_groups < 1 || hints.dyt_groups > kWrwMaxGroups || B % hints.dyt_groups) return UAPS_EINVAL;
-        if (((uintptr_t)hints.dyt_y | (uintptr_t)hints.dyt_out) % 16 || !(hints.dyt_slope >= 0.f && hints.dyt_slope <= 1.f)) return UAPS_ERANGE;
+        if (!(hints.dyt_slope >= 0.f && hints.dyt_slope <= 1.f)) return UAPS_ERANGE;
+        if (((uintptr_t)hints.dyt_y | (uintptr_t)hints.dyt_out) % 16) return UAPS_ENOFORM;      // the in-staging form streams 16-byte pieces
         a.dt_y = hints.dyt_y; a.dt_coef = hints.dyt_coef; a.dt_out = hints.dyt_out; a.dt_slope = hints.dyt_slope; a.dt_Bg = B / hints.dyt_groups;
     }
     // full-width-row kernels (conv_split_wrw_row.hpp): maps of 256 pixels width or a multiple (256-wide column strips), <= 16 output and 16 / 32 input channels, every operand bounded;
@@ -229,6 +230,17 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
             }
             return (int)hipGetLastError();
         }
+        // diagnostic: two rows in flight ahead of the contraction (DEPTH 2 of conv_hrwrw_body; measured slower)
+        if ((uaps_conv_get_tuning() & UAPS_TUNE_DEEP_ROWS) && W == 256) {
+            if (Cin <= 16) {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw2_bn_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrw2_kernel<1>), dim3(grid), dim3(256), 0, s, a);
+            } else {
+                if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrw2_bn_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+                else UAPS_LAUNCH_MAIN((conv_hrwrw2_kernel<2>), dim3(grid), dim3(512), 0, s, a);
+            }
+            return (int)hipGetLastError();
+        }
         if (W > 256) {                                 // 256-wide column strips
             if (Cin <= 16) {
                 if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_kernel<1>), dim3(grid), dim3(256), 0, s, a);
@@ -248,7 +260,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     }
     // (the tile kernels have no DT form: built and measured late in round 4 -- 32 x 32 channel blocks, bit-identical dy -- the extra
     // staging work cost them more than the stand-alone pass it replaced: 12 launches +314 us against 224 us saved)
-    if (dyt) return UAPS_ERANGE;
+    if (dyt) return UAPS_ENOFORM;
     if (p.g1) {
         // single-tensor, 16-byte-aligned form only; workspace and reduce follow the same plan, so the caller chooses: cfg bit 28
         // (exact kernels) for a two-tensor / BatchNorm-in-staging / odd-pointer call of such a layer -- uaps_amd.conv.plan_cfg does

@@ -1,5 +1,6 @@
 #include "hints.hpp"
 #include <string.h>
+#include <stddef.h>
 
 namespace {
 thread_local uaps_call_hints g_hints;
@@ -7,7 +8,9 @@ thread_local bool g_have = false;
 thread_local uaps::LaunchEvents g_launch;
 constexpr int kMaxDevices = 64;
 unsigned* g_error_word[kMaxDevices] = {};      // one per device: a kernel only ever writes to a word of the device it runs on
-int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices ? d : 0; }
+// -1: no current device or one beyond the table -- such a device gets NO error word (its kernels report nothing) instead of device
+// 0's, which a kernel on another device must never store to
+int current_device() { int d = 0; return hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices ? d : -1; }
 }
 
 namespace uaps {
@@ -18,13 +21,15 @@ uaps_call_hints take_hints() {
     return h;
 }
 LaunchEvents& launch_events() { return g_launch; }
-unsigned* error_word() { return g_error_word[current_device()]; }
+unsigned* error_word() { const int d = current_device(); return d >= 0 ? g_error_word[d] : nullptr; }
 }  // namespace uaps
 
 extern "C" int uaps_set_error_word(unsigned* device_word) {
     if ((uintptr_t)device_word % 4) return UAPS_EINVAL;
-    g_error_word[current_device()] = device_word;      // the word of the CURRENT device (hipSetDevice), like every launch here
-    return UAPS_OK;
+    const int d = current_device();
+    if (d < 0) return device_word ? UAPS_ERANGE : UAPS_OK;      // (no device: nothing to attach to, nothing to detach)
+    g_error_word[d] = device_word;      // the word of the CURRENT device (hipSetDevice), like every launch here; ONE word per device:
+    return UAPS_OK;                     // every model / trainer of the process on that device shares it, and whoever reads it clears it for all
 }
 
 // Zero fill of bound slots with agent-scope stores: the slots are then raised by memory-side atomics and read with agent-scope
@@ -53,8 +58,14 @@ extern "C" int uaps_next_launch_events(void* start, void* stop) {
 
 extern "C" int uaps_next_call_hints(const uaps_call_hints* h) {
     if (!h) { g_have = false; return UAPS_OK; }
+    // size-versioned: a client built against an older, shorter struct is read only as far as ITS struct goes
+    const unsigned n = h->struct_size;
+    if (n < offsetof(uaps_call_hints, out_amax) || n > sizeof(uaps_call_hints)) return UAPS_EINVAL;
+    uaps_call_hints t;
+    memset(&t, 0, sizeof t);
+    memcpy(&t, h, n);
     for (int i = 0; i < 3; ++i)
-        if (h->bound[i] && !(h->mul[i] > 0.f && h->mul[i] < 3.0e38f)) return UAPS_EINVAL;
-    g_hints = *h; g_have = true;
+        if (t.bound[i] && !(t.mul[i] > 0.f && t.mul[i] < 3.0e38f)) return UAPS_EINVAL;
+    g_hints = t; g_have = true;
     return UAPS_OK;
 }

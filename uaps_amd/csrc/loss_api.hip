@@ -2,7 +2,7 @@
 #include "loss_dispatch.hpp"
 using namespace uaps;
 
-extern "C" int uaps_abi_version(void) { return 1; }
+extern "C" int uaps_abi_version(void) { return 2; }      // 2 (round 5): uaps_call_hints::struct_size, UAPS_ENOFORM, uaps_conv_ex
 
 // Process-wide pointer to the device-resident step state (philox.hpp); every launch wrapper that has per-step scalars or
 // random draws passes it to its kernel.  NULL = by-value arguments only (the default; eager execution needs nothing else).
@@ -20,6 +20,7 @@ extern "C" const char* uaps_error_string(int code) {
         case UAPS_EINVAL: return "invalid argument (null pointer or non-positive dimension)";
         case UAPS_ERANGE: return "argument outside the supported range (heads 1..8, classes 2..8; conv kernels 1x1 / 3x3, dilation 1 / 2 / 4; the fused BatchNorm forms need W % 4 == 0 and 16-byte aligned tensors)";
         case UAPS_EWORKSPACE: return "workspace too small";
+        case UAPS_ENOFORM: return "the kernel this layer runs on has no form for the requested hint (uaps_call_hints::dyt_*); nothing was launched";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }

@@ -336,9 +336,9 @@ class _BnActConv(torch.autograd.Function):
                         _lib.hints((dzb, xb))
                     rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
                                                            Cout, H, W, ks, cfg, cws.data_ptr(), cws.numel(), st)
-                    if lz is not None and rc == lazybn.ERANGE:
+                    if lz is not None and rc == lazybn.ENOFORM:
                         tm.on = False
-                if lz is not None and rc == lazybn.ERANGE:
+                if lz is not None and rc == lazybn.ENOFORM:
                     return None
                 _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
                 rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
@@ -357,7 +357,7 @@ class _BnActConv(torch.autograd.Function):
             weight_gradient(dz, dzb, None)
         dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys[:3]]      # dgamma, dbeta, d(conv bias) = 0
         ws = _bn_ws(dev, B, Cc, H, W)
-        if ctx.lazy_up:
+        if ctx.lazy_up and not lazybn.observed(y):      # (a hook / retain_grad registered on y since the forward gets the true gradient)
             # the reductions only; d(activation) goes up as it is, its transform pending (lazybn): y's producer forms dy in its weight gradient
             lazybn.prepare(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], ws)
             dy = da

@@ -122,12 +122,11 @@ class StepGraph:
         """Forward, loss block and backward; every per-step scalar comes from the step state (w = None, cw = NaN)."""
         tr = self.tr
         perturb._RngState.offset = 0                 # the key changes every step: the counters may restart (and must, for replays)
-        both = tr.model.forward_pair(x_l, x_u)
-        out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
-        tr.optimizer.zero_grad(set_to_none=True)
-        lazybn.reset()
-        out.loss.backward()
-        lazybn.assert_none_pending()
+        with lazybn.scope():
+            both = tr.model.forward_pair(x_l, x_u)
+            out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
+            tr.optimizer.zero_grad(set_to_none=True)
+            out.loss.backward()
         return out, both
 
     def _tail(self, both, x_l, y_l):

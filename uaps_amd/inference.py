@@ -8,7 +8,7 @@ from typing import Dict, Iterable, Optional, Tuple
 import numpy as np
 import torch
 
-from . import consistency, metrics
+from . import consistency, losses, metrics
 
 
 @torch.no_grad()
@@ -23,13 +23,22 @@ def predict(model: torch.nn.Module, images: torch.Tensor) -> Tuple[torch.Tensor,
 
 
 @torch.no_grad()
+def ensemble_from_heads(heads) -> torch.Tensor:
+    """Arg-max of the mean softmax of the given head logits: `uaps_unsup_fwd` (csrc/loss_kernels.hpp) with uniform mixing weights --
+    its pseudo-label IS argmax_c sum_k w_k softmax(z_k)_c (UAPS_train.py:251-255) -- one pass over the D logit tensors instead of D
+    softmax launches and D - 1 adds.  int64 [B,H,W]."""
+    D = len(heads)
+    if D == 1:
+        return torch.argmax(heads[0], dim=1)
+    return losses.uaps_unsup_loss(tuple(heads), [1.0 / D] * D, 0.0, 0.0).pseudo
+
+
+@torch.no_grad()
 def predict_ensemble(model: torch.nn.Module, images: torch.Tensor) -> torch.Tensor:
-    """Arg-max of the mean softmax over all heads (the "ensemble" rows of the paper's decoder study, README.md:107-111)."""
+    """Arg-max of the mean softmax over all heads (the "ensemble" rows of the paper's decoder study, README.md:107-111; notebook
+    cells 11-19 with every head's softmax averaged), on the loss block's mixing kernel."""
     _, heads = predict(model, images)
-    prob = torch.softmax(heads[0], dim=1)
-    for h in heads[1:]:
-        prob = prob + torch.softmax(h, dim=1)
-    return torch.argmax(prob, dim=1)
+    return ensemble_from_heads(heads)
 
 
 @torch.no_grad()

@@ -2,18 +2,27 @@
 
 The backward of conv -> BatchNorm -> LeakyReLU (UAPS_unet.py:37-43 under autograd) read d(activation) and the raw conv output
 twice (the reductions, then dx) and wrote dy for the convolution's two gradient kernels to read again.  Here the node that owns
-the BatchNorm runs the reductions only (`prepare`) and hands d(activation) upstream UNTRANSFORMED, registered in `_pending`
-under its address; the node that owns the convolution (`take`) lets its weight-gradient kernel form dy while it stages that
-operand and write it through for the input-gradient kernel -- or, where the layer's kernel has no such form, runs the
-stand-alone pass (`materialize`).  Only raw conv outputs whose producer is one of those nodes are handed up this way (the
-producers mark them, `mark`), and `assert_none_pending` after a backward turns a gradient that reached anything else into an
-error instead of a silently wrong step.  UAPS_LAZY_BN_BWD=0 keeps the one-piece backward.
+the BatchNorm runs the reductions only (`prepare`) and hands d(activation) upstream UNTRANSFORMED; the node that owns the
+convolution (`take`) lets its weight-gradient kernel form dy while it stages that operand and write it through for the
+input-gradient kernel -- or, where the layer's kernel has no such form, runs the stand-alone pass (`materialize`).
+
+Safety (round 5).  Between the two nodes the tensor autograd calls "gradient" is not one, so the mechanism is fenced:
+  * it is OFF unless the forward runs inside `lazybn.scope()` -- the trainers (UAPSTrainer, BaselineTrainer, StepGraph) open one
+    around forward + backward of a step; a user-driven `model(x)` / `loss.backward()` (the reference's
+    UAPS_train.py:177-292 loop) always takes the one-piece backward;
+  * the pending record travels ON THE GRADIENT TENSOR (as `_uaps_bound` does), together with the tensor's version counter and
+    address at hand-over: nothing is keyed by an address, a recycled allocation can never meet a stale record, and a gradient
+    that was summed in place with a second consumer's (same object, higher version) is refused with an error instead of being
+    transformed; a sum that made a new tensor drops the record and `assert_none_pending` (scope exit) fails the step;
+  * a conv output that is observed -- a tensor hook, `retain_grad()` -- is never handed an untransformed gradient (checked when
+    the consumer's forward runs and again in its backward): the observer sees the true gradient.
+UAPS_LAZY_BN_BWD=0 keeps the one-piece backward everywhere.
 """
 from __future__ import annotations
 
-import ctypes as C
+import contextlib
 import os
-from typing import Dict, Optional
+from typing import Optional
 
 import torch
 
@@ -21,20 +30,42 @@ from . import _lib, bounds
 
 _ON = os.environ.get("UAPS_LAZY_BN_BWD", "1") != "0"
 _OK = "_uaps_lazy_ok"
+_REC = "_uaps_lazy"
+_depth = 0             # open scopes (forward runs on the caller's thread; autograd's worker threads only touch _outstanding)
+_outstanding = 0       # records handed up and not yet taken
+_prepared = 0          # records ever handed up (tests)
 
 
 class Lazy:
-    __slots__ = ("y", "coef", "slope", "groups", "bound")
+    __slots__ = ("y", "coef", "slope", "groups", "bound", "version", "ptr")
 
-    def __init__(self, y, coef, slope, groups, bound):
+    def __init__(self, y, coef, slope, groups, bound, version=0, ptr=0):
         self.y, self.coef, self.slope, self.groups, self.bound = y, coef, float(slope), int(groups), bound
+        self.version, self.ptr = version, ptr
 
 
-_pending: Dict[int, Lazy] = {}
+@contextlib.contextmanager
+def scope():
+    """Forward + backward of one training step of a caller that drives both itself (the trainers): inside, marked conv outputs get
+    the two-halves backward.  On a clean exit every handed-up gradient must have been taken by its producer; an exception drops
+    what a failed backward left behind."""
+    global _depth, _outstanding
+    if _depth == 0:
+        _outstanding = 0
+    _depth += 1
+    try:
+        yield
+    except BaseException:
+        _outstanding = 0
+        raise
+    finally:
+        _depth -= 1
+    if _depth == 0:
+        assert_none_pending()
 
 
 def enabled() -> bool:
-    return _ON and bounds.enabled()
+    return _ON and _depth > 0 and bounds.enabled()
 
 
 def mark(y: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -48,12 +79,18 @@ def mark(y: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def observed(y: torch.Tensor) -> bool:
+    """Someone other than y's producer will look at y's gradient: a tensor hook or retain_grad()."""
+    return bool(getattr(y, "_backward_hooks", None)) or (y.requires_grad and not y.is_leaf and y.retains_grad)
+
+
 def marked(y: torch.Tensor) -> bool:
-    return enabled() and bool(getattr(y, _OK, False))
+    return enabled() and bool(getattr(y, _OK, False)) and not observed(y)
 
 
 def prepare(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dconv_bias, ws) -> Lazy:
-    """The reductions of the BatchNorm backward of (dout = d(activation), y); registers dout as pending and returns the record."""
+    """The reductions of the BatchNorm backward of (dout = d(activation), y); attaches the pending record to dout and returns it."""
+    global _outstanding, _prepared
     B, Cc, H, W = y.shape
     dev = y.device
     coef = torch.empty((groups, Cc, 8), dtype=torch.float32, device=dev)
@@ -65,18 +102,31 @@ def prepare(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dc
                                                 dconv_bias.data_ptr() if dconv_bias is not None else None, bnd.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
     _lib.check(rc, "uaps_bn_act_bwd_prepare")
-    lz = Lazy(y, coef, slope, groups, (bnd, 1.0))
-    _pending[dout.data_ptr()] = lz
+    lz = Lazy(y, coef, slope, groups, (bnd, 1.0), dout._version, dout.data_ptr())
+    setattr(dout, _REC, lz)
+    _outstanding += 1
+    _prepared += 1
     return lz
 
 
+def prepared_total() -> int:
+    return _prepared
+
+
 def take(dz: Optional[torch.Tensor]) -> Optional[Lazy]:
-    """The pending transform of the gradient tensor dz (call before anything that could copy it), or None."""
-    if dz is None or not _pending:
+    """The pending transform of the gradient tensor dz (call before anything that could copy it), or None.  Raises when dz is
+    no longer the tensor that was handed up (summed in place with another consumer's gradient, resized, re-pointed)."""
+    global _outstanding
+    if dz is None:
         return None
-    lz = _pending.pop(dz.data_ptr(), None)
-    if lz is not None and (lz.y.shape != dz.shape or lz.y.device != dz.device):      # a stale record of an abandoned backward
+    lz = getattr(dz, _REC, None)
+    if lz is None:
         return None
+    delattr(dz, _REC)
+    _outstanding = max(0, _outstanding - 1)
+    if dz._version != lz.version or dz.data_ptr() != lz.ptr or dz.shape != lz.y.shape or dz.device != lz.y.device:
+        raise RuntimeError("a gradient with a pending BatchNorm transform was modified before its producer saw it (a second "
+                           "consumer of a raw conv output inside lazybn.scope()?); set UAPS_LAZY_BN_BWD=0")
     return lz
 
 
@@ -96,17 +146,18 @@ def materialize(dz: torch.Tensor, lz: Lazy) -> torch.Tensor:
 
 
 def reset() -> None:
-    """Forget records a failed backward may have left behind (call in front of a backward: a stale record could meet a new tensor
-    at the same address)."""
-    _pending.clear()
+    """Forget what a failed backward may have left behind (records live on their gradient tensors and die with them; only the
+    count is global)."""
+    global _outstanding
+    _outstanding = 0
 
 
 def assert_none_pending() -> None:
-    if _pending:
-        n = len(_pending)
-        _pending.clear()
+    global _outstanding
+    if _outstanding:
+        n, _outstanding = _outstanding, 0
         raise RuntimeError(f"{n} gradient(s) with a pending BatchNorm transform reached a node that does not apply it "
                            "(uaps_amd/lazybn.py); set UAPS_LAZY_BN_BWD=0")
 
 
-ERANGE = -2
+ENOFORM = -4        # UAPS_ENOFORM (include/uaps_hip.h): the layer's kernel cannot apply the pending transform while staging

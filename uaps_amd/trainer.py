@@ -110,27 +110,26 @@ class UAPSTrainer:
         if not self.model.training:                      # model.train() walks ~2600 modules: only when the mode changes
             self.model.train()
         cw1, cw2 = self.consistency_weights()
-        if self.pair_forward and x_l.shape == x_u.shape:
-            both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
-            if w is None:
-                w = self.mix_rng.dirichlet(np.ones(len(both)), size=1)[0]        # :251
-            out = losses.uaps_pair_loss(both, y_l, w, cw1, cw2, exchange=self.exchange)   # :186-282
-            lab = tuple(z[: x_l.shape[0]] for z in both)
-        else:
-            lab = self.model(x_l)                                                 # UAPS_train.py:177
-            un = self.model(x_u)                                                  # :185
-            if not isinstance(lab, (tuple, list)):
-                lab, un = (lab,), (un,)
-            if w is None:
-                w = self.mix_rng.dirichlet(np.ones(len(un)), size=1)[0]          # :251
-            if self.exchange is not None:
-                out = self.loss_fn(lab, y_l, un, w, cw1, cw2, exchange=self.exchange)
+        with lazybn.scope():                             # forward + backward of a step this trainer drives itself: the two-halves BatchNorm backward may run
+            if self.pair_forward and x_l.shape == x_u.shape:
+                both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
+                if w is None:
+                    w = self.mix_rng.dirichlet(np.ones(len(both)), size=1)[0]        # :251
+                out = losses.uaps_pair_loss(both, y_l, w, cw1, cw2, exchange=self.exchange)   # :186-282
+                lab = tuple(z[: x_l.shape[0]] for z in both)
             else:
-                out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
-        self.optimizer.zero_grad(set_to_none=True)                                # :285
-        lazybn.reset()
-        out.loss.backward()                                                       # :287
-        lazybn.assert_none_pending()
+                lab = self.model(x_l)                                                 # UAPS_train.py:177
+                un = self.model(x_u)                                                  # :185
+                if not isinstance(lab, (tuple, list)):
+                    lab, un = (lab,), (un,)
+                if w is None:
+                    w = self.mix_rng.dirichlet(np.ones(len(un)), size=1)[0]          # :251
+                if self.exchange is not None:
+                    out = self.loss_fn(lab, y_l, un, w, cw1, cw2, exchange=self.exchange)
+                else:
+                    out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
+            self.optimizer.zero_grad(set_to_none=True)                                # :285
+            out.loss.backward()                                                       # :287
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :292
@@ -305,13 +304,12 @@ class BaselineTrainer(UAPSTrainer):
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u=None, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:
             self.model.train()
-        out = self.model(x_l)                                                     # baseline_train.py:158
-        main = out[0] if isinstance(out, (tuple, list)) else out
-        s = losses.uaps_sup_loss((main,), y_l)                                    # :161-164, 0.5 * (dice + CE)
-        self.optimizer.zero_grad(set_to_none=True)                                # :166
-        lazybn.reset()
-        s.loss.backward()                                                         # :168
-        lazybn.assert_none_pending()
+        with lazybn.scope():
+            out = self.model(x_l)                                                 # baseline_train.py:158
+            main = out[0] if isinstance(out, (tuple, list)) else out
+            s = losses.uaps_sup_loss((main,), y_l)                                # :161-164, 0.5 * (dice + CE)
+            self.optimizer.zero_grad(set_to_none=True)                            # :166
+            s.loss.backward()                                                     # :168
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :173
