@@ -202,6 +202,47 @@ def other_configs(steps, dev):
     return out
 
 
+def inference_block(dev, size=256, classes=4, aux=3):
+    """Row f-2 (the reference's only published performance figures are inference: README.md:107-111 / fig_data/decoder-effect.jpg,
+    notebook cells 11-19): ms per image of (a) the main head alone -- encoder + main decoder + arg-max, what the paper's
+    "main decoder only" row times -- and (b) the all-heads ensemble -- every decoder + the mixing kernel's arg-max of the mean
+    softmax -- at batch 1 and 16, eval mode, eager launches on one stream, inputs resident; median of `reps` timed calls."""
+    import numpy as np
+    import torch
+    import uaps_amd
+    import uaps_amd.unet as _unet
+    from uaps_amd import inference
+    streams = _unet._DECODER_STREAMS
+    out = {"note": "eval mode, eager launches, one HIP stream, inputs resident in HBM, fp32; median over timed calls of HIP-event time; "
+                   "the paper's figures (hardware not stated in the repository): main head 4.48 ms / image, ensemble of 4 heads 29.47 ms / image",
+           "paper_ms_per_image": {"main_head": 4.48, "ensemble_4_heads": 29.47}}
+    try:
+        _unet._DECODER_STREAMS = False
+        torch.manual_seed(1337)
+        model = uaps_amd.net_factory("unet_uaps", 3, classes, n_aux=aux)
+        model.eval()
+        for B in (1, 16):
+            x = torch.randn(B, 3, size, size, device=dev)
+            rec = {}
+            for name, fn in (("main_head", lambda: inference.predict_main(model, x)), ("ensemble", lambda: inference.predict_ensemble(model, x))):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(10):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); fn(); e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                rec[name] = {"ms_per_call": round(float(np.median(ts)), 3), "ms_per_image": round(float(np.median(ts)) / B, 3)}
+            out[f"batch_{B}"] = rec
+    except Exception as e:                                   # never lose the headline line to a side measurement
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        _unet._DECODER_STREAMS = streams
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N ...` without torch.distributed.run: start N fresh copies of this command, one rank per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as the launcher would), wait for them and return the job's exit code.
@@ -262,6 +303,7 @@ def main():
     ap.add_argument("--exact-steps", type=int, default=5,
                     help="steps timed with every convolution on the fp32 matrix instruction after the headline (0 = skip)")
     ap.add_argument("--analysis-steps", type=int, default=6, help="single-stream steps after the timed region for the per-kernel figures")
+    ap.add_argument("--no-inference", action="store_true", help="skip the inference block (main head / ensemble ms per image, N = 1 only)")
     ap.add_argument("--other-configs", type=int, default=4,
                     help="N = 1 only: steps timed of each of BASELINE.json configs[3] and the per-GPU shape of configs[4] after everything else (0 = skip)")
     args = ap.parse_args()
@@ -338,7 +380,14 @@ def main():
     # N > 1 steps eagerly (decoder streams, bucket all-reduces overlapped with the backward).  UAPS_GRAPH_MULTI=1 selects the two-graph
     # form of uaps_amd/graph.py instead (two gloo ranks on one card: bit-equal to the eager step; over RCCL only ever run with one
     # rank here, where tools/diag/rccl_split_graph.py once aborted behind other process groups of the same process -- so not the default)
-    use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or os.environ.get("UAPS_GRAPH_MULTI", "0") == "1")
+    # Round 5: the eager step needs the host -- 14.0 ms with two cores per rank, 18.3 ms with one -- so when the
+    # ranks have fewer than 4 usable cores each, the two-graph form is selected by itself (UAPS_GRAPH_MULTI=0 forces eager, =1 forces
+    # the graphs).  The abort seen once behind it happened in a process that had created and destroyed other process groups with captures
+    # in between; this script creates exactly one group per process, before any capture.
+    cores_per_rank = (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(world, 1) if affinity is None else len(affinity)
+    gm = os.environ.get("UAPS_GRAPH_MULTI", "")
+    graph_multi = gm == "1" or (gm != "0" and world > 1 and cores_per_rank < 4)
+    use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or graph_multi)
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
     data = uaps_amd.data.SyntheticBatches(b, args.in_chns, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
 
@@ -384,15 +433,19 @@ def main():
     # profiles): one step with HIP events attached to the dispatch of every hand-written conv / loss kernel (finds the dominant
     # instantiation and sums the step's algorithmic flops), then `analysis_steps` steps with events around the dominant
     # kernel's launches and the loss kernels only, timed as a whole for the single-stream ms/step ----
-    discover, ev, cev, single_ms = None, {}, {}, None
+    discover, ev, cev, single_ms, alg_bytes = None, {}, {}, None, None
     if args.analysis_steps > 0:                              # every rank steps (the gradient exchange is collective); rank 0's events are reported
         _unet._DECODER_STREAMS = False
         trainer.step_graph, trainer.optimizer.from_step_state = None, False     # eager launches: events can bracket each kernel
         trainer.train_step(*data.next())                   # re-warm in the new mode
         torch.cuda.synchronize()
         conv.KERNEL_EVENTS, conv.EVENT_FILTER, losses.KERNEL_EVENTS = {}, None, {}
+        from uaps_amd import _lib as _ulib
+        _ulib.lib().uaps_account(1)                        # the library tallies the algorithmic bytes of every launch of this one step
         trainer.train_step(*data.next())
         torch.cuda.synchronize()
+        _ulib.lib().uaps_account(0)
+        alg_bytes = float(_ulib.lib().uaps_accounted_bytes())
         discover = summarize(conv.KERNEL_EVENTS)
         for k, pairs in losses.KERNEL_EVENTS.items():
             us = [s.elapsed_time(e) * 1e3 for s, e in pairs]
@@ -528,6 +581,16 @@ def main():
             t_mfma_f32 = step_flops / (MFMA_F32_PEAK_TF * 1e12) * 1e3
             t_hbm = step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if step_bytes else None
             t_min = max(t_mfma, t_hbm or 0.0)
+            # the same against the ALGORITHMIC bytes of the step (uaps_account: every launch's operands read once and results written
+            # once in this fused design) -- measured bytes in t_min_hbm raise the floor with every wasted byte, these do not
+            t_alg = alg_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 if alg_bytes else None
+            roof.update({"step_algorithmic_bytes": alg_bytes, "t_min_alg_hbm_ms": round(t_alg, 3) if t_alg else None,
+                         "t_min_alg_ms": round(max(t_mfma, t_alg or 0.0), 3),
+                         "frac_step_alg": round(max(t_mfma, t_alg or 0.0) / ms_per_step, 4),
+                         "hbm_bytes_over_algorithmic": round(step_bytes / alg_bytes, 3) if (step_bytes and alg_bytes) else None,
+                         "step_algorithmic_bytes_note": "sum over the launches of one step of (operand tensors read once + results written once), fp32 / int64 as "
+                                                        "the reference holds them, tallied by the library's entry points (uaps_account; DESIGN.md section 5): the "
+                                                        "traffic floor of THIS fused design, against which step_hbm_bytes (PMC) shows the re-reads"})
             roof.update({"step_flops": step_flops, "step_hbm_bytes": step_bytes,
                          "step_hbm_bytes_note": "sum over all kernels of launches x (2*FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 "
                                                 "--pmc passes of this bench command, per step; null when no PMC summary is committed",
@@ -596,6 +659,10 @@ def main():
             # the other single-GPU shapes of BASELINE.json, a few eager steps each (decoder streams as in the headline): not the
             # metric, but a number the driver sees for them
             res["other_configs"] = other_configs(args.other_configs, dev)
+        if world == 1 and not args.no_inference and args.net == "unet_uaps" and (H, C, args.aux) == (256, 4, 3):
+            res["inference"] = inference_block(dev, H, C, args.aux)
+        if world > 1:
+            res["config"]["cores_per_rank"] = cores_per_rank
         if world == 1 and not args.no_cpu_baseline and args.net == "unet_uaps":
             res["cpu_baseline"] = cpu_baseline(b, H, W)
         print(json.dumps(res), flush=True)

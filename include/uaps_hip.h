@@ -433,6 +433,13 @@ int uaps_next_call_hints(const uaps_call_hints* hints);
  * trace reports it.  One-shot; (NULL, NULL) disarms.  Returns 1 when the previously armed pair was consumed by a launch since
  * the last call, else 0. */
 int uaps_next_launch_events(void* start, void* stop);
+/* Measurement aid (bench.py: roofline.step_algorithmic_bytes).  uaps_account(1) zeroes a process-wide tally and switches it on:
+ * from then on every kernel entry point of this library adds the ALGORITHMIC bytes of the launch it enqueues -- every operand
+ * tensor read once and every result written once, fp32 / int64 as the reference holds them (SURVEY.md 8d's per-unit figures);
+ * workspaces, partial sums, halo and packed-weight re-reads are not counted.  uaps_account(0) stops counting;
+ * uaps_accounted_bytes() reads the tally.  Host-side bookkeeping only: nothing is launched, nothing synchronises. */
+int uaps_account(int enable);
+double uaps_accounted_bytes(void);
 /* Zero n floats of bound storage (a multiple of UAPS_BOUND_FLOATS) with agent-scope stores -- the way bounds handed to
  * uaps_call_hints::out_amax must be cleared (a plain fill may be written back over the atomically raised value). */
 int uaps_zero_bounds(float* bounds, long n, uaps_stream_t stream);

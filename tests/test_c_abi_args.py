@@ -63,6 +63,9 @@ def test_kernel_plan_names_and_statistics_tiles(L):
     assert L.uaps_conv_set_mode(1) == OK and L.uaps_conv_get_mode() == 1
     assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
     assert buf.value.decode() == "conv_s32_kernel<32>"                                   # split modes: the 32x32x16 form (bf16 / fp16 pieces)
+    assert L.uaps_conv_set_mode(2) == OK and L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 0, buf, 96) == OK
+    assert buf.value.decode() == "conv_sfwd_kernel<3, 8, 32, 32, 16>"                    # round 5: 128 channels on 32 x 32 maps with fp16 pieces: the 16x16x32 form
+    assert L.uaps_conv_set_mode(1) == OK
     assert L.uaps_conv_fwd_variant(32, 128, 128, 32, 32, 3, 1 << 28, buf, 96) == OK
     assert buf.value.decode() == "conv_fwd_kernel<3, 8, 32, 32, 8, 4, 1>"                # cfg bit 28: exact kernels for this call
     assert L.uaps_conv_set_mode(7) == EINVAL

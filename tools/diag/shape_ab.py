@@ -9,7 +9,7 @@ from uaps_amd import conv as C, bounds
 from tools.bench_conv import timeit
 
 LAYERS = [("32->32@128", 32, 32, 128), ("64->32@128", 64, 32, 128), ("64->64@64", 64, 64, 64), ("128->64@64", 128, 64, 64),
-          ("128->128@32", 128, 128, 32), ("256->128@32", 256, 128, 32), ("256->256@16", 256, 256, 16), ("16->32@128", 16, 32, 128)]
+          ("128->128@32", 128, 128, 32), ("256->128@32", 256, 128, 32), ("256->256@16", 256, 256, 16), ("128->256@16", 128, 256, 16), ("256->128@16", 256, 128, 16), ("128->256@32", 128, 256, 32), ("16->32@128", 16, 32, 128)]
 VARIANTS = [("auto", 0), ("16x16x32/32", 1 << 29), ("32x32x16/32", (2 << 29) | 32), ("32x32x16/64", (2 << 29) | 64)]
 
 def main():

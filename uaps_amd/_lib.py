@@ -82,6 +82,8 @@ SIGNATURES = {
     "uaps_set_step_state": (C.c_int, [_PTR]),
     "uaps_next_call_hints": (C.c_int, [_PTR]),
     "uaps_conv_ex": (C.c_int, [_PTR]),
+    "uaps_account": (C.c_int, [C.c_int]),
+    "uaps_accounted_bytes": (C.c_double, []),
     "uaps_next_launch_events": (C.c_int, [_PTR, _PTR]),
     "uaps_zero_bounds": (C.c_int, [_PTR, C.c_long, _PTR]),
     "uaps_bn_param_bounds": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, _PTR]),

@@ -9,6 +9,7 @@
 #include <math.h>
 #include "../../include/uaps_hip.h"
 #include "philox.hpp"
+#include "hints.hpp"
 
 namespace {
 constexpr int kThreads = 256;
@@ -68,6 +69,7 @@ extern "C" int uaps_adam_step(float* const* params, const float* const* grads, f
             const int k = base + i;
             if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] <= 0) return UAPS_EINVAL;
             t.p[i] = params[k]; t.g[i] = grads[k]; t.m[i] = exp_avg[k]; t.v[i] = exp_avg_sq[k]; t.n[i] = numel[k];
+            uaps::account_bytes(28.0 * numel[k]);          // p, g, m, v read; p, m, v written
             if (numel[k] > most) most = numel[k];
         }
         long bx = (most / 4 + kThreads - 1) / kThreads;

@@ -268,8 +268,16 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
     p->g1 = p->split && big_1x1 && p->vec && p->CoutP % 64 == 0 && !(cfg & 0x7fffffff);
     const int sel = (cfg >> 29) & 3, bn_req = cfg & 0xff;
     p->sck = ks == 1 ? 32 : (Cin <= 8 ? 8 : 16);
-    p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 512) ? 32 : 16;
+    // 32 output channels per workgroup from 256 workgroups on (round 5, profiles/r05_mfma_shape_ab.txt: 256 -> 256 @ 16 x 16, B = 32:
+    // 42.4 against 46.1 us with 16, 128 -> 256: 23.6 against 25.3; with 128 workgroups -- 256 -> 128 -- 16 stays faster, 34.0 against 40.4)
+    p->sbn = (p->CoutP % 32 == 0 && tiles * (p->CoutP / 32) >= 256) ? 32 : 16;
     p->s32 = p->split && ks == 3 && p->tw == 32 && p->CoutP % 32 == 0 && sel != 1;
+    // round 5 (profiles/r05_mfma_shape_ab.txt, same per-wave tile of 64 pixels x 32 channels): on maps of <= 32 x 32 pixels with >= 128
+    // contraction channels and 128 output channels the 16x16x32 form with 16-channel chunks is 3-5 % faster than either 32x32x16 form
+    // (128 -> 128: 33.1 against 34.3 us, 256 -> 128: 59.2 against 62.4 us at B = 32); everywhere else it loses 4-15 %
+    // (measured in the fp16-split arithmetic only: mode 2)
+    if (p->s32 && conv_mode() == 2 && sel == 0 && !bn_req && p->dil == 1 && (long)H * W <= 1024 && Cin >= 128 && p->CoutP == 128 &&
+        tiles * (p->CoutP / 32) >= 512) { p->s32 = false; p->sbn = 32; p->sck = 16; }
     if (p->s32) {
         p->sck = 8;
         p->sbn = (p->CoutP % 64 == 0 && tiles * (p->CoutP / 64) >= 512) ? 64 : 32;
@@ -327,6 +335,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         if (plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p0)) return UAPS_EINVAL;
         if (p0.g1 != (p.g1 && p.split && !x2 && !y2 && !xf)) return UAPS_ERANGE;
     }
+    uaps::account_bytes(4.0 * B * H * W * ((double)Cin + Cout));      // every input and output element once
     ConvFwdArgs a{};
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats;
@@ -408,6 +417,7 @@ extern "C" int uaps_conv_pack_weights(const float* w, int Cout, int Cin, int ks,
     if (((uintptr_t)wf | (uintptr_t)wb) % 16) return UAPS_EINVAL;
     const PackDesc q = make_pack_desc(w, wf, wb, Cout, Cin, ks);
     const long n = conv_pack_elems(q);
+    uaps::account_bytes(4.0 * ((double)Cout * Cin * ks * ks + (double)n));      // the weight once, every packed layout once
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(conv_weight_scale_kernel, dim3(kH16Parts), dim3(256), 0, (hipStream_t)stream, q);
     hipLaunchKernelGGL(conv_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q);
@@ -428,6 +438,7 @@ extern "C" int uaps_conv_pack_weights_batch(const float* const* w, float* const*
             if (((uintptr_t)wf[k] | (uintptr_t)wb[k]) % 16) return UAPS_EINVAL;
             pb.d[i] = make_pack_desc(w[k], wf[k], wb[k], Cout[k], Cin[k], ks[k]);
             const long e = conv_pack_elems(pb.d[i]);
+            uaps::account_bytes(4.0 * ((double)Cout[k] * Cin[k] * ks[k] * ks[k] + (double)e));
             if (e > most) most = e;
         }
         const int bx = (int)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);

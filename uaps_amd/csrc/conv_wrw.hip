@@ -179,6 +179,8 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     if ((p.split || p.small) && !vec16) return UAPS_ERANGE;      // the split kernels stream 16-byte pieces (W % 4 == 0 is part of the plan; pass cfg bit 28 for odd pointers)
     if (p.dil != 1 && (ks != 3 || (p.dil != 2 && p.dil != 4))) return UAPS_ERANGE;
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
+    // dy and x once each (+ the raw output read and the true dy written through when the call carries a pending BatchNorm transform)
+    uaps::account_bytes(4.0 * B * H * W * ((double)Cin + Cout + (hints.dyt_y ? 2.0 * Cout : 0.0)));
     ConvWrwArgs a{};
     a.dout = dy; a.in = x; a.in2 = x2; a.Csplit = Csplit; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;

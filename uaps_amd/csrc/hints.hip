@@ -1,6 +1,7 @@
 #include "hints.hpp"
 #include <string.h>
 #include <stddef.h>
+#include <atomic>
 
 namespace {
 thread_local uaps_call_hints g_hints;
@@ -23,6 +24,22 @@ uaps_call_hints take_hints() {
 LaunchEvents& launch_events() { return g_launch; }
 unsigned* error_word() { const int d = current_device(); return d >= 0 ? g_error_word[d] : nullptr; }
 }  // namespace uaps
+
+namespace {
+std::atomic<bool> g_acct_on{false};
+std::atomic<unsigned long long> g_acct_bytes{0};
+}
+namespace uaps {
+void account_bytes(double bytes) {
+    if (g_acct_on.load(std::memory_order_relaxed) && bytes > 0.0) g_acct_bytes.fetch_add((unsigned long long)bytes, std::memory_order_relaxed);
+}
+}  // namespace uaps
+extern "C" int uaps_account(int enable) {                 // 1: reset the tally and count from here; 0: stop counting (the tally stays readable)
+    if (enable) g_acct_bytes.store(0);
+    g_acct_on.store(enable != 0);
+    return UAPS_OK;
+}
+extern "C" double uaps_accounted_bytes(void) { return (double)g_acct_bytes.load(); }
 
 extern "C" int uaps_set_error_word(unsigned* device_word) {
     if ((uintptr_t)device_word % 4) return UAPS_EINVAL;

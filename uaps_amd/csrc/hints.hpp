@@ -15,6 +15,10 @@ uaps_call_hints take_hints();
 // of two extra packets on the stream.
 // uaps_set_error_word: the sticky device error word the fp16-split kernels OR UAPS_ERR_* into, or nullptr
 unsigned* error_word();
+// uaps_account (include/uaps_hip.h): while switched on, every kernel entry point adds the ALGORITHMIC bytes of its launch -- each
+// operand tensor read once, each result written once, fp32 / int64 as the reference holds them; workspaces, packed copies' re-reads,
+// halo re-reads and partial sums are not counted -- to a process-wide tally (bench.py: roofline.step_algorithmic_bytes)
+void account_bytes(double bytes);
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; bool armed = false, used = false; };
 LaunchEvents& launch_events();
 #define UAPS_LAUNCH_MAIN(kernel, grid, block, shmem, stream, ...)                                                            \

@@ -128,6 +128,8 @@ extern "C" int uaps_pairloss_fwd(const float* const* lab_logits, const float* co
     a.ce_coef = 0.5f / D; a.dice_coef = 0.5f / D; a.cw1 = cw1; a.cw2 = cw2; a.eps = eps; a.labels = labels; a.pseudo = pseudo;
     a.var = var; a.sscal = sup_scalars; a.uscal = unsup_scalars; a.sums = sums_out; a.partials = (float*)ws; a.cfg = cfg;
     a.stream = (hipStream_t)stream;
+    // per pixel, labelled 4DC + 8 (labels), unlabelled 4DC + 8 (pseudo-label written) + 4D when the variance maps are stored
+    uaps::account_bytes((double)B * H * W * (2.0 * (4.0 * D * C + 8.0) + (var ? 4.0 * D : 0.0)));
     return launch_pair_fwd(a);
 }
 
@@ -155,5 +157,6 @@ extern "C" int uaps_pairloss_bwd(const float* const* lab_logits, const float* co
     a.sscal = const_cast<float*>(sup_scalars); a.uscal = const_cast<float*>(unsup_scalars);
     a.Nloss = n_pixels_loss > 0 ? n_pixels_loss : (long)B * H * W; a.gscale = gscale; a.cfg = cfg; a.stream = (hipStream_t)stream;
     a.amax_out = amax_out;
+    uaps::account_bytes((double)B * H * W * 2.0 * (8.0 * D * C + 8.0));      // both branches: logits + labels read, gradients written
     return launch_pair_bwd(a);
 }

@@ -543,6 +543,8 @@ static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_i
     if (rc) return rc;
     if (!gamma || !beta || !save_mean || !save_invstd || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
     if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    // y read and the activated tensor written (+ the residual read; + one more read of y when the statistics pass runs here)
+    uaps::account_bytes(4.0 * B * C * H * W * (2.0 + (given_partials ? 0.0 : 1.0) + (hints.residual ? 1.0 : 0.0)));
     const long HW = (long)H * W;
     if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -645,6 +647,7 @@ static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, co
     if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
     const long HW = (long)H * W;
     if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    uaps::account_bytes(4.0 * B * C * HW * 5.0);      // the reductions need all of (d, y) before dx can start: 2 + 2 reads, 1 write
     hipStream_t s = (hipStream_t)stream;
     const BnWs w = carve(ws, B, C, HW);
     const int nch = nchunks_for(HW), Bg = B / groups;
@@ -704,6 +707,7 @@ extern "C" int uaps_bn_act_bwd_prepare(const float* dout, const float* y, const 
     if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
     const long HW = (long)H * W;
     if (ws_bytes < bn_ws_bytes(B, C, HW)) return UAPS_EWORKSPACE;
+    uaps::account_bytes(4.0 * B * C * HW * 2.0);
     hipStream_t s = (hipStream_t)stream;
     const BnWs w = carve(ws, B, C, HW);
     const int nch = nchunks_for(HW), Bg = B / groups;
@@ -727,6 +731,7 @@ extern "C" int uaps_bn_act_bwd_apply(const float* dout, const float* y, const fl
     if (rc) return rc;
     if (!y || !coef || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
     const long HW = (long)H * W;
+    uaps::account_bytes(4.0 * B * C * HW * 3.0);
     const dim3 grid(nchunks_for(HW), B * C);
     if ((HW % 4 == 0) && al16(y) && al16(dout) && al16(dy))
         hipLaunchKernelGGL(bn_bwd_dx_coef_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, dout, y, dy, C, HW, coef, slope, B / groups, amax_out);

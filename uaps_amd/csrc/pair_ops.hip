@@ -342,6 +342,7 @@ inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 extern "C" int uaps_cat2(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
     float* amax = uaps::take_hints().out_amax;
     if (!a || !b || !out || n <= 0) return UAPS_EINVAL;
+    uaps::account_bytes(16.0 * n);                        // both halves read, the joined batch written
     const long n4 = (al16p(a) && al16p(b) && al16p(out) && n % 4 == 0) ? n / 4 : 0;
     hipLaunchKernelGGL(cat2_amax_kernel, dim3(grid_for(n4 > 0 ? 2 * n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, a, b, out, n4, n, amax);
     return (int)hipGetLastError();

@@ -6,6 +6,7 @@
 #include "../../include/uaps_hip.h"
 #include "rn_math.hpp"
 #include "philox.hpp"
+#include "hints.hpp"
 using uaps::mul_rn; using uaps::add_rn; using uaps::U4; using uaps::philox4x32_10; using uaps::u01;
 
 namespace {
@@ -518,6 +519,7 @@ extern "C" int uaps_feat_dropout_fwd(const float* x, float* y, int B, int C, int
     const long HW = (long)H * W;
     uint32_t* maxkey = (uint32_t*)ws;
     float* att = (float*)((char*)ws + (((size_t)B * 4 + 255) / 256) * 256);
+    uaps::account_bytes(4.0 * B * HW * (C + 1.0));       // x once, the attention map once
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, maxkey, (long)B);      // a kernel, not hipMemsetAsync: see zero_words_kernel
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -597,6 +599,11 @@ extern "C" int uaps_fanout_perturbed(const float* f, float* const* out, const in
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
     a.st = (const uint32_t*)uaps_get_step_state();
     a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4;
+    {   // f once, every perturbed copy once (+ the FeatureDropout keep masks, one byte per pixel)
+        double by = 4.0 * B * C * HW * (1.0 + n);
+        for (int k = 0; k < n; ++k) if (mode[k] == 3) by += (double)B * HW;
+        uaps::account_bytes(by);
+    }
     hipLaunchKernelGGL(fanout_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, (const float4*)f, a);
     return (int)hipGetLastError();
 }
@@ -636,6 +643,11 @@ extern "C" int uaps_fanin_perturbed(const float* const* g, const int* mode, cons
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
     a.st = (const uint32_t*)uaps_get_step_state();
     a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4; a.W = W;
+    {   // every incoming gradient once (mode 4: the pooled gradient and its index bytes), the keep masks, the sum once
+        double by = 4.0 * B * C * HW;
+        for (int k = 0; k < n; ++k) by += mode[k] == 4 ? 5.0 * B * C * HW / 4 : 4.0 * B * C * HW + (mode[k] == 3 ? (double)B * HW : 0.0);
+        uaps::account_bytes(by);
+    }
     hipLaunchKernelGGL(fanin_perturbed_kernel, dim3(grid_for((long)B * a.chw4)), dim3(kThreads), 0, (hipStream_t)stream, a, (float4*)out);
     return (int)hipGetLastError();
 }
@@ -647,6 +659,7 @@ extern "C" int uaps_maxpool2x2_fwd(const float* x, int B, int C, int H, int W, f
     if (!x || !out || !idx || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (H % 2 || W % 8 || !al16(x) || !al16(out) || (reinterpret_cast<uintptr_t>(idx) & 3)) return UAPS_EINVAL;
     const long planes = (long)B * C;
+    uaps::account_bytes((double)planes * H * W * (4.0 + 5.0 / 4));      // x once, the pooled map and its index bytes once
     hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(grid_for(planes * (H / 2) * (W / 8))), dim3(kThreads), 0, (hipStream_t)stream, x, out,
                        idx, planes, H, W);
     return (int)hipGetLastError();
@@ -658,6 +671,7 @@ extern "C" int uaps_seg_confusion(const float* logits, const int64_t* labels, in
     if (C < 1 || C > UAPS_MAX_CLASSES) return UAPS_ERANGE;
     hipStream_t s = (hipStream_t)stream;
     const long HW = (long)H * W, N = (long)B * HW;
+    uaps::account_bytes((double)N * (4.0 * C + 8.0));
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((2 * C * C + 255) / 256)), dim3(256), 0, s, reinterpret_cast<uint32_t*>(counts), (long)2 * C * C);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

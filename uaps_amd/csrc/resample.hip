@@ -262,6 +262,7 @@ extern "C" int uaps_up_cat_fwd(const float* skip, const float* low, float* out, 
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * (Cs + Cl) * H * W;
+    uaps::account_bytes(4.0 * ((double)B * Cl * h * w + 2.0 * B * Cs * H * W + (double)B * Cl * H * W));      // low once, (skip copied,) the 4x larger output once
     if (amax_out && !(Cs == 0 && W % 4 == 0 && al16(out))) return UAPS_ERANGE;      // only the plain up-sampling form tracks max|out|
     if (Cs == 0 && W % 4 == 0 && al16(out)) {            // plain up-sampling: the LDS-tiled kernel
         const bool wide = W >= 64, tall = wide && H >= 64;      // 64 x 64 output tiles (4 row groups per thread) where the map holds one
@@ -287,6 +288,7 @@ extern "C" int uaps_up_cat_bwd(const float* dout, float* dskip, float* dlow, int
     const int H = 2 * h, W = 2 * w;
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     hipStream_t s = (hipStream_t)stream;
+    uaps::account_bytes(4.0 * ((double)B * Cl * H * W + (double)B * Cl * h * w + (dskip ? 2.0 * B * Cs * H * W : 0.0)));
     if (dskip && Cs > 0) {
         const long HW = (long)H * W;
         if (HW % 4 == 0 && al16(dout) && al16(dskip))

@@ -23,6 +23,17 @@ def predict(model: torch.nn.Module, images: torch.Tensor) -> Tuple[torch.Tensor,
 
 
 @torch.no_grad()
+def predict_main(model: torch.nn.Module, images: torch.Tensor) -> torch.Tensor:
+    """Main-head arg-max mask with ONLY the encoder and the main decoder run (the paper's "main decoder only" inference row,
+    fig_data/decoder-effect.jpg: its time does not depend on the number of auxiliary decoders); the same mask as predict()[0].
+    Models without a `forward_main` (the ResNet variant) run every head."""
+    model.eval()
+    fm = getattr(model, "forward_main", None)
+    logits = fm(images) if fm is not None else predict(model, images)[1][0]
+    return torch.argmax(logits, dim=1)
+
+
+@torch.no_grad()
 def ensemble_from_heads(heads) -> torch.Tensor:
     """Arg-max of the mean softmax of the given head logits: `uaps_unsup_fwd` (csrc/loss_kernels.hpp) with uniform mixing weights --
     its pseudo-label IS argmax_c sum_k w_k softmax(z_k)_c (UAPS_train.py:251-255) -- one pass over the D logit tensors instead of D

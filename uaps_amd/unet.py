@@ -236,6 +236,19 @@ class UNet_UAPS(nn.Module):
             return [perturb.Dropout(f) for f in feats]
         return [perturb.FeatureDropout(f, groups=groups) for f in feats]
 
+    def forward_main(self, x):
+        """Main-head logits only: the shared encoder and the main decoder on clean features (UAPS_unet.py:224-226), the auxiliary
+        decoders not run -- the evaluation path's cost when only the mask is wanted (notebook cells 11-13 use `output` alone)."""
+        if x.is_cuda:
+            if self._conv_weights is None:
+                self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
+            conv.pack_all(self._conv_weights)
+            if self.training:
+                if self._bns is None:
+                    self._bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+                bounds.refresh(self._bns)
+        return self.main_decoder(self.encoder(x))
+
     def forward_pair(self, x_a, x_b, perturbations=None):
         """The two forwards of a training step (UAPS_train.py:177 labelled, :185 unlabelled) as ONE pass over the
         concatenated batch: every convolution runs once on 2B images, while everything the reference computes per
