@@ -476,6 +476,14 @@ int uaps_conv_bwd_weight_reduce(const void* workspace, float* dw, float* dbias, 
  * reads torch.cat([skip, upsampled], dim=1) (UAPS_unet.py:84-85).  x1 [B,C1,H,W], x2 [B,C2,H,W], weights packed for
  * Cin = C1 + C2 as usual; C1 must be a multiple of 16.  The input gradient comes back as two tensors, and the
  * weight gradient reads the two inputs; uaps_conv_bwd_weight_reduce(.., Cin = C1 + C2, ..) finishes it. */
+/* cfg bit UAPS_CONV_X2_UP2 on uaps_conv_fwd_cat / uaps_conv_bwd_weight_partial_cat (round 5): x2 is the LOW-resolution tensor
+ * [B, C2, H/2, W/2] of an UpBlock and is bilinearly up-sampled x2 (align_corners = True, ATen's arithmetic: bit-identical to
+ * uaps_up_cat_fwd's output) while the kernel stages it -- `self.up(x1)` of UAPS_unet.py:74-75, 83 is never materialised.  bound[1]
+ * (forward) / bound[2] (weight gradient) is the bound of the low tensor (interpolation is convex).  Built for the full-width-row
+ * kernels of up4's first convolution (16 + 16 -> 16 channels, W == 256, H % 16 == 0, fp16-split arithmetic with every operand
+ * bounded); anything else returns UAPS_ENOFORM with nothing launched: call uaps_up_cat_fwd and the plain entry point.  The input
+ * gradient (uaps_conv_bwd_data_cat) still yields the gradient of the up-sampled tensor; uaps_up_cat_bwd folds it to [B,C2,H/2,W/2]. */
+#define UAPS_CONV_X2_UP2 (1 << 10)
 int uaps_conv_fwd_cat(const float* x1, int C1, const float* x2, int C2, const float* wf, const float* bias, float* y,
                       void* stats_or_null, int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
 int uaps_conv_bwd_data_cat(const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2, int B, int Cout,

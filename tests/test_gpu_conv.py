@@ -468,3 +468,55 @@ def test_the_explicit_conv_call_equals_the_hinted_entry_points():
     assert float((y2 - y_ref).abs().max()) <= 2e-5 * float(y_ref.abs().max())
     c.struct_size = 8
     assert L.uaps_conv_ex(C.byref(c)) == -1 and L.uaps_conv_ex(None) == -1
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_up_sampling_in_the_staging_equals_the_materialised_operand(lazy):
+    """conv2d_cat(skip, low, w, up2=True) -- up4's first convolution reading the 1x1 projection's LOW-resolution output and
+    up-sampling it x2 while staging (UAPS_unet.py:74-75, 83-85; csrc/up2_staging.hpp) -- against the same convolution on the
+    materialised nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) output with the same operand bound: forward,
+    BatchNorm partial sums and every gradient bit for bit (the staged values are identical, the kernels' summation orders too);
+    the up-sampled operand itself against torch.  lazy: the weight gradient also applies a pending BatchNorm transform (the
+    form the training step runs)."""
+    import torch.nn as nn
+    from uaps_amd import bounds, conv, fused, lazybn
+    if conv.get_mode() != "h16":
+        pytest.skip("the up-sampling forms exist in the fp16-split arithmetic only")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    B, H, W = 4, 32, 256
+    skip0 = torch.randn(B, 16, H, W, device=dev)
+    low0 = torch.randn(B, 16, H // 2, W // 2, device=dev) * 1.7
+    w1 = (torch.randn(16, 32, 3, 3, device=dev) / 10)
+    w2 = (torch.randn(16, 16, 3, 3, device=dev) / 10)
+    bn = nn.BatchNorm2d(16).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    bounds.refresh([bn])
+    g = torch.randn(B, 16, H, W, device=dev)
+    assert conv.up2_eligible(bounds.put(skip0.clone(), bounds.from_value(skip0.abs().max())), w1)
+
+    def run(fusedp):
+        skip = bounds.put(skip0.clone().requires_grad_(True), bounds.from_value(skip0.abs().max()))
+        low = low0.clone().requires_grad_(True)
+        lb = bounds.from_value(low0.abs().max())
+        wa, wb_ = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        import contextlib
+        with (lazybn.scope() if lazy else contextlib.nullcontext()), fused.stat_groups(2):
+            if fusedp:
+                y, st = conv.conv2d_cat(skip, bounds.put(low, lb), wa, None, True, up2=True)
+            else:
+                up = fused.upsample2x(low)
+                y, st = conv.conv2d_cat(skip, bounds.put(up, lb), wa, None, True)       # the same bound: the same power-of-two scale
+            z = fused.bn_act_conv(y, st, None, bn, 0.01, wb_, None)
+            z.backward(bounds.put(g.clone(), bounds.from_value(g.abs().max())))
+        return [y.detach(), st.detach(), z.detach(), skip.grad, low.grad, wa.grad, wb_.grad]
+
+    a, b = run(True), run(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), (i, float((u - v).abs().max()))
+    up_t = torch.nn.functional.interpolate(low0.cpu(), scale_factor=2, mode="bilinear", align_corners=True)
+    torch.testing.assert_close(fused.upsample2x(low0).cpu(), up_t, rtol=1e-5, atol=2e-6)
+    # without a bound on the low tensor the kernel refuses (UAPS_ENOFORM -> an error, not a silent fallback)
+    with pytest.raises(Exception):
+        conv.conv2d_cat(bounds.put(skip0.clone(), bounds.from_value(skip0.abs().max())), low0.clone(), w1, None, up2=True)

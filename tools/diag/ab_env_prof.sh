@@ -9,7 +9,7 @@ cd /tmp
 for arm in A B; do
   if [ $arm = A ]; then export $KV; else unset ${KV%%=*}; fi
   rm -rf $R/gpurun_out/abprof_$arm
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abprof_$arm -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --analysis-steps 0 --exact-steps 0 --single-stream --no-graph --no-cpu-baseline --other-configs 0 > $R/gpurun_out/abprof_$arm.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/abprof_$arm -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --analysis-steps 0 --exact-steps 0 --single-stream --no-graph --no-cpu-baseline --no-inference --other-configs 0 > $R/gpurun_out/abprof_$arm.log 2>&1
   find $R/gpurun_out/abprof_$arm -name "*kernel_trace.csv" -delete
 done
 cd $R

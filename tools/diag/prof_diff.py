@@ -6,7 +6,7 @@ import csv, re, sys
 def load(p):
     d = {}
     for r in csv.DictReader(open(p)):
-        n = re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("(anonymous namespace)::", "").replace("uaps::", "")
+        n = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("uaps::", "")
         c, t = d.get(n, (0, 0.0))
         d[n] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
     return d

@@ -9,6 +9,7 @@ fallback on this path: CPU tensors are refused.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -42,6 +43,7 @@ register_optimizer_step_post_hook(invalidate_packed_weights)
 KERNEL_EVENTS: Optional[Dict[str, list]] = None
 EVENT_FILTER: Optional[set] = None
 _variant_cache: Dict[tuple, str] = {}
+ENOFORM = -4                      # UAPS_ENOFORM (include/uaps_hip.h)
 
 
 def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: int, cfg: int = 0) -> str:
@@ -68,9 +70,13 @@ def kernel_variant(kind: str, B: int, Cin: int, Cout: int, H: int, W: int, ks: i
 
 
 class _timed:
-    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False, stats=False, dt=False):
+    def __init__(self, kind, B, Cin, Cout, H, W, ks, cfg, h16=False, stats=False, dt=False, name=None):
         self.on = False
-        if KERNEL_EVENTS is not None:
+        if KERNEL_EVENTS is not None and name is not None:      # the caller knows the instantiation (the up-sampling forms)
+            self.name = name.replace("_kernel", "_dt_kernel", 1) if dt else name
+            self.on = EVENT_FILTER is None or self.name in EVENT_FILTER
+            self.flops = 2.0 * B * H * W * Cin * Cout * ks * ks
+        elif KERNEL_EVENTS is not None:
             self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg)
             if stats and self.name.startswith("conv_small"):      # the exact-N kernels have no statistics epilogue: the matrix kernel ran
                 self.name = kernel_variant(kind, B, Cin, Cout, H, W, ks, cfg | (1 << 28))
@@ -270,6 +276,45 @@ def plan_cfg(ks: int, cfg: int, plain: bool, *tensors) -> int:
     return cfg
 
 
+# ---- the up-sampled half of an UpBlock's concatenation formed in the consuming kernels' staging (round 5) ----------------------
+X2_UP2 = 1 << 10                  # UAPS_CONV_X2_UP2 (include/uaps_hip.h)
+_FUSED_UP2 = os.environ.get("UAPS_FUSED_UP2", "1") != "0"
+_amax_request = False             # the next forward convolution of this thread's model code raises a bound to max|its output|
+_last_out_amax = None
+
+
+def request_out_amax() -> None:
+    """The next conv2d / bn_act_conv forward tracks max|output| (uaps_call_hints::out_amax; the fp32-instruction kernels have it):
+    the 1x1 projection in front of an up-sampling has no BatchNorm behind it to bound its output.  Fetch it with take_out_amax()."""
+    global _amax_request, _last_out_amax
+    _amax_request, _last_out_amax = True, None
+
+
+def _claim_amax(dev):
+    global _amax_request
+    if not _amax_request:
+        return None
+    _amax_request = False
+    return bounds.new_amax(dev) if bounds.enabled() else None
+
+
+def take_out_amax():
+    global _amax_request, _last_out_amax
+    am, _last_out_amax, _amax_request = _last_out_amax, None, False
+    return am
+
+
+def up2_eligible(skip: torch.Tensor, weight: torch.Tensor) -> bool:
+    """May conv2d_cat(skip, low, weight, up2=True) run (csrc/conv_fwd.hip / conv_wrw.hip: the UP2 forms)?  up4's first convolution
+    at the metric's size: 16 + 16 -> <= 16 channels, 3x3, a 256-wide map with H % 16 == 0, fp16-split arithmetic, bounded skip."""
+    if not (_FUSED_UP2 and skip.is_cuda and get_mode() == "h16" and bounds.get(skip) is not None):
+        return False
+    Cout, Cin, ks, _ = weight.shape
+    B, C1, H, W = skip.shape
+    return (ks == 3 and Cin == 32 and C1 == 16 and Cout <= 16 and W == 256 and H % 16 == 0 and skip.dtype == torch.float32
+            and not (_lib.lib().uaps_conv_get_tuning() & (1 | 2 | 8 | 128 | 256)))
+
+
 def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, ks: int, cfg: int = 0,
                  want_stats: bool = False, xb=None, stat_shift=None):
     """y = conv(x); with want_stats also the per-tile (sum, sum of squares) of y as float2 [Cout][B][parts_per_image]
@@ -282,16 +327,25 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     if want_stats:
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
-    with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb), want_stats):
-        if xb is not None or (want_stats and stat_shift is not None):
-            _lib.hints((xb,), None, stat_shift if want_stats else None)
-        if want_stats:
-            rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
-                                       _lib.current_stream(x.device))
-        else:
-            rc = L.uaps_conv_fwd(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
-                                 _lib.current_stream(x.device))
+    global _last_out_amax
+    am = _claim_amax(x.device)
+    for attempt in range(2):
+        with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb), want_stats) as tm:
+            if xb is not None or (want_stats and stat_shift is not None) or am is not None:
+                _lib.hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
+            if want_stats:
+                rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
+                                           _lib.current_stream(x.device))
+            else:
+                rc = L.uaps_conv_fwd(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
+                                     _lib.current_stream(x.device))
+            if rc == ENOFORM:
+                tm.on = False
+        if rc != ENOFORM or am is None:
+            break
+        am = None                                     # this layer's kernel cannot track max|y|: run it without (the caller falls back)
     _lib.check(rc, "uaps_conv_fwd")
+    _last_out_amax = am
     return (y, stats, ppi) if want_stats else y
 
 
@@ -438,14 +492,17 @@ class _Conv2dCat(torch.autograd.Function):
     UAPS_unet.py:84-85): the kernels read the two tensors, the input gradient comes back as two tensors."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, want_stats, stat_shift=None):
+    def forward(ctx, x1, x2, weight, bias, want_stats, stat_shift=None, up2=False):
+        """up2: x2 is the LOW-resolution tensor [B, C2, H/2, W/2]; the kernels up-sample it x2 (bilinear, align_corners) while they
+        stage it (UAPS_CONV_X2_UP2) -- `self.up(x1)` of UAPS_unet.py:74-75 is never materialised.  Only where up2_eligible()."""
         _lib.require_device(x1, "conv2d_cat")
         ctx.set_materialize_grads(False)
         x1, x2 = x1.contiguous(), x2.contiguous()
         B, C1, H, W = x1.shape
         C2 = x2.shape[1]
         Cout, Cin, ks, _ = weight.shape
-        if x2.shape != (B, C2, H, W) or C1 + C2 != Cin:
+        ctx.up2 = bool(up2)
+        if x2.shape != ((B, C2, H // 2, W // 2) if up2 else (B, C2, H, W)) or C1 + C2 != Cin:
             raise ValueError(f"conv2d_cat: inputs {tuple(x1.shape)} + {tuple(x2.shape)} do not concatenate to {Cin} channels")
         if C1 % 16:
             raise ValueError("conv2d_cat: the first tensor must have a multiple of 16 channels")
@@ -458,12 +515,13 @@ class _Conv2dCat(torch.autograd.Function):
             stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg), 2), dtype=torch.float32, device=dev)
         b1, b2 = bounds.get(x1), bounds.get(x2)
         ctx.xb = (b1, b2)
-        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(b1, b2)):
+        ucfg = cfg | (X2_UP2 if up2 else 0)
+        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(b1, b2), name="conv_hr16_up_kernel" if up2 else None):
             if (b1 is not None and b2 is not None) or (want_stats and stat_shift is not None):
                 _lib.hints((b1, b2) if (b1 is not None and b2 is not None) else (), None, stat_shift if want_stats else None)
             rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
                                               bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                              stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, cfg, _lib.current_stream(dev))
+                                              stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, ucfg, _lib.current_stream(dev))
         _lib.check(rc, "uaps_conv_fwd_cat")
         ctx.save_for_backward(x1, x2, wb)
         ctx.meta = (C1, C2, Cout, ks, bias is not None, cfg)
@@ -476,9 +534,12 @@ class _Conv2dCat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *_unused):
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x1, x2, wb = ctx.saved_tensors
         C1, C2, Cout, ks, has_bias, cfg = ctx.meta
+        up2 = ctx.up2
+        ucfg = cfg | (X2_UP2 if up2 else 0)
+        x2w = x2                               # what the weight gradient reads as the second tensor
         lz = lazybn.take(dy)                   # dy is d(activation) behind the BatchNorm that follows: the weight gradient runs first
         dyb = bounds.get(dy)
         b1, b2 = ctx.xb
@@ -490,6 +551,12 @@ class _Conv2dCat(torch.autograd.Function):
         dx1 = dx2 = dw = db = None
         want_db = has_bias and ctx.needs_input_grad[3]
         want_w = ctx.needs_input_grad[2] or want_db
+        if up2 and want_w and (b1 is None or b2 is None or (lz is None and dyb is None)):
+            # an operand without a bound: the up-sampling form (fp16-split only) cannot run -- materialise the operand for this call
+            x2w = torch.empty((B, C2, H, W), dtype=torch.float32, device=dev)
+            with _lib.device_guard(dev):
+                _lib.check(L.uaps_up_cat_fwd(x2.data_ptr(), x2.data_ptr(), x2w.data_ptr(), B, 0, C2, H // 2, W // 2, st), "uaps_up_cat_fwd")
+            ucfg = cfg
 
         def weight_gradient(dy, dyb, lz):
             """(dw, db, dy): with a pending transform the kernel writes the true dy through (None: it has no such form here)"""
@@ -499,13 +566,14 @@ class _Conv2dCat(torch.autograd.Function):
             dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
             db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
             out = torch.empty_like(dy) if lz is not None else None
-            with _timed("wrw", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb, b1, b2), dt=lz is not None) as tm:
+            with _timed("wrw", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb, b1, b2), dt=lz is not None,
+                        name="conv_hrwrw_up_kernel" if ucfg != cfg else None) as tm:
                 if lz is not None:
                     _lib.hints((dyb, b1, b2), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
                 elif dyb is not None and b1 is not None and b2 is not None:
                     _lib.hints((dyb, b1, b2))
-                rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2.data_ptr(), C2, int(want_db), B, Cout,
-                                                        H, W, ks, cfg, ws.data_ptr(), ws.numel(), st)
+                rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2w.data_ptr(), C2, int(want_db), B, Cout,
+                                                        H, W, ks, ucfg, ws.data_ptr(), ws.numel(), st)
                 if lz is not None and rc == lazybn.ENOFORM:
                     tm.on = False
             if lz is not None and rc == lazybn.ENOFORM:
@@ -529,7 +597,7 @@ class _Conv2dCat(torch.autograd.Function):
                 dyb = bounds.get(dy)
             if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
                 dx1 = torch.empty_like(x1)
-                dx2 = torch.empty_like(x2)
+                dx2 = torch.empty((B, C2, H, W), dtype=torch.float32, device=dev) if up2 else torch.empty_like(x2)
                 with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb)):
                     if dyb is not None:
                         _lib.hints((dyb,))
@@ -538,14 +606,20 @@ class _Conv2dCat(torch.autograd.Function):
                 _lib.check(rc, "uaps_conv_bwd_data_cat")
             if want_w and not done_w:
                 dw, db, _ = weight_gradient(dy, dyb, None)
-        return dx1, dx2, dw, db, None, None
+            if up2 and dx2 is not None:               # the gradient of the up-sampled tensor folds to the low-resolution one (uaps_up_cat_bwd)
+                dlow = torch.empty_like(x2)
+                rc = L.uaps_up_cat_bwd(dx2.data_ptr(), None, dlow.data_ptr(), B, 0, C2, H // 2, W // 2, st)
+                _lib.check(rc, "uaps_up_cat_bwd")
+                dx2 = dlow
+        return dx1, dx2, dw, db, None, None, None
 
 
 def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               with_stats: bool = False, stat_shift=None):
+               with_stats: bool = False, stat_shift=None, up2: bool = False):
     """F.conv2d(torch.cat([x1, x2], 1), weight, bias, padding=k//2) reading the two tensors in place (stat_shift: see
-    conv2d_with_stats)."""
-    res = _Conv2dCat.apply(x1, x2, weight, bias, with_stats, stat_shift)
+    conv2d_with_stats).  up2: x2 is [B, C2, H/2, W/2] and stands for nn.Upsample(scale_factor=2, mode='bilinear',
+    align_corners=True)(x2), formed in the kernels' staging (only where up2_eligible(x1, weight) and x2 carries a bound)."""
+    res = _Conv2dCat.apply(x1, x2, weight, bias, with_stats, stat_shift, up2)
     return _mark(res, stat_shift is not None, weight) if with_stats else res
 
 

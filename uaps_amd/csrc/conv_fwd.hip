@@ -148,6 +148,17 @@ int launch_hr16(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// 16 + 16 -> 16 channels, the second 16 up-sampled x2 from a low-resolution tensor while staging (conv_hr16_up_kernel; W == 256)
+int launch_hr16_up(ConvFwdArgs a, hipStream_t s) {
+    const long nruns = (long)a.B * (a.H / 16);
+    if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
+    const int h = a.H / 2, w = a.W / 2;
+    a.up_rh = (float)(h - 1) / (float)(a.H - 1); a.up_rw = (float)(w - 1) / (float)(a.W - 1);      // as uaps_up_cat_fwd
+    const unsigned grid = (unsigned)(((nruns < 256 ? nruns : 256) + 7) / 8 * 8);
+    UAPS_LAUNCH_MAIN(conv_hr16_up_kernel, dim3(grid), dim3(512), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 int launch_hr16x2(ConvFwdArgs a, hipStream_t s) {
     const long nruns = (long)a.B * (a.H / 16) * (a.W / 256);
     if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
@@ -317,6 +328,10 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
                  float* y2 = nullptr, int Osplit = -1, const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
     const uaps_call_hints hints = take_hints();
     if (!x || !wp || !y) return UAPS_EINVAL;
+    // UAPS_CONV_X2_UP2: x2 is [B, Cin - Csplit, H / 2, W / 2] and is up-sampled x2 (bilinear, align_corners) while staged
+    const bool up2 = (cfg & UAPS_CONV_X2_UP2) != 0;
+    cfg &= ~UAPS_CONV_X2_UP2;
+    if (up2 && (!x2 || H % 2 || W % 2)) return UAPS_EINVAL;
     if (xf && (x2 || groups < 1 || B % groups || (uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (xf && !(xf_slope >= 0.f && xf_slope <= 1.f)) return UAPS_ERANGE;      // leaky_relu is evaluated as max(z, slope * z)
     if (Csplit < 0 || !x2) Csplit = Cin;
@@ -325,7 +340,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     FwdPlan p{};
     const int rc = plan_fwd(x, y, B, Cin, Cout, H, W, ks, cfg, &p);
     if (rc) return rc;
-    if ((x2 && (uintptr_t)x2 % 16) || (y2 && (uintptr_t)y2 % 16)) p.vec = false;
+    if ((x2 && !up2 && (uintptr_t)x2 % 16) || (y2 && (uintptr_t)y2 % 16)) p.vec = false;
     if (!p.vec || (Csplit < Cin && Csplit % p.sck)) p.split = false;      // unaligned tensors / odd concat split: exact kernels
     if (p.dil > 1 && (!p.s32 || x2 || y2 || xf)) p.split = false;        // the dilated split form: one tensor per side, no staging BatchNorm
     // uaps_conv_fwd_stats_parts reported the GEMM-tiled plan's parts (shape alone decides it); a call that cannot run that plan
@@ -335,13 +350,19 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         if (plan_fwd(nullptr, nullptr, B, Cin, Cout, H, W, ks, cfg, &p0)) return UAPS_EINVAL;
         if (p0.g1 != (p.g1 && p.split && !x2 && !y2 && !xf)) return UAPS_ERANGE;
     }
-    uaps::account_bytes(4.0 * B * H * W * ((double)Cin + Cout));      // every input and output element once
+    uaps::account_bytes(4.0 * B * H * W * ((double)Csplit + (Cin - Csplit) * (up2 ? 0.25 : 1.0) + Cout));      // every input and output element once
     ConvFwdArgs a{};
     a.in = x; a.in2 = x2; a.Csplit = Csplit; a.out2 = y2; a.Osplit = Osplit;
     a.wp = wp; a.bias = bias; a.out = y; a.stats = stats;
     if (stats) { a.stats_mean = hints.stats_mean; a.stats_bias = hints.stats_bias; } a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CinP = p.CinP; a.CoutP = p.CoutP;
     a.xf = (const float2*)xf; a.xf_slope = xf_slope; a.xf_Bg = xf ? B / groups : B;
+    // out_amax: raised to max|y| by the fp32-instruction kernels only (the U-Net's 1x1 projections, whose output has no BatchNorm
+    // behind it to bound it); a plan that runs another kernel has no such form
+    if (hints.out_amax) {
+        if (p.split || p.small || p.g1 || (uintptr_t)hints.out_amax % 16) return UAPS_ENOFORM;
+        a.amax = hints.out_amax;
+    }
     const bool wide = p.tw == 32;
     // a side with <= 4 channels: the exact-N fp32 kernels (no BatchNorm statistics epilogue, one tensor per side)
     const bool no_small = (g_conv_tuning & UAPS_TUNE_NO_SMALL) != 0;
@@ -350,6 +371,9 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     const bool row16 = p.split && conv_mode() == 2 && hints.bound[0] && ks == 3 && p.dil == 1 && W % 256 == 0 && H % 16 == 0 && p.CoutP == 16 &&
                        Cin > 8 && Cin <= 32 && Cin % 8 == 0 && !y2 && (!x2 || Csplit >= Cin || hints.bound[1]) &&
                        !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16));
+    // the up-sampling form exists in ONE kernel: up4's first convolution on a 256-wide map (16 + 16 -> 16 channels, bounded operands)
+    if (up2 && !(row16 && x2 && Csplit == 16 && Cin == 32 && W == 256 && !xf && p.vec && up2_pattern_ok(W / 2)))
+        return UAPS_ENOFORM;
     if (!no_small && !row16 && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
     if (p.split) {
         // the split weights follow the exact ones in the packed buffer (uaps_conv_pack_floats)
@@ -377,6 +401,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         if (p.s32) return p.sbn == 64 ? launch_s32<64>(a, s) : launch_s32<32>(a, s);
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
         if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) {
+            if (up2) return launch_hr16_up(a, s);
             if (W % 256 == 0 && H % 16 == 0 && !(g_conv_tuning & UAPS_TUNE_NO_ROW16)) return launch_hr16(a, s);
             return launch_hp16(a, s);
         }

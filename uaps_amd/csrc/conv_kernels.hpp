@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/uaps_hip.h"
+#include "hints.hpp"
 
 namespace uaps {
 
@@ -163,6 +164,10 @@ struct ConvFwdArgs {
     const float* in_bound; const float* in2_bound; const float* wscale;
     float in_mul, in2_mul;
     unsigned* err;      // fp16-split kernels: sticky device error word (uaps_set_error_word) or nullptr
+    // UP2 forms of the full-width-row kernels (up2_staging.hpp): in2 is [B, Cin - Csplit, H / 2, W / 2] and is up-sampled x2 while
+    // staging; (H/2 - 1) / (H - 1) and (W/2 - 1) / (W - 1) as fp32, computed on the host like uaps_up_cat_fwd does
+    float up_rh, up_rw;
+    float* amax;        // fp32 kernels: raise this bound (uaps_call_hints::out_amax) to max|output|, or nullptr
 };
 
 // A magnitude bound that was too small lets a scaled operand overflow fp16: the pieces become +-inf and every output they
@@ -343,6 +348,7 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
 
     // ---- epilogue: lane (j, kq) holds pixels kq*4..kq*4+3 of channel j of every tile ------------
     float st_s[NW], st_q[NW];
+    float am = 0.f;                              // max|stored output| of this thread (ConvFwdArgs::amax)
 #pragma unroll
     for (int n = 0; n < NW; ++n) {
         st_s[n] = 0.f; st_q[n] = 0.f;
@@ -364,11 +370,12 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
             if (VEC == 4) {                       // W % 4 == 0: the 4 pixels are all inside or all outside
                 const bool ok = row_ok && gx < a.W;
                 if (ok) *reinterpret_cast<f32x4*>(p) = v;
+                if (ok) am = __builtin_fmaxf(__builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))), __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
                 if (ok) { const f32x4 d = v - sh; st_s[n] += (d.x + d.y) + (d.z + d.w); st_q[n] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (row_ok && gx + r < a.W) { p[r] = v[r]; const float d = v[r] - sh; st_s[n] += d; st_q[n] += d * d; }
+                    if (row_ok && gx + r < a.W) { p[r] = v[r]; am = __builtin_fmaxf(am, __builtin_fabsf(v[r])); const float d = v[r] - sh; st_s[n] += d; st_q[n] += d * d; }
             }
         }
     }
@@ -389,6 +396,10 @@ __device__ __forceinline__ void conv_fwd_body(const ConvFwdArgs& a) {
             const int tpi = a.tiles_x * a.tiles_y;
             a.stats[((size_t)(co0 + tid) * a.B + b) * tpi + ty * a.tiles_x + tx] = make_float2(s0, q0);
         }
+    }
+    if (a.amax != nullptr) {                     // wave-uniform: the bound of a later convolution's operand (uaps_call_hints::out_amax)
+        __shared__ float s_am[16];
+        block_amax_to(a.amax, am, s_am);
     }
 #ifdef UAPS_CLK_DEBUG
     if (tid == 0 && gridDim.x == 512 && (blockIdx.x % 37 == 0 || blockIdx.x == 511)) {
@@ -444,6 +455,8 @@ struct ConvWrwArgs {
     const float* dt_y; const float* dt_coef; float* dt_out;
     float dt_slope;
     int dt_Bg;
+    // UP2 forms of the full-width-row kernels (up2_staging.hpp): in2 is [B, Cin - Csplit, H / 2, W / 2], up-sampled x2 while staged
+    float up_rh, up_rw;
 };
 constexpr int kWrwMaxGroups = 8;     // statistics groups a conv_wrw_bn_kernel keeps coefficients for (norm_act.hip kMaxGroups)
 

@@ -20,6 +20,7 @@
 // the BatchNorm partial sums keep the 8 x 32-tile layout of those kernels (uaps_conv_fwd_stats_parts does not depend on which runs).
 #pragma once
 #include "conv_split.hpp"
+#include "up2_staging.hpp"
 
 namespace uaps {
 
@@ -28,7 +29,11 @@ namespace uaps {
 // tensors, a.out / a.out2 with Osplit = 16; no statistics epilogue in that form)
 // STRIP: maps wider than 256 pixels (W % 256 == 0) as 256-wide column strips: a run is 16 rows of one strip, and the one real pixel
 // either side of a strip (zero at the image edge) is fetched per row into the margin units that the 256-wide form leaves zero
-template <int NCG, bool XF, int NT = 1, bool STRIP = false>
+// UP2 (round 5): the second source (channel groups >= Csplit / 8) is the LOW-resolution tensor [B, Cin - Csplit, H / 2, W / 2]; its rows
+// are bilinearly up-sampled x2 while they are staged (up2_staging.hpp) -- the up-sampled half of up4's concatenation is never
+// written or re-read.  An up-sampling wave fetches 8 bytes per lane of two low rows per channel (16 loads: the registers of the
+// 8 full-row loads of a plain wave).  Bit-identical to the materialised operand.
+template <int NCG, bool XF, int NT = 1, bool STRIP = false, bool UP2 = false>
 __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     constexpr int WIDTH = 256, IW = WIDTH + 8, NSLOT = 4, ROWS = 16, XS = 3;
     constexpr int NWV = 2 * NCG, NTHR = 64 * NWV, HALF = NWV / 2;
@@ -38,6 +43,7 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     constexpr int CGU = NSLOT * IW, PIECE = NCG * CGU;       // 16-byte units between channel groups / pieces
     static_assert(NCG == 2 || NCG == 4, "16 or 32 input channels");
     static_assert(NT == 1 || (NT == 2 && NCG == 2 && !XF), "two output tiles: 16 input channels, plain input");
+    static_assert(!UP2 || (!XF && !STRIP && NT == 1), "up-sampled second source: plain 256-wide single-tile form");
 
     __shared__ __attribute__((aligned(16))) u32x4 sIn[2 * PIECE];      // [piece][channel group][slot][column]: 67.6 KB (NCG 2), 135 KB (NCG 4)
     __shared__ float sRed[NT == 1 ? NWV * 4 * NTC * 16 * 2 : 1];
@@ -93,6 +99,9 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     // ---- staging: this wave stages channel group scg of row (pair base + srr); lane = pixels 4 lane .. 4 lane + 3 ----
     const int scg = wave_u % NCG, srr = wave_u / NCG;
     float rin[8][4];
+    float up_lh0 = 0.f, up_lh1 = 0.f;                 // UP2: the row weights of the pair of source rows the registers hold
+    Up2Lane up_l{};
+    if constexpr (UP2) up_l = up2_lane(a.up_rw, lane);
     float rh[1] = {0.f};                              // STRIP: lanes 0..7 the pixel left of the strip, lanes 8..15 the pixel right of it, channel lane & 7
     f32x2 rxf[XF ? 8 : 1];
     f32x2 rxf_h = f32x2{0.f, 0.f};                    // STRIP && XF: the coefficients of channel lane & 7
@@ -102,9 +111,33 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     const bool second = c0 >= a.Csplit;               // wave-uniform: a channel group lies in one source (Csplit % 8 == 0)
 
     auto load_pair = [&](int b, int y1, int x0) {     // rows y1 and y1 + 1 of image b, columns x0 .. x0 + 255
+        const int gy = y1 + srr;
+        if constexpr (UP2) {
+            // ONE instruction stream for both kinds of wave (a load inside a wave-uniform branch comes back through a phi of differently
+            // shaped registers, and the copies behind it wait for the prefetch in front of the matrix loop): every wave issues two
+            // 8-byte loads per channel -- a plain wave the two halves of its 16 bytes of the row, an up-sampling wave its two low
+            // columns 2 lane, 2 lane + 1 of the source rows h0 and h1 (rin[c][0..1] <- row h0, rin[c][2..3] <- row h1; up2_row)
+            const int h = a.H / 2, w = a.W / 2;
+            urow = gy;
+            uin = (unsigned)gy < (unsigned)a.H && c0 < a.Cin;
+            const float sy = mul_rn(a.up_rh, (float)gy);
+            const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
+            up_lh1 = sy - (float)h0; up_lh0 = 1.f - up_lh1;
+            const uint32_t plane4 = second ? (uint32_t)(h * w) * 4u : HW4;
+            const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * h * w, (uint32_t)(a.Cin - a.Csplit) * plane4)
+                                                     : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
+            const uint32_t oa = second ? (uint32_t)((c0 - a.Csplit) * h * w + h0 * w + 2 * lane) * 4u : (uint32_t)(c0 * HW + gy * a.W + x0 + lane * 4) * 4u;
+            const uint32_t ob = second ? (uint32_t)((c0 - a.Csplit) * h * w + h1 * w + 2 * lane) * 4u : oa + 8u;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x2 t0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(uin ? oa + (uint32_t)c * plane4 : kOob), 0, 0));
+                const f32x2 t1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(uin ? ob + (uint32_t)c * plane4 : kOob), 0, 0));
+                rin[c][0] = t0.x; rin[c][1] = t0.y; rin[c][2] = t1.x; rin[c][3] = t1.y;
+            }
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
                                                  : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
-        const int gy = y1 + srr;
         urow = gy;
         uin = (unsigned)gy < (unsigned)a.H && c0 < a.Cin;
         const uint32_t off = (uint32_t)((second ? c0 - a.Csplit : c0) * HW + gy * a.W + x0 + lane * 4) * 4u;
@@ -133,6 +166,15 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rin[c][0]), "+v"(rin[c][1]), "+v"(rin[c][2]), "+v"(rin[c][3]));
+        if constexpr (UP2) {
+            if (second) {                             // the four up-sampled pixels of every channel replace the fetched source pixels
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const up2_f32x4 v = up2_row(up2_f32x2{rin[c][0], rin[c][1]}, up2_f32x2{rin[c][2], rin[c][3]}, up_l, up_lh0, up_lh1);
+                    rin[c][0] = v[0]; rin[c][1] = v[1]; rin[c][2] = v[2]; rin[c][3] = v[3];      // (a row outside the image was fetched as zeros: its interpolation is zero)
+                }
+            }
+        }
         const int base = (scg * NSLOT + ((urow + 1) & 3)) * IW + 4 + lane * 4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -212,8 +254,18 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
 #pragma unroll 1
         for (int k = 0; k < ROWS / 2; ++k) {
             const int y = r0 + 2 * k;                 // output rows y, y + 1 from input rows y - 1 .. y + 2
+            if constexpr (UP2) {
+                // ONE call site (two made the compiler split the load sequence over the branches and wait for all of it in front of
+                // the matrix loop): the next pair of this run, the next run's first pair, or -- behind the last run -- rows outside the
+                // image (nothing is read)
+                const bool more = k + 1 < ROWS / 2;
+                const int nr = run + nblk, nrr = nr % rpi;
+                load_pair(more ? b : (next_run ? nr / rpi : b), more ? y + 3 : (next_run ? (nrr % rps) * ROWS - 1 : -4), more ? x0 : (nrr / rps) * WIDTH);
+                __builtin_amdgcn_sched_barrier(0);    // the loads leave HERE, in front of the matrix loop (straight-line, the scheduler sinks them behind it)
+            } else {
             if (k + 1 < ROWS / 2) load_pair(b, y + 3, x0);
             else if (next_run) { const int nr = run + nblk, nrr = nr % rpi; load_pair(nr / rpi, (nrr % rps) * ROWS - 1, (nrr / rps) * WIDTH); }
+            }
 
             int aoff[NSTEP];
 #pragma unroll
@@ -309,6 +361,8 @@ template <int NCG>
 __global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
 // 16 -> 32 channels (two 16-channel output tiles, one or two output tensors), no statistics
 __global__ UAPS_HR16_BOUNDS(256) void conv_hr16x2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2>(a); }
+// 16 + 16 -> 16 channels with the second 16 up-sampled x2 from the low-resolution tensor while staging (UP2; up4's first convolution)
+__global__ UAPS_HR16_BOUNDS(512) void conv_hr16_up_kernel(ConvFwdArgs a) { conv_hr16_body<4, false, 1, false, true>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
 template <int NCG>
 __global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16w_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, false, 1, true>(a); }

@@ -15,6 +15,7 @@
 // enter the sums differs, so the results agree to rounding, not bit for bit.
 #pragma once
 #include "conv_split_wrw.hpp"
+#include "up2_staging.hpp"
 
 namespace uaps {
 
@@ -28,7 +29,10 @@ namespace uaps {
 // (one register set; the load latency is exposed behind the step's ~0.5 us of matrix work).  2: they were fetched a step earlier
 // (two alternating register sets, the row loop unrolled by two so that every set has ONE issue point and ONE consumption point):
 // twice the bytes in flight per CU.  Same arithmetic and summation order, bit-identical slabs.  Not with DT (register budget).
-template <int WCI, bool XF, bool STRIP = false, bool DT = false, int DEPTH = 1>
+// UP2 (round 5): the second source is the LOW-resolution tensor [B, Cin - Csplit, H / 2, W / 2], up-sampled x2 while its rows are
+// staged (up2_staging.hpp; conv_hr16_body's UP2 form is the forward of the same layer): an up-sampling wave fetches 8 bytes per lane
+// of two low rows per channel into the registers of a plain wave's one full-row load.
+template <int WCI, bool XF, bool STRIP = false, bool DT = false, int DEPTH = 1, bool UP2 = false>
 __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     constexpr int WIDTH = 256, NG = WIDTH / 8, XG = NG + 2, NSLOT = 3, ROWS = 16;
     constexpr int CI = 16 * WCI, NWV = 4 * WCI, NTHR = 64 * NWV;
@@ -39,6 +43,7 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     static_assert(RED_FLOATS / 4 <= X_UNITS, "the reduction scratch fits the input image");
     static_assert(WCI == 1 || WCI == 2, "16 or 32 input channels");
     static_assert(DEPTH == 1 || (DEPTH == 2 && !DT && ROWS % DEPTH == 0), "two rows ahead: plain dy only");
+    static_assert(!UP2 || (!XF && !STRIP && DEPTH == 1), "up-sampled second source: plain 256-wide form");
 
     __shared__ __attribute__((aligned(16))) u32x4 sX[X_UNITS];      // [piece][ci][slot][group]
     __shared__ __attribute__((aligned(16))) u32x4 sD[D_UNITS];      // [piece][co][group]
@@ -68,6 +73,10 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     // (fetched rows live in 128-bit vector variables: a set that crosses the row loop's back edge is then ONE loop-carried value per
     // load, which the register allocator keeps in place; as scalars it copied them behind the loads, i.e. waited for them at once)
     f32x4 rx[NXL], rd[NDL];
+    f32x4 rxb[1];                                        // (unused: an up-sampling wave keeps both low source rows in its set, 8 bytes per lane each)
+    float rxw[2] = {0.f, 0.f};                           // UP2: (lh0, lh1), the row weights of the set's pair of source rows
+    Up2Lane up_l{};
+    if constexpr (UP2) up_l = up2_lane(a.up_rw, lane);
     f32x4 rx2[DEPTH > 1 ? NXL : 1], rd2[DEPTH > 1 ? NDL : 1];      // DEPTH 2: the second set
     float rhx2[1] = {0.f};
     bool x_in2 = false, d_in2 = false, h_in2 = false;
@@ -81,8 +90,30 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
     const bool second = xc0 >= a.Csplit;
     int x0 = 0;                                          // first column of the run's strip
     auto ld4 = [](__amdgpu_buffer_rsrc_t rs, uint32_t off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0)); };
-    auto load_x = [&](int b, int gy, f32x4 (&dst)[NXL], bool& ok, float (&hdst)[1], bool& hok) {
+    auto load_x = [&](int b, int gy, f32x4 (&dst)[NXL], bool& ok, float (&hdst)[1], bool& hok, f32x4 (&dstb)[1], float (&lh)[2]) {
         ok = (unsigned)gy < (unsigned)a.H;
+        if constexpr (UP2) {
+            // one instruction stream for both kinds of wave (conv_hr16_body's UP2 form says why): two 8-byte loads per channel -- the two
+            // halves of a plain wave's 16 bytes of the row, or an up-sampling wave's low columns 2 lane, 2 lane + 1 of the source rows
+            // h0 and h1 (dst[i] = (row h0: x, y; row h1: z, w); up2_row)
+            const int h = a.H / 2, w = a.W / 2;
+            const float sy = mul_rn(a.up_rh, (float)gy);
+            const int h0 = (int)sy, h1 = h0 + (h0 < h - 1 ? 1 : 0);
+            lh[1] = sy - (float)h0; lh[0] = 1.f - lh[1];
+            const uint32_t plane4 = second ? (uint32_t)(h * w) * 4u : HW4;
+            const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * h * w, (uint32_t)(a.Cin - a.Csplit) * plane4)
+                                                     : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
+            const uint32_t oa = second ? (uint32_t)((xc0 - a.Csplit) * h * w + h0 * w + 2 * lane) * 4u : (uint32_t)(xc0 * HW + gy * a.W + x0 + lane * 4) * 4u;
+            const uint32_t ob = second ? (uint32_t)((xc0 - a.Csplit) * h * w + h1 * w + 2 * lane) * 4u : oa + 8u;
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) {
+                const bool v = ok && xc0 + i < a.Cin;
+                const f32x2 t0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(v ? oa + (uint32_t)i * plane4 : kOob), 0, 0));
+                const f32x2 t1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(v ? ob + (uint32_t)i * plane4 : kOob), 0, 0));
+                dst[i] = f32x4{t0.x, t0.y, t1.x, t1.y};
+            }
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rs = second ? make_rsrc(a.in2 + (size_t)b * (a.Cin - a.Csplit) * HW, (uint32_t)(a.Cin - a.Csplit) * HW4)
                                                  : make_rsrc(a.in + (size_t)b * a.Csplit * HW, (uint32_t)a.Csplit * HW4);
         const uint32_t off = (uint32_t)((second ? xc0 - a.Csplit : xc0) * HW + gy * a.W + x0 + lane * 4) * 4u;
@@ -113,10 +144,16 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
             }
         }
     };
-    auto store_x = [&](f32x4 (&src)[NXL], bool ok, int slot, float (&hsrc)[1], bool hok) {
+    auto store_x = [&](f32x4 (&src)[NXL], bool ok, int slot, float (&hsrc)[1], bool hok, f32x4 (&srcb)[1], float (&lh)[2]) {
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
             asm volatile("" : "+v"(src[i]));          // first touch (conv_hp16_body)
+            if constexpr (UP2) {
+                if (second) {                         // the four up-sampled pixels replace the fetched source pixels (zero outside the image)
+                    const up2_f32x4 u = up2_row(up2_f32x2{src[i][0], src[i][1]}, up2_f32x2{src[i][2], src[i][3]}, up_l, lh[0], lh[1]);
+                    src[i] = u;                       // (a row outside the image was fetched as zeros: its interpolation is zero)
+                }
+            }
             float v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -217,17 +254,17 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
         }
         // rows r0 - 1 and r0 into slots 0 and 1, then row r0 + 1 (slot 2) and dy row r0: two fetch rounds, both in flight together
         {
-            f32x4 ra[NXL], rb[NXL];
-            float ha[1] = {0.f}, hb[1] = {0.f};
+            f32x4 ra[NXL], rb[NXL], rab[1], rbb[1];
+            float ha[1] = {0.f}, hb[1] = {0.f}, wa[2] = {0.f, 0.f}, wb2[2] = {0.f, 0.f};
             bool oka, okb, hoka = false, hokb = false;
-            load_x(b, r0 - 1, ra, oka, ha, hoka);
-            load_x(b, r0, rb, okb, hb, hokb);
-            load_x(b, r0 + 1, rx, x_in, rhx, h_in);
+            load_x(b, r0 - 1, ra, oka, ha, hoka, rab, wa);
+            load_x(b, r0, rb, okb, hb, hokb, rbb, wb2);
+            load_x(b, r0 + 1, rx, x_in, rhx, h_in, rxb, rxw);
             load_d(b, r0, rd, d_in);
             __builtin_amdgcn_sched_barrier(0);
-            store_x(ra, oka, 0, ha, hoka);
-            store_x(rb, okb, 1, hb, hokb);
-            store_x(rx, x_in, 2, rhx, h_in);
+            store_x(ra, oka, 0, ha, hoka, rab, wa);
+            store_x(rb, okb, 1, hb, hokb, rbb, wb2);
+            store_x(rx, x_in, 2, rhx, h_in, rxb, rxw);
             store_d(rd);
         }
         __syncthreads();
@@ -275,10 +312,10 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
 #pragma unroll 1
             for (int y = r0; y < r0 + ROWS; ++y) {
                 const bool more = y + 1 < r0 + ROWS;
-                if (more) { load_x(b, y + 2, rx, x_in, rhx, h_in); load_d(b, y + 1, rd, d_in); }
+                if (more) { load_x(b, y + 2, rx, x_in, rhx, h_in, rxb, rxw); load_d(b, y + 1, rd, d_in); }
                 contract();
                 __syncthreads();                          // every wave is done with input row y - 1 and dy row y
-                if (more) { store_x(rx, x_in, s0, rhx, h_in); store_d(rd); }
+                if (more) { store_x(rx, x_in, s0, rhx, h_in, rxb, rxw); store_d(rd); }
                 s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
                 __syncthreads();
             }
@@ -288,23 +325,23 @@ __device__ __forceinline__ void conv_hrwrw_body(const ConvWrwArgs& a) {
             // range: zeros, no memory access) and stored all the same -- with a load or a store inside a branch the compiler's vmcnt
             // bookkeeping merges the paths and waits for BOTH sets in front of the first store (ISA: tools/diag/isa_outline.py).
             const int rend = r0 + ROWS;
-            load_x(b, r0 + 2, rx, x_in, rhx, h_in); load_d(b, r0 + 1, rd, d_in);
+            load_x(b, r0 + 2, rx, x_in, rhx, h_in, rxb, rxw); load_d(b, r0 + 1, rd, d_in);
             __builtin_amdgcn_sched_barrier(0);            // (the two sets' loads stay in this order)
-            load_x(b, r0 + 3, rx2, x_in2, rhx2, h_in2); load_d(b, r0 + 2, rd2, d_in2);
+            load_x(b, r0 + 3, rx2, x_in2, rhx2, h_in2, rxb, rxw); load_d(b, r0 + 2, rd2, d_in2);
 #pragma unroll 1
             for (int y = r0; y < rend; y += 2) {
                 contract();
                 __syncthreads();
-                store_x(rx, x_in, s0, rhx, h_in); store_d(rd);          // input row y + 2, dy row y + 1
+                store_x(rx, x_in, s0, rhx, h_in, rxb, rxw); store_d(rd);          // input row y + 2, dy row y + 1
                 s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
                 __syncthreads();
-                { const bool v = y + 3 < rend; load_x(b, v ? y + 4 : -1, rx, x_in, rhx, h_in); load_d(b, v ? y + 3 : -1, rd, d_in); }
+                { const bool v = y + 3 < rend; load_x(b, v ? y + 4 : -1, rx, x_in, rhx, h_in, rxb, rxw); load_d(b, v ? y + 3 : -1, rd, d_in); }
                 contract();
                 __syncthreads();
-                store_x(rx2, x_in2, s0, rhx2, h_in2); store_d(rd2);     // input row y + 3, dy row y + 2 (zeros behind the run's last step)
+                store_x(rx2, x_in2, s0, rhx2, h_in2, rxb, rxw); store_d(rd2);     // input row y + 3, dy row y + 2 (zeros behind the run's last step)
                 s0 = s0 + 1 >= NSLOT ? 0 : s0 + 1;
                 __syncthreads();
-                { const bool v = y + 4 < rend; load_x(b, v ? y + 5 : -1, rx2, x_in2, rhx2, h_in2); load_d(b, v ? y + 4 : -1, rd2, d_in2); }
+                { const bool v = y + 4 < rend; load_x(b, v ? y + 5 : -1, rx2, x_in2, rhx2, h_in2, rxb, rxw); load_d(b, v ? y + 4 : -1, rd2, d_in2); }
             }
         }
     }
@@ -376,6 +413,9 @@ template <int WCI>
 __global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true, true>(a); }
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_bn_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, true, true, true>(a); }
+// 16 + 16 input channels with the second 16 up-sampled x2 from the low-resolution tensor while staging (UP2; up4's first convolution)
+__global__ __launch_bounds__(512, 2) void conv_hrwrw_up_kernel(ConvWrwArgs a) { conv_hrwrw_body<2, false, false, false, 1, true>(a); }
+__global__ __launch_bounds__(512, 2) void conv_hrwrw_up_dt_kernel(ConvWrwArgs a) { conv_hrwrw_body<2, false, false, true, 1, true>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)
 template <int WCI>
 __global__ __launch_bounds__(256 * WCI, 2) void conv_hrwrww_kernel(ConvWrwArgs a) { conv_hrwrw_body<WCI, false, true>(a); }

@@ -167,6 +167,10 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
                             const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
     const uaps_call_hints hints = uaps::take_hints();
     if (!dy || !x || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    // UAPS_CONV_X2_UP2 (include/uaps_hip.h): x2 is [B, Cin - Csplit, H / 2, W / 2], up-sampled x2 while staged
+    const bool up2 = (cfg & UAPS_CONV_X2_UP2) != 0;
+    cfg &= ~UAPS_CONV_X2_UP2;
+    if (up2 && (!x2 || xf || H % 2 || W % 2)) return UAPS_EINVAL;
     if (xf && (x2 || groups < 1 || groups > kWrwMaxGroups || B % groups || (uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (xf && !(xf_slope >= 0.f && xf_slope <= 1.f)) return UAPS_ERANGE;      // leaky_relu is evaluated as max(z, slope * z)
     if (!x2) Csplit = Cin;
@@ -180,7 +184,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     if (p.dil != 1 && (ks != 3 || (p.dil != 2 && p.dil != 4))) return UAPS_ERANGE;
     if (ws_bytes < wrw_ws_floats(p, taps) * sizeof(float)) return UAPS_EWORKSPACE;
     // dy and x once each (+ the raw output read and the true dy written through when the call carries a pending BatchNorm transform)
-    uaps::account_bytes(4.0 * B * H * W * ((double)Cin + Cout + (hints.dyt_y ? 2.0 * Cout : 0.0)));
+    uaps::account_bytes(4.0 * B * H * W * ((double)Csplit + (Cin - Csplit) * (up2 ? 0.25 : 1.0) + Cout + (hints.dyt_y ? 2.0 * Cout : 0.0)));
     ConvWrwArgs a{};
     a.dout = dy; a.in = x; a.in2 = x2; a.Csplit = Csplit; a.slab = (float*)ws; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     a.CoutS = p.CoutS; a.CinS = p.CinS; a.tiles_x = (W + p.TW - 1) / p.TW; a.tiles_y = (H + p.TH - 1) / p.TH;
@@ -212,6 +216,13 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
         if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[2]; a.in2_mul = hints.mul[2]; }
         a.err = uaps::error_word();
         const unsigned grid = (unsigned)((p.nsplit + 7) / 8 * 8);
+        if (up2) {                                     // up4's first convolution: 16 + 16 input channels, the second 16 from the low-resolution tensor
+            if (!(Cin == 32 && Csplit == 16 && W == 256 && uaps::up2_pattern_ok(W / 2))) return UAPS_ENOFORM;
+            a.up_rh = (float)(H / 2 - 1) / (float)(H - 1); a.up_rw = (float)(W / 2 - 1) / (float)(W - 1);      // as uaps_up_cat_fwd
+            if (dyt) UAPS_LAUNCH_MAIN(conv_hrwrw_up_dt_kernel, dim3(grid), dim3(512), 0, s, a);
+            else UAPS_LAUNCH_MAIN(conv_hrwrw_up_kernel, dim3(grid), dim3(512), 0, s, a);
+            return (int)hipGetLastError();
+        }
         if (dyt && W > 256) {                          // column strips
             if (Cin <= 16) {
                 if (a.xf) UAPS_LAUNCH_MAIN((conv_hrwrww_bn_dt_kernel<1>), dim3(grid), dim3(256), 0, s, a);
@@ -262,7 +273,7 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     }
     // (the tile kernels have no DT form: built and measured late in round 4 -- 32 x 32 channel blocks, bit-identical dy -- the extra
     // staging work cost them more than the stand-alone pass it replaced: 12 launches +314 us against 224 us saved)
-    if (dyt) return UAPS_ENOFORM;
+    if (dyt || up2) return UAPS_ENOFORM;
     if (p.g1) {
         // single-tensor, 16-byte-aligned form only; workspace and reduce follow the same plan, so the caller chooses: cfg bit 28
         // (exact kernels) for a two-tensor / BatchNorm-in-staging / odd-pointer call of such a layer -- uaps_amd.conv.plan_cfg does

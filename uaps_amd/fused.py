@@ -286,13 +286,21 @@ class _BnActConv(torch.autograd.Function):
                                           nbt.data_ptr() if nbt is not None else None, float(momentum), float(eps), B, Cc, H, W,
                                           groups, stats[0].data_ptr(), stats[1].data_ptr(), xf.data_ptr(), st)
             _lib.check(rc, "uaps_bn_finalize_train")
-            with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, cfg, _conv._h16(xb)):
-                if xb is not None or (want_stats and stat_shift is not None):
-                    _lib.hints((xb,), None, stat_shift if want_stats else None)
-                rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
-                                        bias.data_ptr() if bias is not None else None, z.data_ptr(),
-                                        zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, cfg, st)
+            am = _conv._claim_amax(dev)               # conv.request_out_amax(): track max|z| (the 1x1 projection in front of an up-sampling)
+            for attempt in range(2):
+                with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, cfg, _conv._h16(xb)) as tm:
+                    if xb is not None or (want_stats and stat_shift is not None) or am is not None:
+                        _lib.hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
+                    rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
+                                            bias.data_ptr() if bias is not None else None, z.data_ptr(),
+                                            zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, cfg, st)
+                    if rc == _conv.ENOFORM:
+                        tm.on = False
+                if rc != _conv.ENOFORM or am is None:
+                    break
+                am = None                             # this layer's kernel cannot track it: run without (the caller falls back)
             _lib.check(rc, "uaps_conv_fwd_bn")
+            _conv._last_out_amax = am
         ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)

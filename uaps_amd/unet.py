@@ -54,8 +54,9 @@ class ConvBlock(nn.Module):
                   nn.LeakyReLU(LEAKY_SLOPE)]
         self.conv_conv = nn.Sequential(*layers)      # indices 0,1,4,5 carry the parameters
 
-    def forward(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None, lazy: bool = False):
+    def forward(self, x: torch.Tensor, x2: Optional[torch.Tensor] = None, lazy: bool = False, x2_low: bool = False):
         """x2: second half of a channel concatenation [x, x2] that is not materialised (GPU only).
+        x2_low: x2 is the LOW-resolution tensor; the first convolution's kernels up-sample it x2 while staging (conv.conv2d_cat up2).
         lazy: the caller feeds the result to exactly one convolution and can apply the last BatchNorm + LeakyReLU there
         (fused.bn_act_conv); then a PendingBnAct may come back instead of a tensor (train mode on the GPU only)."""
         if not x.is_cuda:
@@ -67,7 +68,7 @@ class ConvBlock(nn.Module):
             # the epilogue sums are taken about running_mean - conv bias of the BatchNorm they feed (no variance cancellation)
             sh0, sh1 = ((b0.running_mean, c0.bias), (b1.running_mean, c1.bias)) if _STAT_SHIFT else (None, None)
             y, st = (conv.conv2d_with_stats(x, c0.weight, None, stat_shift=sh0) if x2 is None
-                     else conv.conv2d_cat(x, x2, c0.weight, None, True, stat_shift=sh0))
+                     else conv.conv2d_cat(x, x2, c0.weight, None, True, stat_shift=sh0, up2=x2_low))
             if d0.p == 0.0 and _FUSED_BN_CONV and fused.can_fuse_bn_into_conv(y, c1.weight):
                 # no dropout in between (decoder blocks): the second conv normalises + activates while staging its input
                 y, st = fused.bn_act_conv(y, st, c0.bias, b0, LEAKY_SLOPE, c1.weight, None, want_stats=True, stat_shift=sh1)
@@ -77,7 +78,7 @@ class ConvBlock(nn.Module):
             a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, True, st)
             y, st = conv.conv2d_with_stats(a, c1.weight, None, stat_shift=sh1)
             return fused.bn_act(y, c1.bias, b1, LEAKY_SLOPE, 0.0, True, st)
-        y = conv.conv2d(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None)
+        y = conv.conv2d(x, c0.weight, None) if x2 is None else conv.conv2d_cat(x, x2, c0.weight, None, up2=x2_low)
         a = fused.bn_act(y, c0.bias, b0, LEAKY_SLOPE, d0.p, self.training)
         return fused.bn_act(conv.conv2d(a, c1.weight, None), c1.bias, b1, LEAKY_SLOPE, 0.0, self.training)
 
@@ -124,12 +125,22 @@ class UpBlock(nn.Module):
     def forward(self, coarse, skip, lazy: bool = False):
         """coarse: tensor or PendingBnAct (the previous UpBlock's output before its last BatchNorm + LeakyReLU);
         lazy: the caller accepts a PendingBnAct (see ConvBlock.forward)."""
+        if not isinstance(coarse, PendingBnAct) and not coarse.is_cuda:
+            return self.conv(torch.cat([skip, self.up(self.conv1x1(coarse))], dim=1))
+        # up4 at the metric's size: the up-sampled tensor is never written -- the ConvBlock's first convolution reads the 1x1
+        # projection's LOW-resolution output and up-samples it while staging (conv.conv2d_cat up2); that operand's bound is the
+        # projection's own max|output| (it has no BatchNorm behind it), tracked in its epilogue on request
+        fuse_up = _VIRTUAL_CAT and skip.shape[1] % 16 == 0 and conv.up2_eligible(skip, self.conv.conv_conv[0].weight)
+        if fuse_up:
+            conv.request_out_amax()
         if isinstance(coarse, PendingBnAct):
             low = coarse.conv(self.conv1x1.weight, self.conv1x1.bias)
-        elif not coarse.is_cuda:
-            return self.conv(torch.cat([skip, self.up(self.conv1x1(coarse))], dim=1))
         else:
             low = conv.conv2d(coarse, self.conv1x1.weight, self.conv1x1.bias)
+        if fuse_up:
+            am = conv.take_out_amax()
+            if am is not None and low.shape[2] * 2 == skip.shape[2] and low.shape[3] * 2 == skip.shape[3]:
+                return self.conv(skip, bounds.put(low, am), lazy=lazy, x2_low=True)
         if _VIRTUAL_CAT and skip.shape[1] % 16 == 0:
             return self.conv(skip, fused.upsample2x(low), lazy=lazy)     # the conv kernels read [skip | up] as two tensors
         return self.conv(fused.up_cat(skip, low), lazy=lazy)     # bilinear x2 written straight into the concat buffer
