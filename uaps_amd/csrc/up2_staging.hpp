@@ -22,9 +22,15 @@ struct Up2Lane { float lw0[4], lw1[4]; bool first; };
 // lane_global: index of the lane's 4-pixel group in the row (x = 4 * lane_global)
 __device__ __forceinline__ Up2Lane up2_lane(float rw, int lane_global) {
     Up2Lane L;
+    // (rw as an opaque per-lane value, one scalar multiply per pixel: from the kernel-argument scalar pair the compiler packed the
+    // four products into v_pk_mul_f32 with the scalar broadcast by op_sel -- a form tools/isa_lint.py keeps out of the library)
+    float r = rw;
+    asm volatile("" : "+v"(r));
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const float sx = mul_rn(rw, (float)(4 * lane_global + p));
+        float x = (float)(4 * lane_global + p);
+        asm volatile("" : "+v"(x));
+        const float sx = mul_rn(r, x);
         const int w0 = (int)sx;
         L.lw1[p] = sx - (float)w0; L.lw0[p] = 1.f - L.lw1[p];
     }

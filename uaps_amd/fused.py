@@ -125,9 +125,11 @@ class _BnAddRelu(torch.autograd.Function):
         _lib.require_device(y, "bn_add_relu")
         ctx.set_materialize_grads(False)
         y, identity = y.contiguous(), identity.contiguous()
+        if identity.data_ptr() % 16:              # a contiguous view at an odd storage offset: the apply pass streams 16-byte pieces of it
+            identity = identity.clone()
         B, Cc, H, W = y.shape
-        if identity.shape != y.shape or B % groups:
-            raise ValueError(f"bn_add_relu: y {tuple(y.shape)}, identity {tuple(identity.shape)}, {groups} statistics groups")
+        if identity.shape != y.shape or B % groups or identity.device != y.device:
+            raise ValueError(f"bn_add_relu: y {tuple(y.shape)}, identity {tuple(identity.shape)} on {identity.device}, {groups} statistics groups")
         if stats_partials.shape[:2] != (Cc, B) or stats_partials.shape[-1] != 2 or not stats_partials.is_contiguous():
             raise ValueError("bn_add_relu: stats must be the [C, B, parts, 2] tensor conv2d_with_stats returned for this y")
         dev = y.device
@@ -477,8 +479,9 @@ def cat_batches(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """torch.cat([a, b], dim=0) of the step's two input batches (forward_pair) by one kernel that also takes max|.| of the result:
     the bound lets the first convolution's weight gradient run in the fp16 form (csrc/conv_split_wrw_row.hpp).  Inputs that
     take part in autograd, or are not fp32 on the GPU, go through torch.cat."""
-    if not (a.is_cuda and b.is_cuda and a.dtype == b.dtype == torch.float32 and a.shape == b.shape) or a.requires_grad or b.requires_grad:
-        return torch.cat([a, b], dim=0)
+    if not (a.is_cuda and b.is_cuda and a.device == b.device and a.dtype == b.dtype == torch.float32 and a.shape == b.shape) \
+            or a.requires_grad or b.requires_grad:
+        return torch.cat([a, b], dim=0)           # (two devices: torch.cat raises, as it should -- the kernel would read a foreign pointer)
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
     am = bounds.new_amax(a.device) if bounds.enabled() else None
