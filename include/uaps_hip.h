@@ -424,6 +424,23 @@ typedef struct uaps_call_hints {
     float* dyt_out;
     float dyt_slope;
     int dyt_groups;
+    /* uaps_conv_bwd_data (round 5): the input gradient this call produces IS d(activation) of a train-mode BatchNorm + LeakyReLU
+     * (the layer in front of the convolution); its kernel also forms that BatchNorm's backward sums -- what the first pass of
+     * uaps_bn_act_bwd_prepare computes from (gradient, y) -- in its epilogue: bsum_y the BatchNorm's raw input [B, Cin, H, W],
+     * bsum_mean / bsum_invstd [groups][Cin] and bsum_gamma / bsum_beta [Cin] its saved statistics and parameters, bsum_partials
+     * float2 [Cin][B][H / 16] (sum d, sum d x_hat per 16-row run of the kernel),
+     * bsum_max two zeroed bounds (2 * UAPS_BOUND_FLOATS floats: max|d|, max|x_hat|).  uaps_bn_act_bwd_finalize then replaces
+     * uaps_bn_act_bwd_prepare.  UAPS_ENOFORM (nothing launched) where the layer's kernel has no such form (built: the
+     * full-width-row kernel, 16 -> 16 channels on a 256-wide map). */
+    const float* bsum_y;
+    const float* bsum_mean;
+    const float* bsum_invstd;
+    const float* bsum_gamma;
+    const float* bsum_beta;
+    void* bsum_partials;
+    float* bsum_max;
+    float bsum_slope;
+    int bsum_groups;
 } uaps_call_hints;
 int uaps_next_call_hints(const uaps_call_hints* hints);
 /* Measurement aid (bench.py): `start` / `stop` are two hipEvent_t created with timing enabled.  The calling thread's next MAIN
@@ -592,6 +609,9 @@ int uaps_bn_act_bwd_prepare(const float* dout, const float* y, const float* gamm
                             const float* save_invstd, float slope, int B, int C, int H, int W, int groups, float* coef,
                             float* dgamma, float* dbeta, float* dconv_bias, float* dy_bound, void* workspace, size_t workspace_bytes,
                             uaps_stream_t stream);
+int uaps_bn_act_bwd_finalize(const void* partials, int parts_per_image, const float* maxes, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_invstd, int B, int C, int H, int W, int groups, float* coef,
+                             float* dgamma, float* dbeta, float* dconv_bias, float* dy_bound, uaps_stream_t stream);
 int uaps_bn_act_bwd_apply(const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W, int groups,
                           float* dy, uaps_stream_t stream);
 

@@ -220,3 +220,49 @@ def test_dy_formed_in_the_weight_gradient_kernel_is_the_stand_alone_dy_bit_for_b
         if first is None:
             first = dw.clone()
         assert torch.equal(dw, first)
+
+
+def test_backward_sums_in_the_input_gradient_epilogue_match_the_sums_pass():
+    """uaps_call_hints::bsum_* (round 5): the 16 -> 16 input gradient on a 256-wide map forms the backward sums of the BatchNorm in
+    front of the convolution in its epilogue (conv_hr16_bs_kernel) + uaps_bn_act_bwd_finalize, against uaps_bn_act_bwd_prepare's own
+    pass over (gradient, y): the same input gradient bit for bit, coefficients / dgamma / dbeta to the rounding of differently
+    grouped fp32 partial sums, a dy bound that is an upper bound; two launches give the same bits."""
+    from uaps_amd import _lib, bounds, conv, fused, lazybn
+    if conv.get_mode() != "h16":
+        pytest.skip("fp16-split arithmetic only")
+    dev = torch.device(DEV)
+    torch.manual_seed(21)
+    B, Cc, H, W, groups = 4, 16, 32, 256, 2
+    y = (torch.randn(B, Cc, H, W, device=dev) * 1.5 + 0.2)
+    dz = torch.randn(B, Cc, H, W, device=dev)
+    w = torch.randn(Cc, Cc, 3, 3, device=dev) / 10
+    _, wb = conv.pack_weights(w)
+    bn = nn.BatchNorm2d(Cc).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.4, 0.4)
+    Bg = B // groups
+    mean = torch.stack([y[g * Bg:(g + 1) * Bg].mean((0, 2, 3)) for g in range(groups)]).contiguous()
+    var = torch.stack([y[g * Bg:(g + 1) * Bg].var((0, 2, 3), unbiased=False) for g in range(groups)])
+    invstd = (var + bn.eps).rsqrt().contiguous()
+    dzb = (bounds.from_value(dz.abs().max()), 1.0)
+    plain = conv.conv_bwd_data_raw(dz, wb, Cc, 3, 0, dyb=dzb)
+    prev, conv._FUSED_BSUM = conv._FUSED_BSUM, True       # (not the default: profiles/r05_bn_sums_epilogue_ab.txt)
+    da, partials, maxes = conv.conv_bwd_data_raw(dz, wb, Cc, 3, 0, dyb=dzb, bsum=(y, mean, invstd, bn.weight, bn.bias, 0.01, groups))
+    assert partials is not None and torch.equal(da, plain)
+    da2, partials2, maxes2 = conv.conv_bwd_data_raw(dz, wb, Cc, 3, 0, dyb=dzb, bsum=(y, mean, invstd, bn.weight, bn.bias, 0.01, groups))
+    conv._FUSED_BSUM = prev
+    assert torch.equal(partials, partials2) and torch.equal(maxes, maxes2)
+    dg1, db1, dc1 = (torch.empty(Cc, device=dev) for _ in range(3))
+    dg2, db2, dc2 = (torch.empty(Cc, device=dev) for _ in range(3))
+    ws = fused._bn_ws(dev, B, Cc, H, W)
+    lz_ref = lazybn.prepare(da, y, bn.weight, bn.bias, mean, invstd, 0.01, groups, dg1, db1, dc1, ws)
+    assert lazybn.take(da) is lz_ref
+    lz = lazybn.prepare_from_partials(da, y, bn.weight, bn.bias, mean, invstd, 0.01, groups, dg2, db2, dc2, partials, maxes)
+    assert lazybn.take(da) is lz
+    torch.testing.assert_close(lz.coef, lz_ref.coef, rtol=2e-5, atol=1e-7)
+    torch.testing.assert_close(dg2, dg1, rtol=2e-5, atol=1e-3)
+    torch.testing.assert_close(db2, db1, rtol=2e-5, atol=1e-3)
+    b_ref, b_new = float(bounds.value(lz_ref.bound[0])), float(bounds.value(lz.bound[0]))
+    dy = lazybn.materialize(da, lz)
+    assert float(dy.abs().max()) <= b_new and abs(b_new - b_ref) <= 1e-4 * b_ref
+    lazybn.reset()

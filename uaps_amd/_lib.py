@@ -119,6 +119,7 @@ SIGNATURES = {
     "uaps_cat2": (C.c_int, [_PTR, _PTR, _PTR, C.c_long, _PTR]),
     "uaps_bn_act_bwd_prepare": (C.c_int, [_PTR] * 6 + [C.c_float] + [C.c_int] * 5 + [_PTR] * 6 + [C.c_size_t, _PTR]),
     "uaps_bn_act_bwd_apply": (C.c_int, [_PTR] * 3 + [C.c_float] + [C.c_int] * 5 + [_PTR, _PTR]),
+    "uaps_bn_act_bwd_finalize": (C.c_int, [_PTR, C.c_int] + [_PTR] * 5 + [C.c_int] * 5 + [_PTR] * 6),
     "uaps_seg_confusion": (C.c_int, [_PTR, _PTR] + [C.c_int] * 4 + [_PTR, _PTR]),
 }
 
@@ -187,7 +188,10 @@ class CallHints(C.Structure):
     """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
     _fields_ = [("struct_size", C.c_uint), ("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
                 ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p), ("residual", C.c_void_p),
-                ("dyt_y", C.c_void_p), ("dyt_coef", C.c_void_p), ("dyt_out", C.c_void_p), ("dyt_slope", C.c_float), ("dyt_groups", C.c_int)]
+                ("dyt_y", C.c_void_p), ("dyt_coef", C.c_void_p), ("dyt_out", C.c_void_p), ("dyt_slope", C.c_float), ("dyt_groups", C.c_int),
+                ("bsum_y", C.c_void_p), ("bsum_mean", C.c_void_p), ("bsum_invstd", C.c_void_p), ("bsum_gamma", C.c_void_p),
+                ("bsum_beta", C.c_void_p), ("bsum_partials", C.c_void_p), ("bsum_max", C.c_void_p), ("bsum_slope", C.c_float),
+                ("bsum_groups", C.c_int)]
 
 
 class ConvCall(C.Structure):
@@ -199,7 +203,7 @@ class ConvCall(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("hints", CallHints), ("stream", C.c_void_p)]
 
 
-def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None) -> None:
+def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None, bsum=None) -> None:
     """bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
     None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about; residual: the
     tensor a BatchNorm apply pass adds before its ReLU (residual joins)."""
@@ -216,6 +220,12 @@ def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None) -> None
     else:
         h.dyt_y = h.dyt_coef = h.dyt_out = None
         h.dyt_slope, h.dyt_groups = 0.0, 0
+    if bsum is not None:                      # (y, mean, invstd, gamma, beta, partials, maxes, slope, groups): uaps_call_hints::bsum_*
+        (h.bsum_y, h.bsum_mean, h.bsum_invstd, h.bsum_gamma, h.bsum_beta, h.bsum_partials, h.bsum_max) = [t.data_ptr() for t in bsum[:7]]
+        h.bsum_slope, h.bsum_groups = float(bsum[7]), int(bsum[8])
+    else:
+        h.bsum_y = h.bsum_mean = h.bsum_invstd = h.bsum_gamma = h.bsum_beta = h.bsum_partials = h.bsum_max = None
+        h.bsum_slope, h.bsum_groups = 0.0, 0
     if stats is not None:
         if stats[0] is not None:
             h.stats_mean = stats[0].data_ptr()

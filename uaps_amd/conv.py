@@ -349,17 +349,43 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     return (y, stats, ppi) if want_stats else y
 
 
-def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0, dyb=None):
+# BatchNorm-backward sums in the input-gradient kernel's epilogue (uaps_call_hints::bsum_*): built and measured in round 5 -- the
+# sums pass it removes (46 us at 5.8 TB/s) costs the row kernel 38 us (it moves bytes at 4.0 TB/s): a wash, so OFF unless asked for
+# (profiles/r05_bn_sums_epilogue_ab.txt)
+_FUSED_BSUM = os.environ.get("UAPS_FUSED_BN_SUMS", "0") == "1"
+
+
+def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0, dyb=None, bsum=None):
+    """bsum = (y, mean, invstd, gamma, beta, slope, groups): dx is d(activation) of the train-mode BatchNorm + LeakyReLU whose raw
+    input is y; where the layer's kernel can (uaps_call_hints::bsum_*), its epilogue also forms that BatchNorm's backward sums --
+    then (dx, partials, maxes) comes back for lazybn.prepare_from_partials, else (dx, None, None)."""
     B, Cout, H, W = dy.shape
-    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dy.device)
+    dev = dy.device
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dev)
     cfg = plan_cfg(ks, cfg, True, dy, dx)
-    with _lib.device_guard(dy.device), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, _h16(dyb)):
+    L = _lib.lib()
+    partials = maxes = None
+    if bsum is not None and _FUSED_BSUM and dyb is not None and ks == 3 and Cin == 16 and Cout == 16 and W == 256 and H % 16 == 0:
+        ppi = H // 16                              # one part per 16-row run of the full-width-row kernel
+        partials = torch.empty((Cin, B, ppi, 2), dtype=torch.float32, device=dev)
+        maxes = torch.empty(2 * bounds.FLOATS, dtype=torch.float32, device=dev)
+        with _lib.device_guard(dev):
+            _lib.check(L.uaps_zero_bounds(maxes.data_ptr(), maxes.numel(), _lib.current_stream(dev)), "uaps_zero_bounds")
+            with _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, True, name="conv_hr16_bs_kernel") as tm:
+                _lib.hints((dyb,), bsum=(bsum[0], bsum[1], bsum[2], bsum[3], bsum[4], partials, maxes, bsum[5], bsum[6]))
+                rc = L.uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(dev))
+                if rc == ENOFORM:
+                    tm.on = False
+        if rc != ENOFORM:
+            _lib.check(rc, "uaps_conv_bwd_data")
+            return dx, partials, maxes
+        partials = maxes = None
+    with _lib.device_guard(dev), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, _h16(dyb)):
         if dyb is not None:
             _lib.hints((dyb,))
-        rc = _lib.lib().uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
-                                           _lib.current_stream(dy.device))
+        rc = L.uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(dev))
     _lib.check(rc, "uaps_conv_bwd_data")
-    return dx
+    return (dx, None, None) if bsum is not None else dx
 
 
 def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None,

@@ -159,6 +159,15 @@ int launch_hr16_up(ConvFwdArgs a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// 16 -> 16 channels, 256 wide: the input gradient that also forms the BatchNorm-backward sums of the layer in front (conv_hr16_bs_kernel)
+int launch_hr16_bs(ConvFwdArgs a, hipStream_t s) {
+    const long nruns = (long)a.B * (a.H / 16);
+    if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
+    const unsigned grid = (unsigned)(((nruns < 512 ? nruns : 512) + 7) / 8 * 8);
+    UAPS_LAUNCH_MAIN(conv_hr16_bs_kernel, dim3(grid), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
 int launch_hr16x2(ConvFwdArgs a, hipStream_t s) {
     const long nruns = (long)a.B * (a.H / 16) * (a.W / 256);
     if (nruns <= 0 || nruns > 0x7fffffffL) return UAPS_EINVAL;
@@ -371,6 +380,19 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
     const bool row16 = p.split && conv_mode() == 2 && hints.bound[0] && ks == 3 && p.dil == 1 && W % 256 == 0 && H % 16 == 0 && p.CoutP == 16 &&
                        Cin > 8 && Cin <= 32 && Cin % 8 == 0 && !y2 && (!x2 || Csplit >= Cin || hints.bound[1]) &&
                        !(g_conv_tuning & (UAPS_TUNE_NO_ROW16 | UAPS_TUNE_NO_HP16));
+    // BatchNorm-backward sums in the epilogue (uaps_call_hints::bsum_*): ONE kernel, the 16 -> 16 input gradient on a 256-wide map
+    const bool bsum = hints.bsum_y != nullptr;
+    if (bsum) {
+        if (!hints.bsum_mean || !hints.bsum_invstd || !hints.bsum_gamma || !hints.bsum_beta || !hints.bsum_partials || !hints.bsum_max ||
+            hints.bsum_groups < 1 || B % hints.bsum_groups || !(hints.bsum_slope >= 0.f && hints.bsum_slope <= 1.f)) return UAPS_EINVAL;
+        if (!(row16 && !x2 && !xf && !stats && !up2 && Cin == 16 && Cout == 16 && W == 256 && p.vec && (uintptr_t)hints.bsum_y % 16 == 0 &&
+              (uintptr_t)hints.bsum_max % 16 == 0))
+            return UAPS_ENOFORM;
+        a.bs_y = hints.bsum_y; a.bs_mean = hints.bsum_mean; a.bs_invstd = hints.bsum_invstd; a.bs_gamma = hints.bsum_gamma;
+        a.bs_beta = hints.bsum_beta; a.bs_slope = hints.bsum_slope; a.bs_Bg = B / hints.bsum_groups; a.bs_max = hints.bsum_max;
+        a.stats = (float2*)hints.bsum_partials;
+        uaps::account_bytes(4.0 * B * H * W * Cout);      // the BatchNorm's raw input, once more
+    }
     // the up-sampling form exists in ONE kernel: up4's first convolution on a 256-wide map (16 + 16 -> 16 channels, bounded operands)
     if (up2 && !(row16 && x2 && Csplit == 16 && Cin == 32 && W == 256 && !xf && p.vec && up2_pattern_ok(W / 2)))
         return UAPS_ENOFORM;
@@ -402,6 +424,7 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         const bool no_hp16 = (g_conv_tuning & UAPS_TUNE_NO_HP16) != 0;
         if (!no_hp16 && a.wscale && ks == 3 && wide && p.CoutP == 16 && Cin > 8 && Cin <= 32 && Osplit == Cout) {
             if (up2) return launch_hr16_up(a, s);
+            if (bsum) return launch_hr16_bs(a, s);
             if (W % 256 == 0 && H % 16 == 0 && !(g_conv_tuning & UAPS_TUNE_NO_ROW16)) return launch_hr16(a, s);
             return launch_hp16(a, s);
         }

@@ -168,6 +168,12 @@ struct ConvFwdArgs {
     // staging; (H/2 - 1) / (H - 1) and (W/2 - 1) / (W - 1) as fp32, computed on the host like uaps_up_cat_fwd does
     float up_rh, up_rw;
     float* amax;        // fp32 kernels: raise this bound (uaps_call_hints::out_amax) to max|output|, or nullptr
+    // BS form of the full-width-row kernel (uaps_call_hints::bsum_*): the output IS d(activation) of a train-mode BatchNorm +
+    // LeakyReLU whose raw input is bs_y [B, Cout, H, W]; the epilogue forms that BatchNorm's backward sums (sum d, sum d x_hat per
+    // 8 x 32-pixel tile into `stats`, the layout of the forward statistics) and raises bs_max[0 / 1] to max|d| / max|x_hat|
+    const float* bs_y; const float* bs_mean; const float* bs_invstd; const float* bs_gamma; const float* bs_beta;
+    float bs_slope; int bs_Bg;
+    float* bs_max;
 };
 
 // A magnitude bound that was too small lets a scaled operand overflow fp16: the pieces become +-inf and every output they

@@ -33,7 +33,11 @@ namespace uaps {
 // are bilinearly up-sampled x2 while they are staged (up2_staging.hpp) -- the up-sampled half of up4's concatenation is never
 // written or re-read.  An up-sampling wave fetches 8 bytes per lane of two low rows per channel (16 loads: the registers of the
 // 8 full-row loads of a plain wave).  Bit-identical to the materialised operand.
-template <int NCG, bool XF, int NT = 1, bool STRIP = false, bool UP2 = false>
+// BS (round 5): this launch is an input gradient whose output is d(activation) of a BatchNorm(train) + LeakyReLU; instead of the
+// forward statistics its epilogue forms that BatchNorm's BACKWARD sums (sum d, sum d x_hat with d = the LeakyReLU-masked gradient:
+// norm_act.hip's bn_bwd_sums_max_kernel, a pass of its own over (gradient, y) until now) per 8 x 32-pixel tile into `stats`, and
+// the two maxima the finalize needs.  The raw BatchNorm input y is fetched at the top of the step, beside the next row pair.
+template <int NCG, bool XF, int NT = 1, bool STRIP = false, bool UP2 = false, bool BS = false>
 __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     constexpr int WIDTH = 256, IW = WIDTH + 8, NSLOT = 4, ROWS = 16, XS = 3;
     constexpr int NWV = 2 * NCG, NTHR = 64 * NWV, HALF = NWV / 2;
@@ -44,6 +48,7 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     static_assert(NCG == 2 || NCG == 4, "16 or 32 input channels");
     static_assert(NT == 1 || (NT == 2 && NCG == 2 && !XF), "two output tiles: 16 input channels, plain input");
     static_assert(!UP2 || (!XF && !STRIP && NT == 1), "up-sampled second source: plain 256-wide single-tile form");
+    static_assert(!BS || (!XF && !STRIP && !UP2 && NT == 1), "BatchNorm-backward sums: plain 256-wide single-tile form");
 
     __shared__ __attribute__((aligned(16))) u32x4 sIn[2 * PIECE];      // [piece][channel group][slot][column]: 67.6 KB (NCG 2), 135 KB (NCG 4)
     __shared__ float sRed[NT == 1 ? NWV * 4 * NTC * 16 * 2 : 1];
@@ -224,6 +229,9 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
     float st_s[NTC], st_q[NTC];
 #pragma unroll
     for (int i = 0; i < NTC; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+    float bs_md = 0.f, bs_mx = 0.f;                   // BS: max|d|, max|x_hat| of this thread
+    float bs_mu = 0.f, bs_is = 0.f, bs_sc = 0.f, bs_sh = 0.f;      // BS: (mean, invstd, gamma invstd, beta) of channel j in the run's statistics group
+    float ybuf[BS ? MW : 1][4];                       // BS: the raw BatchNorm input at this step's output pixels
     const int tiles8 = a.H / 8;                       // statistics parts per image: 8-row x 32-pixel tiles, as the tile kernels write them
 
     const int txs = a.W / 32;                         // statistics tiles per tile row
@@ -235,6 +243,12 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
         const int b = run / rpi, rr = run % rpi, r0 = (rr % rps) * ROWS, x0 = (rr / rps) * WIDTH;
         const bool next_run = run + nblk < nruns;
         load_xf(b);
+        if constexpr (BS) {
+            const int g = b / a.bs_Bg;
+            const bool ok = co_ok[0];
+            bs_mu = ok ? a.bs_mean[g * a.Cout + j] : 0.f; bs_is = ok ? a.bs_invstd[g * a.Cout + j] : 0.f;
+            bs_sc = ok ? a.bs_gamma[j] * bs_is : 0.f; bs_sh = ok ? a.bs_beta[j] : 0.f;
+        }
         store_pair();                                 // rows r0 - 1, r0
         load_pair(b, r0 + 1, x0);
         store_pair();                                 // rows r0 + 1, r0 + 2
@@ -267,6 +281,12 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
             else if (next_run) { const int nr = run + nblk, nrr = nr % rpi; load_pair(nr / rpi, (nrr % rps) * ROWS - 1, (nrr / rps) * WIDTH); }
             }
 
+            if constexpr (BS) {                       // y at this step's output pixels: in flight over the matrix loop, used in the epilogue
+                const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(a.bs_y + (size_t)b * a.Cout * HW, (uint32_t)a.Cout * HW4);
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+                    buf_load<4>(rs_y, out_c[0] == kOob ? kOob : out_c[0] + (uint32_t)((y + orr) * a.W + x0 + (tb + m) * 16 + kq * 4) * 4u, ybuf[m]);
+            }
             int aoff[NSTEP];
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) aoff[s] = kxo[s] + ((y + orr + kyv[s]) & 3) * IW;     // input row y + orr + ky - 1 -> its slot
@@ -315,7 +335,15 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
                     const bool second_out = NT == 2 && n * 16 >= a.Osplit;      // wave-uniform
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), second_out ? rs_out2 : rs_out,
                                                            (int)(out_c[n] + (uint32_t)(gy * a.W + gx) * 4u), 0, 0);
-                    if constexpr (NT == 1) {
+                    if constexpr (BS) {               // norm_act.hip: dpre / bn_bwd_sums_max_kernel's arithmetic per element; ONE pair of sums per run
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float yc = ybuf[m][e] - bs_mu, z = yc * bs_sc + bs_sh;
+                            const float d = z > 0.f ? v[e] : v[e] * a.bs_slope, xh = yc * bs_is;
+                            st_s[0] += d; st_q[0] += d * xh;
+                            bs_md = __builtin_fmaxf(bs_md, __builtin_fabsf(d)); bs_mx = __builtin_fmaxf(bs_mx, __builtin_fabsf(xh));
+                        }
+                    } else if constexpr (NT == 1) {
                         const f32x4 d = v - sh;
                         st_s[m / 2] += (d.x + d.y) + (d.z + d.w);
                         st_q[m / 2] += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
@@ -323,7 +351,7 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
                 }
             }
             report_nonfinite(a.err, chk, UAPS_ERR_CONV_NONFINITE);
-            const bool band_end = NT == 1 && (k & 3) == 3;       // an 8-row band of statistics tiles is complete
+            const bool band_end = NT == 1 && (BS ? k == ROWS / 2 - 1 : (k & 3) == 3);       // an 8-row band of statistics tiles (BS: the run) is complete
             if (a.stats != nullptr && band_end) {
 #pragma unroll
                 for (int i = 0; i < NTC; ++i) {
@@ -334,6 +362,20 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
             }
             __syncthreads();                          // every wave is done with the rows that fall out of reach; the partial sums are visible
             if (k + 1 < ROWS / 2) store_pair();
+            if constexpr (BS) {
+                // one part per (channel, run): the run's sums over all waves and lane groups (only slot i = 0 carries sums), fixed order
+                if (a.stats != nullptr && band_end && tid < 16 && tid < a.Cout) {
+                    float s0 = 0.f, q0 = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < NWV; ++wv)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int e = (((wv * 4 + g) * NTC + 0) * 16 + tid) * 2;
+                            s0 += sRed[e]; q0 += sRed[e + 1];
+                        }
+                    a.stats[((size_t)tid * a.B + b) * (a.H / ROWS) + r0 / ROWS] = make_float2(s0, q0);
+                }
+            } else
             if (a.stats != nullptr && band_end && tid < 128 && (tid & 15) < a.Cout) {
                 // per-tile BatchNorm partial sums, fixed order: the tile's column tc lies with the waves (orr 0 / 1, tc / NTC), 4 lane groups each
                 const int tc = tid >> 4, ch = tid & 15, wv = tc / NTC, i = tc % NTC;
@@ -350,6 +392,12 @@ __device__ __forceinline__ void conv_hr16_body(const ConvFwdArgs& a) {
             __syncthreads();
         }
     }
+    if constexpr (BS) {                               // every thread of the workgroup gets here (a workgroup without a run left at the top)
+        __shared__ float s_bs[2][16];
+        if (!co_ok[0]) { bs_md = 0.f; bs_mx = 0.f; }
+        block_amax_to(a.bs_max, bs_md, s_bs[0]);
+        block_amax_to(a.bs_max + UAPS_BOUND_FLOATS, bs_mx, s_bs[1]);
+    }
 }
 
 // Two waves per SIMD for every form: left unbounded the two-output-tile and column-strip forms took 300-400 registers, i.e. ONE
@@ -361,6 +409,8 @@ template <int NCG>
 __global__ UAPS_HR16_BOUNDS(128 * NCG) void conv_hr16_bn_kernel(ConvFwdArgs a) { conv_hr16_body<NCG, true>(a); }
 // 16 -> 32 channels (two 16-channel output tiles, one or two output tensors), no statistics
 __global__ UAPS_HR16_BOUNDS(256) void conv_hr16x2_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 2>(a); }
+// the input gradient that also forms the BatchNorm-backward sums of the layer in front (BS)
+__global__ UAPS_HR16_BOUNDS(256) void conv_hr16_bs_kernel(ConvFwdArgs a) { conv_hr16_body<2, false, 1, false, false, true>(a); }
 // 16 + 16 -> 16 channels with the second 16 up-sampled x2 from the low-resolution tensor while staging (UP2; up4's first convolution)
 __global__ UAPS_HR16_BOUNDS(512) void conv_hr16_up_kernel(ConvFwdArgs a) { conv_hr16_body<4, false, 1, false, true>(a); }
 // the column-strip forms for maps wider than 256 pixels (W % 256 == 0)

@@ -724,6 +724,19 @@ extern "C" int uaps_bn_act_bwd_prepare(const float* dout, const float* y, const 
     return (int)hipGetLastError();
 }
 
+// The second half of uaps_bn_act_bwd_prepare on its own: the sums were formed in the epilogue of the kernel that wrote the gradient
+// (uaps_call_hints::bsum_* on uaps_conv_bwd_data) -- partials float2 [C][B][parts_per_image], maxes = the two raised bounds.
+extern "C" int uaps_bn_act_bwd_finalize(const void* partials, int parts_per_image, const float* maxes, const float* gamma, const float* beta,
+                                        const float* save_mean, const float* save_invstd, int B, int C, int H, int W, int groups,
+                                        float* coef, float* dgamma, float* dbeta, float* dconv_bias, float* dy_bound, uaps_stream_t stream) {
+    if (!partials || parts_per_image <= 0 || !maxes || B <= 0 || C <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
+    if (!gamma || !beta || !save_mean || !save_invstd || !coef || !dgamma || !dbeta || !dy_bound) return UAPS_EINVAL;
+    if (groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, (const float2*)partials, parts_per_image, B, B / groups, C,
+                       (long)H * W, save_mean, save_invstd, gamma, beta, maxes, maxes + UAPS_BOUND_FLOATS, coef, dgamma, dbeta, dconv_bias, dy_bound);
+    return (int)hipGetLastError();
+}
+
 extern "C" int uaps_bn_act_bwd_apply(const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W,
                                      int groups, float* dy, uaps_stream_t stream) {
     float* amax_out = uaps::take_hints().out_amax;

@@ -362,14 +362,22 @@ class _BnActConv(torch.autograd.Function):
             done_w = out is not None
             dz = out if done_w else lazybn.materialize(dz, lz_in)
             dzb = bounds.get(dz)
-        da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, cfg, dyb=dzb)
+        lazy_up = ctx.lazy_up and not lazybn.observed(y)      # (a hook / retain_grad registered on y since the forward gets the true gradient)
+        partials = maxes = None
+        if lazy_up:      # where the input-gradient kernel can, its epilogue forms this BatchNorm's backward sums (no pass of their own)
+            da, partials, maxes = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, cfg, dyb=dzb, bsum=(y, stats[0], stats[1], gamma, beta, slope, groups))
+        else:
+            da = _conv.conv_bwd_data_raw(dz, wb, Cc, ks, cfg, dyb=dzb)
         if not done_w:
             weight_gradient(dz, dzb, None)
         dgb = [_graddest.take(k, (Cc,), dev) for k in ctx.keys[:3]]      # dgamma, dbeta, d(conv bias) = 0
         ws = _bn_ws(dev, B, Cc, H, W)
-        if ctx.lazy_up and not lazybn.observed(y):      # (a hook / retain_grad registered on y since the forward gets the true gradient)
+        if lazy_up:
             # the reductions only; d(activation) goes up as it is, its transform pending (lazybn): y's producer forms dy in its weight gradient
-            lazybn.prepare(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], ws)
+            if partials is not None:
+                lazybn.prepare_from_partials(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], partials, maxes)
+            else:
+                lazybn.prepare(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], ws)
             dy = da
         else:
             dy = torch.empty_like(y)

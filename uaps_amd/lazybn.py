@@ -109,6 +109,27 @@ def prepare(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dc
     return lz
 
 
+def prepare_from_partials(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dconv_bias, partials, maxes) -> Lazy:
+    """`prepare` whose reductions were formed in the epilogue of the kernel that wrote dout (conv.conv_bwd_data_raw bsum:
+    partials float2 [C][B][parts], maxes = max|d| and max|x_hat|): the finalize alone."""
+    global _outstanding, _prepared
+    B, Cc, H, W = y.shape
+    dev = y.device
+    coef = torch.empty((groups, Cc, 8), dtype=torch.float32, device=dev)
+    bnd = bounds.new_amax(dev)
+    with _lib.device_guard(dev):
+        rc = _lib.lib().uaps_bn_act_bwd_finalize(partials.data_ptr(), int(partials.shape[2]), maxes.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 mean.data_ptr(), invstd.data_ptr(), B, Cc, H, W, int(groups), coef.data_ptr(), dgamma.data_ptr(),
+                                                 dbeta.data_ptr(), dconv_bias.data_ptr() if dconv_bias is not None else None, bnd.data_ptr(),
+                                                 _lib.current_stream(dev))
+    _lib.check(rc, "uaps_bn_act_bwd_finalize")
+    lz = Lazy(y, coef, slope, groups, (bnd, 1.0), dout._version, dout.data_ptr())
+    setattr(dout, _REC, lz)
+    _outstanding += 1
+    _prepared += 1
+    return lz
+
+
 def prepared_total() -> int:
     return _prepared
 
