@@ -8,7 +8,7 @@ D=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $D
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --output-format csv -d $D/$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --steps 2 --warmup 1 --analysis-steps 0 --exact-steps 0 --single-stream --no-graph --no-cpu-baseline --other-configs 0 > $D/$c.log 2>&1
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $D/$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py "$@" --steps 2 --warmup 1 --analysis-steps 0 --exact-steps 0 --single-stream --no-graph --no-cpu-baseline --no-inference --other-configs 0 > $D/$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py gpurun_out/pmc_$tag 3 > $D/summary.txt 2>&1
