@@ -380,13 +380,15 @@ def main():
     # N > 1 steps eagerly (decoder streams, bucket all-reduces overlapped with the backward).  UAPS_GRAPH_MULTI=1 selects the two-graph
     # form of uaps_amd/graph.py instead (two gloo ranks on one card: bit-equal to the eager step; over RCCL only ever run with one
     # rank here, where tools/diag/rccl_split_graph.py once aborted behind other process groups of the same process -- so not the default)
-    # Round 5: the eager step needs the host -- 14.0 ms with two cores per rank, 18.3 ms with one -- so when the
-    # ranks have fewer than 4 usable cores each, the two-graph form is selected by itself (UAPS_GRAPH_MULTI=0 forces eager, =1 forces
-    # the graphs).  The abort seen once behind it happened in a process that had created and destroyed other process groups with captures
-    # in between; this script creates exactly one group per process, before any capture.
+    # Round 5: the eager step needs the host -- 14.0 ms with two cores per rank, 18.3 ms with one -- so when a rank
+    # has fewer than 2 usable cores, the two-graph form is selected by itself (UAPS_GRAPH_MULTI=0 forces eager, =1 forces the graphs).
+    # Not already below 4, as the round-4 review suggested: with 2-3 cores the eager step is within 7 % of the replayed one, and the
+    # two-graph form has never run over RCCL with more than one rank -- 7 % is not worth the first such run being the scaling run.
+    # The abort seen once behind it happened in a process that had created and destroyed other process groups with captures in
+    # between; this script creates exactly one group per process, before any capture.
     cores_per_rank = (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(world, 1) if affinity is None else len(affinity)
     gm = os.environ.get("UAPS_GRAPH_MULTI", "")
-    graph_multi = gm == "1" or (gm != "0" and world > 1 and cores_per_rank < 4)
+    graph_multi = gm == "1" or (gm != "0" and world > 1 and cores_per_rank < 2)
     use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or graph_multi)
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
     data = uaps_amd.data.SyntheticBatches(b, args.in_chns, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
