@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Timeline of the HEADLINE step (hipGraph replay, decoder streams) from a rocprofv3 kernel trace: per step, the wall time between its
+first and last kernel, the time no kernel runs, the time exactly one kernel runs, and which kernels run alone the longest.
+  python tools/diag/headline_timeline.py <kernel_trace.csv> [steps to skip]"""
+import csv, re, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+skip = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+ks = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "").replace("uaps::", "")) for r in rows))
+# a step starts at cat2_amax_kernel (the first kernel of forward_pair)
+starts = [i for i, k in enumerate(ks) if k[2].startswith("cat2_amax_kernel")]
+print(f"{len(ks)} kernels, {len(starts)} steps in the trace")
+for si in range(skip, min(len(starts) - 1, skip + 3)):
+    seg = ks[starts[si]:starts[si + 1]]
+    t0, t1 = seg[0][0], max(e for _, e, _ in seg)
+    ev = sorted([(s, 1, n) for s, e, n in seg] + [(e, -1, n) for s, e, n in seg])
+    active, last = 0, t0
+    idle = alone = 0
+    alone_by = collections.Counter()
+    cur = []
+    for t, d, n in ev:
+        dt = t - last
+        if active == 0: idle += dt
+        elif active == 1: alone += dt; alone_by[cur[0]] += dt
+        last = t
+        if d == 1: active += 1; cur.append(n)
+        else: active -= 1; cur.remove(n)
+    busy = sum(e - s for s, e, _ in seg)
+    print(f"step {si}: wall {(t1 - t0) / 1e6:.3f} ms, {len(seg)} kernels, sum of kernel durations {busy / 1e6:.3f} ms, idle {idle / 1e6:.3f} ms, exactly one kernel running {alone / 1e6:.3f} ms")
+    print("   longest alone: " + ", ".join(f"{k[:40]} {v / 1e3:.0f} us" for k, v in alone_by.most_common(12)))
