@@ -18,6 +18,12 @@
 
 namespace uaps {
 
+// Diagnostic builds only (make -C uaps_amd/csrc g1abl; tools/diag/g1_ablate.sh): UAPS_G1_ABLATE = 5 drops the staging behind the
+// first chunk, 6 also the barriers, 7 also the LDS fragment reads -- timing only, the results are meaningless.
+#ifndef UAPS_G1_ABLATE
+#define UAPS_G1_ABLATE 0
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // forward / input gradient.  BN = 128 or 64 output channels per workgroup; packed weights as conv_s32_body reads them
 // ([piece][tap = 0][channel group][CoutP][8]); ConvFwdArgs::CinP = padded channel groups, tiles_x = pixel tiles per image.
@@ -117,12 +123,33 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
     split_chunk();
     store_chunk();
     __syncthreads();
+#if UAPS_G1_ABLATE >= 7
+    bf16x8 af7[2][NP], bf7[NTW][NP];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) af7[m][p] = __builtin_bit_cast(bf16x8, sA[(p * KG + h) * TM + aoff + m * 32]);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) bf7[n][p] = __builtin_bit_cast(bf16x8, sB[(p * KG + h) * BN + boff + n * 32]);
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
-        const bool more = ch + 1 < nchunks;
+        const bool more = UAPS_G1_ABLATE >= 5 ? false : ch + 1 < nchunks;
         if (more) load_chunk((ch + 1) * 32);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[2][NP], bfr[NTW][NP];
+#if UAPS_G1_ABLATE >= 7
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { af[m][p] = af7[m][p]; asm volatile("" : "+v"(af[m][p])); }
+#pragma unroll
+            for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { bfr[n][p] = bf7[n][p]; asm volatile("" : "+v"(bfr[n][p])); }
+#else
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -131,6 +158,7 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
             for (int n = 0; n < NTW; ++n)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) bfr[n][p] = __builtin_bit_cast(bf16x8, sB[(p * KG + 2 * ks + h) * BN + boff + n * 32]);
+#endif
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -153,9 +181,13 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
                 }
         }
         if (more) split_chunk();                     // behind the matrix phase: the fetched chunk has had its time to arrive
+#if UAPS_G1_ABLATE < 6
         __syncthreads();
+#endif
         if (more) store_chunk();
+#if UAPS_G1_ABLATE < 6
         __syncthreads();
+#endif
     }
 
     // ---- epilogue.  C/D of 32x32: lane (n = r, h) register i holds pixel 8 (i >> 2) + 4 h + (i & 3) of channel n ----
