@@ -360,6 +360,7 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above (default 2); proces
 #define UAPS_TUNE_NO_ROW16 128u       /* no full-width-row kernels (csrc/conv_split_row16.hpp): the 8 x 32-tile persistent kernels instead */
 #define UAPS_TUNE_NO_ROW_WRW 256u     /* no full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp) */
 #define UAPS_TUNE_DEEP_ROWS 512u      /* diagnostic: the full-width-row kernels with two row sets in flight (round 5: measured slower) */
+#define UAPS_TUNE_G1_NARROW 1024u    /* 1x1 GEMM kernels: 128 output channels per workgroup also where 256 divide the layer's width */
 int uaps_conv_set_tuning(unsigned flags);
 unsigned uaps_conv_get_tuning(void);
 
@@ -489,6 +490,15 @@ int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias,
                                  int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
 int uaps_conv_bwd_weight_reduce(const void* workspace, float* dw, float* dbias, int B, int Cin, int Cout, int H, int W,
                                 int ks, int cfg, uaps_stream_t stream);
+/* The reductions of SEVERAL weight gradients by one launch (per 28 items): items[i] names what uaps_conv_bwd_weight_reduce would
+ * have been called with for gradient i (the workspace its *_partial call wrote, dims and cfg of that call); results are
+ * bit-identical to the single calls.  The workspaces must be distinct buffers, untouched between the partial call and this one.
+ * A training step has ~60 convolutions; their reductions are 5-6 us launches of latency each (uaps_amd/conv.py: deferred_reduces). */
+typedef struct uaps_wrw_reduce_item {
+    const void* workspace; float* dw; float* dbias;      /* dbias NULL: the partial call ran with want_bias = 0 */
+    int B, Cin, Cout, H, W, ks, cfg;
+} uaps_wrw_reduce_item;
+int uaps_conv_bwd_weight_reduce_batch(const uaps_wrw_reduce_item* items, int n, uaps_stream_t stream);
 /* Convolutions over a channel concatenation that is never materialised: the first ConvBlock conv of an UpBlock
  * reads torch.cat([skip, upsampled], dim=1) (UAPS_unet.py:84-85).  x1 [B,C1,H,W], x2 [B,C2,H,W], weights packed for
  * Cin = C1 + C2 as usual; C1 must be a multiple of 16.  The input gradient comes back as two tensors, and the

@@ -51,6 +51,7 @@ SHAPES = [
     (1, 512, 128, 32, 48, 1),
     (2, 200, 136, 32, 32, 1),   # channel counts that are no multiples of the block sizes (stays on the 3x3-style tiling: CoutP % 64)
     (1, 1024, 256, 40, 40, 1),
+    (1, 128, 512, 24, 24, 1),   # two 256-channel output blocks (conv_g1h256_kernel), a partial pixel tile
     # 32-channel blocks on 16-row tiles (csrc/conv_split.hpp, MR = 4): >= 512 tiles of 16 x 32 pixels, ragged in both directions
     (5, 24, 32, 200, 264, 3),
     (4, 32, 32, 256, 256, 3),
@@ -520,3 +521,45 @@ def test_up_sampling_in_the_staging_equals_the_materialised_operand(lazy):
     # without a bound on the low tensor the kernel refuses (UAPS_ENOFORM -> an error, not a silent fallback)
     with pytest.raises(Exception):
         conv.conv2d_cat(bounds.put(skip0.clone(), bounds.from_value(skip0.abs().max())), low0.clone(), w1, None, up2=True)
+
+
+def test_batched_weight_gradient_reduction_equals_the_single_reductions():
+    """uaps_conv_bwd_weight_reduce_batch over 31 gradients (two launches: 28 + 3) of mixed shapes -- 3x3 / 1x1, small / large
+    element counts (both lane arrangements of the reduction), with / without a bias gradient -- equals
+    uaps_conv_bwd_weight_reduce item by item, bit for bit."""
+    import ctypes as C
+    from uaps_amd import _lib, conv
+    L = _lib.lib()
+    DEV = torch.device("cuda:0")
+    shapes = [(2, 16, 16, 32, 64, 3, True), (2, 64, 64, 16, 16, 3, False), (1, 128, 256, 16, 16, 3, True), (2, 256, 128, 16, 16, 1, False),
+              (2, 3, 16, 24, 64, 3, True), (1, 20, 40, 18, 18, 3, False), (2, 16, 4, 32, 256, 3, True)]
+    items, keep, singles = [], [], []
+    st = _lib.current_stream(DEV)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for i in range(31):
+        B, Cin, Cout, H, W, ks, bias = shapes[i % len(shapes)]
+        x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+        dy = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+        cfg = conv.plan_cfg(ks, 0, True, dy, x)
+        n = C.c_size_t()
+        _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "ws")
+        ws = torch.empty(max(n.value, 16), dtype=torch.uint8, device=DEV)
+        _lib.check(L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(bias), B, Cin, Cout, H, W, ks, cfg, ws.data_ptr(), ws.numel(), st), "partial")
+        dw1, db1 = torch.full((Cout, Cin, ks, ks), float("nan"), device=DEV), (torch.full((Cout,), float("nan"), device=DEV) if bias else None)
+        _lib.check(L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw1.data_ptr(), db1.data_ptr() if bias else None, B, Cin, Cout, H, W, ks, cfg, st), "reduce")
+        dw2, db2 = torch.full_like(dw1, float("nan")), (torch.full_like(db1, float("nan")) if bias else None)
+        items.append((ws, dw2, db2, B, Cin, Cout, H, W, ks, cfg))
+        singles.append((dw1, db1))
+        keep.append((x, dy))
+    arr = (_lib.WrwReduceItem * len(items))()
+    for a, (ws, dw, db, B, Cin, Cout, H, W, ks, cfg) in zip(arr, items):
+        a.workspace, a.dw, a.dbias = ws.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+        a.B, a.Cin, a.Cout, a.H, a.W, a.ks, a.cfg = B, Cin, Cout, H, W, ks, cfg
+    _lib.check(L.uaps_conv_bwd_weight_reduce_batch(arr, len(items), st), "batch")
+    torch.cuda.synchronize()
+    for (dw1, db1), it in zip(singles, items):
+        assert torch.isfinite(dw1).all()
+        np.testing.assert_array_equal(it[1].cpu().numpy(), dw1.cpu().numpy())
+        if db1 is not None:
+            np.testing.assert_array_equal(it[2].cpu().numpy(), db1.cpu().numpy())
+    assert L.uaps_conv_bwd_weight_reduce_batch(None, 0, st) == 0 and L.uaps_conv_bwd_weight_reduce_batch(None, 2, st) != 0

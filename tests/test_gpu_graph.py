@@ -327,3 +327,56 @@ def test_two_trainers_interleave_their_step_states():
             assert torch.equal(pa, pb), (k, n)
         for (n, ba), bb in zip(solo[k].named_buffers(), both[k].buffers()):
             assert torch.equal(ba, bb), (k, n)
+
+
+@pytest.mark.parametrize("streams", [False, True])
+def test_deferred_weight_gradient_reductions_give_the_same_step_bit_for_bit(streams, monkeypatch):
+    """conv.deferred_reduces (the trainers' scope: one batched reduction launch behind the backward instead of one launch per
+    convolution) against the immediate reductions: same gradients, hence the same parameters after three steps, bit for bit --
+    eagerly, with decoder streams, and through the captured graph."""
+    import uaps_amd
+    from uaps_amd import conv
+    import uaps_amd.unet as _unet
+    monkeypatch.setattr(_unet, "_DECODER_STREAMS", streams)
+    data = _batches(3, 2, 64, 64)
+    results = []
+    for defer, graph in ((False, False), (True, False), (True, True)):
+        monkeypatch.setattr(conv, "_DEFER", defer)
+        m = _model(7).to(DEV)
+        tr = uaps_amd.UAPSTrainer(m, base_lr=1e-3, seed=11, step_state=True, use_graph=graph)
+        flushed = []
+        orig = conv.flush_weight_reduces
+        monkeypatch.setattr(conv, "flush_weight_reduces", lambda: flushed.append(orig()) or flushed[-1])
+        for xl, y, xu in data + data:
+            tr.train_step(xl, y, xu)
+        monkeypatch.setattr(conv, "flush_weight_reduces", orig)
+        torch.cuda.synchronize()
+        tr.check_errors()
+        assert conv._deferred is None                       # no scope left open
+        if defer:
+            assert flushed and all(n > 40 for n in flushed)   # every convolution of the net rode in the batch
+        else:
+            assert not any(flushed)
+        results.append({n: p.detach().cpu().numpy() for n, p in m.named_parameters()})
+    for other in results[1:]:
+        for n, a in results[0].items():
+            np.testing.assert_array_equal(other[n], a, err_msg=n)
+
+
+def test_a_failing_backward_drops_the_pending_reductions():
+    import uaps_amd
+    from uaps_amd import conv
+    x = torch.randn(2, 8, 32, 32, device=DEV, requires_grad=True)
+    w = torch.randn(16, 8, 3, 3, device=DEV, requires_grad=True)
+    with pytest.raises(RuntimeError, match="boom"):
+        with conv.deferred_reduces():
+            y = conv.conv2d(x, w, None)
+            y.sum().backward()
+            assert conv._deferred and len(conv._deferred) == 1
+            raise RuntimeError("boom")
+    assert conv._deferred is None
+    # outside a scope the reduction is immediate and the gradient is the oracle's
+    w.grad = None
+    conv.conv2d(x, w, None).sum().backward()
+    ref = torch.nn.grad.conv2d_weight(x.detach().cpu().double(), w.shape, torch.ones(2, 16, 32, 32, dtype=torch.float64), padding=1)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-4)

@@ -1,8 +1,10 @@
 """configs[4] per-GPU shape (ResNet-50 encoder, K = 3, 640 x 640, 8 + 8): eager against the captured hipGraph of the step.
 GPU box: python3 tools/diag/resnet_graph_ab.py [steps]"""
+import os
 import sys
 import time
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import uaps_amd

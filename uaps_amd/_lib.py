@@ -70,6 +70,7 @@ SIGNATURES = {
     "uaps_conv_wrw_workspace_bytes": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_size_t)]),
     "uaps_conv_bwd_weight_partial": (C.c_int, [_PTR, _PTR] + [C.c_int] * 8 + [_PTR, C.c_size_t, _PTR]),
     "uaps_conv_bwd_weight_reduce": (C.c_int, [_PTR, _PTR, _PTR] + [C.c_int] * 7 + [_PTR]),
+    "uaps_conv_bwd_weight_reduce_batch": (C.c_int, [_PTR, C.c_int, _PTR]),
     "uaps_conv_fwd_cat": (C.c_int, [_PTR, C.c_int, _PTR, C.c_int] + [_PTR] * 4 + [C.c_int] * 6 + [_PTR]),
     "uaps_conv_bwd_data_cat": (C.c_int, [_PTR, _PTR, _PTR, C.c_int, _PTR, C.c_int] + [C.c_int] * 6 + [_PTR]),
     "uaps_conv_bwd_weight_partial_cat": (C.c_int, [_PTR, _PTR, C.c_int, _PTR, C.c_int] + [C.c_int] * 7 + [_PTR, C.c_size_t, _PTR]),
@@ -167,7 +168,8 @@ def lib() -> C.CDLL:
 # diagnosis scripts set; the library itself reads no environment
 _TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, None), ("UAPS_DIAG_NO_SMALL", 4, None),
              ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"), ("UAPS_FWD_TALL", 64, "0"),
-             ("UAPS_DIAG_NO_ROW16", 128, None), ("UAPS_DIAG_NO_ROW_WRW", 256, None), ("UAPS_DIAG_DEEP_ROWS", 512, None))
+             ("UAPS_DIAG_NO_ROW16", 128, None), ("UAPS_DIAG_NO_ROW_WRW", 256, None), ("UAPS_DIAG_DEEP_ROWS", 512, None),
+             ("UAPS_DIAG_G1_NARROW", 1024, None))
 
 
 def _configure_from_environment(l) -> None:
@@ -182,6 +184,12 @@ def _configure_from_environment(l) -> None:
         if v is not None and (on_value is None or v == on_value):
             flags |= bit
     l.uaps_conv_set_tuning(flags)
+
+
+class WrwReduceItem(C.Structure):
+    """uaps_wrw_reduce_item (include/uaps_hip.h)."""
+    _fields_ = [("workspace", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("H", C.c_int), ("W", C.c_int), ("ks", C.c_int), ("cfg", C.c_int)]
 
 
 class CallHints(C.Structure):

@@ -96,6 +96,8 @@ class _timed:
                     self.name = "conv_hr16wx2_kernel" if W > 256 else "conv_hr16x2_kernel"       # 16 -> 16 + 16 channels: two output tiles of the full-width-row kernel
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
+                if self.name == "conv_g1h_kernel<128>" and (Cin if kind == "bwd_data" else Cout) % 256 == 0 and not (_lib.lib().uaps_conv_get_tuning() & 1024):
+                    self.name = "conv_g1h256_kernel"       # 256 output channels per workgroup (csrc/conv_fwd.hip: launch_g1)
                 if (kind in ("wrw", "wrw_bn") and ks == 3 and W % 256 == 0 and H % 16 == 0 and Cout <= 16 and Cin <= 32 and not (cfg >> 24)
                         and (self.name.startswith("conv_hwrw") or self.name.startswith("conv_small_wrw") or self.name.startswith("conv_wrw_"))
                         and not (_lib.lib().uaps_conv_get_tuning() & (256 | 2))):
@@ -155,6 +157,108 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
         w = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=dev)
         _ws[key] = w
     return w
+
+
+# ---- deferred weight-gradient reductions ---------------------------------------------------------------------------------------
+# A weight gradient is two launches: the matrix kernel that writes per-split partial sums and the fixed-order reduction of them,
+# a 5-6 us launch that is all latency -- ~60 per training step.  Inside `deferred_reduces()` (the trainers open it around forward +
+# backward of a step) every weight gradient keeps its partials in a buffer of its own and the reductions of the whole backward run
+# as one launch per 28 gradients when the scope ends (`flush_weight_reduces`), bit-identical to the single launches.  Until then the
+# gradient tensors autograd has been handed are allocated but NOT written: nothing may read a .grad inside the scope -- which is why
+# it is a scope the step owns (like lazybn.scope) and not a global mode; gradient hooks that send .grad somewhere (the overlapped
+# data-parallel exchange) must not be combined with it (UAPSTrainer does not open it then).
+_deferred: Optional[list] = None
+_DEFER = os.environ.get("UAPS_DEFER_WRW_REDUCE", "1") != "0"
+
+
+def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Weak references to (weight, bias) when their gradients may be written late -- leaf tensors without tensor hooks, whose
+    gradients go straight to AccumulateGrad (a non-leaf weight's gradient, e.g. conv3x3s2's re-arranged kernel, is read by the next
+    autograd node at once) -- else None: that convolution reduces immediately whatever the scope."""
+    for t in (weight, bias):
+        if t is not None and (not t.is_leaf or t._backward_hooks):
+            return None
+    return (weakref.ref(weight), weakref.ref(bias) if bias is not None else None)
+
+
+def _defers(prefs) -> bool:
+    return _deferred is not None and prefs is not None
+
+
+def _wrw_workspace(dev: torch.device, nbytes: int, prefs=None) -> torch.Tensor:
+    if _defers(prefs):
+        return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    return _workspace(dev, nbytes)
+
+
+def _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs=None) -> None:
+    """The reduction of one weight gradient's partials: now, or at the end of the enclosing deferred_reduces() scope (prefs =
+    leaf_refs(weight, bias) of the convolution, same value as given to _wrw_workspace)."""
+    if _defers(prefs):
+        # addresses and storages, not the tensors: AccumulateGrad takes a gradient over as .grad only while nobody else holds it
+        # (it copies otherwise -- here it would copy memory that is not written yet)
+        _deferred.append((ws, dw.data_ptr(), dw.untyped_storage(), dw.device, db.data_ptr() if db is not None else None,
+                          db.untyped_storage() if db is not None else None, B, Cin, Cout, H, W, ks, cfg, prefs))
+        return
+    rc = _lib.lib().uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, B, Cin, Cout,
+                                                H, W, ks, cfg, st)
+    _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+
+
+def flush_weight_reduces() -> int:
+    """Run the pending reductions on the current stream of each device (after the backward has returned, i.e. after autograd has
+    joined its streams); the number of gradients reduced.  Raises if a parameter's .grad is not the buffer its reduction writes
+    (autograd summed or copied the unwritten gradient: a weight used by two convolutions, gradient accumulation over several
+    backward passes -- such training loops set UAPS_DEFER_WRW_REDUCE=0)."""
+    global _deferred
+    if not _deferred:
+        return 0
+    items, _deferred = _deferred, []
+    by_dev: Dict[torch.device, list] = {}
+    for it in items:
+        by_dev.setdefault(it[3], []).append(it)
+    for dev, its in by_dev.items():
+        arr = (_lib.WrwReduceItem * len(its))()
+        for a, (ws, dwp, _dws, _dev, dbp, _dbs, B, Cin, Cout, H, W, ks, cfg, prefs) in zip(arr, its):
+            for ref, ptr in ((prefs[0], dwp), (prefs[1], dbp)):
+                t = ref() if (ref is not None and ptr is not None) else None
+                if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
+                    raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction writes (the "
+                                       "unwritten gradient was summed or copied by autograd: shared weights, or gradient accumulation over "
+                                       "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
+            a.workspace, a.dw, a.dbias = ws.data_ptr(), dwp, dbp
+            a.B, a.Cin, a.Cout, a.H, a.W, a.ks, a.cfg = B, Cin, Cout, H, W, ks, cfg
+        with _lib.device_guard(dev):
+            rc = _lib.lib().uaps_conv_bwd_weight_reduce_batch(arr, len(its), _lib.current_stream(dev))
+        _lib.check(rc, "uaps_conv_bwd_weight_reduce_batch")
+    return len(items)
+
+
+class deferred_reduces:
+    """Scope of a training step's forward + backward: see the comment above.  Not re-entrant across threads; nested scopes join the
+    outer one.  An exception inside drops the pending reductions (their gradients stay unwritten, like the step they belonged to)."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled and _DEFER
+        self.outer = False
+
+    def __enter__(self):
+        global _deferred
+        if self.enabled:
+            self.outer = _deferred is None
+            if self.outer:
+                _deferred = []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _deferred
+        if self.enabled and self.outer:
+            try:
+                if exc_type is None:
+                    flush_weight_reduces()
+            finally:
+                _deferred = None
+        return False
 
 
 def _remember(weight: torch.Tensor, wf, wb) -> None:
@@ -389,7 +493,7 @@ def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg
 
 
 def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None,
-                        dyb=None, xb=None, lz=None):
+                        dyb=None, xb=None, lz=None, prefs=None):
     """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest).
     lz (lazybn.Lazy): `dy` is d(activation) behind the BatchNorm that follows this convolution; the kernel forms the true dy while
     staging and writes it through -- returned as a third value (with its bound) -- or the stand-alone pass does, where the layer's
@@ -401,7 +505,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     n = C.c_size_t()
     cfg = plan_cfg(ks, cfg, True, dy, x)
     _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-    ws = _workspace(dev, n.value)
+    ws = _wrw_workspace(dev, n.value, prefs)
     dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
     db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
     dy_true = None
@@ -427,9 +531,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
                 rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
                                                     ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "uaps_conv_bwd_weight_partial")
-        rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_bias else None, B, Cin, Cout, H, W,
-                                           ks, cfg, st)
-    _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+        _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs)
     if lz is not None:
         return dw, db, dy_true
     return dw, db
@@ -458,6 +560,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, wb)
         ctx.meta = (Cin, Cout, ks, bias is not None, cfg)
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
+        ctx.prefs = leaf_refs(weight, bias)
         ctx.xb = xb = bounds.get(x)
         if want_stats:
             y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True, xb=xb, stat_shift=stat_shift)
@@ -481,11 +584,11 @@ class _Conv2d(torch.autograd.Function):
             dy, lz = lazybn.materialize(dy, lz), None
             dyb = bounds.get(dy)
         if lz is not None:
-            dw, db, dy = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, xb=ctx.xb, lz=lz)
+            dw, db, dy = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, xb=ctx.xb, lz=lz, prefs=ctx.prefs)
             dyb = bounds.get(dy)
         dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb) if ctx.needs_input_grad[0] else None
         if lz is None and want_w:
-            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb)
+            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb, prefs=ctx.prefs)
         return dx, dw, db, None, None, None
 
 
@@ -552,6 +655,7 @@ class _Conv2dCat(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, wb)
         ctx.meta = (C1, C2, Cout, ks, bias is not None, cfg)
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
+        ctx.prefs = leaf_refs(weight, bias)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -588,7 +692,7 @@ class _Conv2dCat(torch.autograd.Function):
             """(dw, db, dy): with a pending transform the kernel writes the true dy through (None: it has no such form here)"""
             n = C.c_size_t()
             _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-            ws = _workspace(dev, n.value)
+            ws = _wrw_workspace(dev, n.value, ctx.prefs)
             dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
             db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
             out = torch.empty_like(dy) if lz is not None else None
@@ -605,9 +709,7 @@ class _Conv2dCat(torch.autograd.Function):
             if lz is not None and rc == lazybn.ENOFORM:
                 return None, None, None
             _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
-            rc = L.uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, C1 + C2, Cout,
-                                               H, W, ks, cfg, st)
-            _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+            _wrw_reduce(ws, dw, db, B, C1 + C2, Cout, H, W, ks, cfg, st, ctx.prefs)
             return dw, db, (bounds.put(out, *lz.bound) if lz is not None else dy)
 
         with _lib.device_guard(dev):

@@ -184,7 +184,8 @@ int launch_g1(ConvFwdArgs a, int bn, hipStream_t s) {
     const long grid = ((long)a.B * a.tiles_x * a.nblk + 7) / 8 * 8;
     if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
     if (a.wscale) {
-        if (bn == 128) UAPS_LAUNCH_MAIN((conv_g1h_kernel<128>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        if (bn == 256) UAPS_LAUNCH_MAIN(conv_g1h256_kernel, dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
+        else if (bn == 128) UAPS_LAUNCH_MAIN((conv_g1h_kernel<128>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
         else UAPS_LAUNCH_MAIN((conv_g1h_kernel<64>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
     } else {
         if (bn == 128) UAPS_LAUNCH_MAIN((conv_g1s_kernel<128>), dim3((unsigned)grid), dim3(kConvThreads), 0, s, a);
@@ -412,7 +413,10 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         }
         if (p.g1) {
             // no two-tensor / BatchNorm-in-staging form of the GEMM-tiled kernels: the 3x3-style tiling (never with statistics, see above)
-            if (!x2 && !y2 && !xf) return launch_g1(a, p.CoutP % 128 == 0 ? 128 : 64, s);
+            if (!x2 && !y2 && !xf) {
+                const bool wide = a.wscale && p.CoutP % 256 == 0 && !(g_conv_tuning & UAPS_TUNE_G1_NARROW);
+                return launch_g1(a, wide ? 256 : (p.CoutP % 128 == 0 ? 128 : 64), s);
+            }
         }
         // 16 -> 32 channels on a 256-wide map without statistics (the input gradient of up4's two-tensor convolution): two output
         // tiles of the full-width-row kernel, written as one or two 16-channel tensors

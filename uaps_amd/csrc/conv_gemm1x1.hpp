@@ -19,7 +19,8 @@
 namespace uaps {
 
 // Diagnostic builds only (make -C uaps_amd/csrc g1abl; tools/diag/g1_ablate.sh): UAPS_G1_ABLATE = 5 drops the staging behind the
-// first chunk, 6 also the barriers, 7 also the LDS fragment reads -- timing only, the results are meaningless.
+// first chunk, 6 also the barriers, 7 also the LDS fragment reads; 1 .. 4 drop ONE part of the staging behind the first chunk
+// (1 the activation loads, 2 the weight loads, 3 the split arithmetic, 4 the LDS stores) -- timing only, the results are meaningless.
 #ifndef UAPS_G1_ABLATE
 #define UAPS_G1_ABLATE 0
 #endif
@@ -65,27 +66,48 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
     const int CGP = a.CinP;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in + (size_t)b * a.Cin * HW, (uint32_t)a.Cin * HW4);
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.wp, (uint32_t)NP * CGP * a.CoutP * 16u);
-    uint32_t wgoff[NWT];
+    // weight unit e = tid + n * 256 -> (piece, k-group g, column); with BN = 256 the column is the thread and (piece, g) are the
+    // same for the whole workgroup: one vector offset + scalar offsets
+    constexpr bool WUNI = BN == kConvThreads;
+    uint32_t wgoff[WUNI ? 1 : NWT];
+    if constexpr (WUNI) wgoff[0] = (uint32_t)(co0 + tid) * 16u;
+    else {
 #pragma unroll
-    for (int n = 0; n < NWT; ++n) {
-        const int e = tid + n * kConvThreads;
-        const int col = e % BN, g = (e / BN) % KG, piece = e / (BN * KG);
-        wgoff[n] = (uint32_t)((piece * CGP + g) * a.CoutP + co0 + col) * 16u;
+        for (int n = 0; n < NWT; ++n) {
+            const int e = tid + n * kConvThreads;
+            const int col = e % BN, g = (e / BN) % KG, piece = e / (BN * KG);
+            wgoff[n] = (uint32_t)((piece * CGP + g) * a.CoutP + co0 + col) * 16u;
+        }
     }
 
     f32x2 rin[8];
     u32x4 rw[NWT];
     u32x4 pk[NP][2];
     auto load_chunk = [&](int ci0) {
+        if (UAPS_G1_ABLATE != 1 || ci0 == 0) {
 #pragma unroll
         for (int c = 0; c < 8; ++c)                   // channels past Cin lie beyond the buffer's range: zeros
             rin[c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_in, uin ? (int)(ugoff + (uint32_t)(ci0 + c) * HW4) : (int)kOob, 0, 0));
+        }
         const uint32_t wbase = (uint32_t)(ci0 / 8) * a.CoutP * 16u;
+        if (UAPS_G1_ABLATE != 2 || ci0 == 0) {
 #pragma unroll
-        for (int n = 0; n < NWT; ++n)
-            rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wgoff[n] + wbase), 0, 0));
+        for (int n = 0; n < NWT; ++n) {
+            if constexpr (WUNI)
+                rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)wgoff[0], (int)(wbase + (uint32_t)(((n / KG) * CGP + n % KG) * a.CoutP) * 16u), 0));
+            else
+                rw[n] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wgoff[n] + wbase), 0, 0));
+        }
+        }
     };
+    bool first_split = true;
     auto split_chunk = [&]() {
+        if (UAPS_G1_ABLATE == 3 && !first_split) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(rin[c]));      // the loads are still awaited
+            return;
+        }
+        first_split = false;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -102,7 +124,16 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
                 }
             }
     };
+    bool first_store = true;
     auto store_chunk = [&]() {
+        if (UAPS_G1_ABLATE == 4 && !first_store) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) { asm volatile("" : "+v"(pk[q][0])); asm volatile("" : "+v"(pk[q][1])); }
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) asm volatile("" : "+v"(rw[n]));
+            return;
+        }
+        first_store = false;
 #pragma unroll
         for (int q = 0; q < NP; ++q) { sA[q * KG * TM + uloff] = pk[q][0]; sA[q * KG * TM + uloff + 1] = pk[q][1]; }
 #pragma unroll
@@ -160,9 +191,9 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
                 for (int p = 0; p < NP; ++p) bfr[n][p] = __builtin_bit_cast(bf16x8, sB[(p * KG + 2 * ks + h) * BN + boff + n * 32]);
 #endif
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int n = 0; n < NTW; ++n)
 #pragma unroll
-                for (int n = 0; n < NTW; ++n) {       // smallest partial products first
+                for (int m = 0; m < 2; ++m) {         // smallest partial products first
                     f32x16 c = acc[m][n];
                     if constexpr (H16) {
                         const auto H = [](const bf16x8& v) { return __builtin_bit_cast(f16x8, v); };
@@ -240,6 +271,9 @@ __device__ __forceinline__ void conv_g1_body(const ConvFwdArgs& a) {
 template <int BN>
 __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))      // 168 registers (the compiler's free choice was 170)
 void conv_g1h_kernel(ConvFwdArgs a) { conv_g1_body<BN, true>(a); }
+// 256 output channels per workgroup (a wave: 64 pixels x 128 channels, 128 accumulator registers, two workgroups per CU): every
+// staged activation element -- the expensive operand: fp32, fetched as 8-byte pieces and split here -- feeds twice the matrix work
+static __global__ __launch_bounds__(kConvThreads, 2) void conv_g1h256_kernel(ConvFwdArgs a) { conv_g1_body<256, true>(a); }
 template <int BN>
 __global__ __launch_bounds__(kConvThreads, 2) void conv_g1s_kernel(ConvFwdArgs a) { conv_g1_body<BN, false>(a); }
 

@@ -739,6 +739,54 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(const float* __res
     }
 }
 
+// The same reduction for up to kReduceBatch weight gradients by ONE launch (uaps_conv_bwd_weight_reduce_batch): a step has ~60 of
+// them, each a 5-6 us launch of mostly latency.  Block -> (item, block of the item) through the prefix table; an item is summed
+// exactly as conv_wrw_reduce_kernel<el> sums it (same lanes, same order): bit-identical results.
+constexpr int kReduceBatch = 28;
+struct ReduceDesc {
+    const float* slab; const float* bslab; float* dw; float* db;
+    int nsplit, taps, Cout, Cin, CoutS, CinS;
+    int el;                 // 16 or 64: elements per block, as the single launch chooses
+    unsigned first;         // first block of this item
+};
+struct ReduceBatch { ReduceDesc d[kReduceBatch]; int n; unsigned blocks; };
+
+static __global__ __launch_bounds__(256) void conv_wrw_reduce_batch_kernel(ReduceBatch rb) {
+    __shared__ float red[256];
+    if (blockIdx.x >= rb.blocks) return;
+    int i = 0;
+    while (i + 1 < rb.n && rb.d[i + 1].first <= blockIdx.x) ++i;      // uniform: <= kReduceBatch scalar compares
+    const ReduceDesc& q = rb.d[i];
+    const int EL = q.el, SL = 256 / EL;
+    const long n = (long)q.taps * q.CoutS * q.CinS;
+    const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
+    const long e = (long)(blockIdx.x - q.first) * EL + el;
+    const bool is_w = e < n, is_b = !is_w && q.bslab != nullptr && e - n < q.CoutS;
+    const float* src = is_w ? q.slab + e : (is_b ? q.bslab + (e - n) : nullptr);
+    const size_t stride = is_w ? (size_t)n : (size_t)q.CoutS;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (src) {
+        int k = sl;
+        for (; k + 3 * SL < q.nsplit; k += 4 * SL) {
+            s0 += src[(size_t)k * stride]; s1 += src[(size_t)(k + SL) * stride];
+            s2 += src[(size_t)(k + 2 * SL) * stride]; s3 += src[(size_t)(k + 3 * SL) * stride];
+        }
+        for (; k < q.nsplit; k += SL) s0 += src[(size_t)k * stride];
+    }
+    red[sl * EL + el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl != 0) return;
+    float s = red[el];
+    for (int r = 1; r < SL; ++r) s += red[r * EL + el];
+    if (is_w) {
+        const int ci = (int)(e % q.CinS); const long r = e / q.CinS;
+        const int co = (int)(r % q.CoutS), t = (int)(r / q.CoutS);
+        if (co < q.Cout && ci < q.Cin) q.dw[((long)co * q.Cin + ci) * q.taps + t] = s;
+    } else if (is_b && q.db && e - n < q.Cout) {
+        q.db[e - n] = s;
+    }
+}
+
 // (weight packing, exact and split layouts: conv_split.hpp)
 
 }  // namespace uaps

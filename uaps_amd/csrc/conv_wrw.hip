@@ -368,6 +368,41 @@ extern "C" int uaps_conv_bwd_weight_reduce(const void* ws, float* dw, float* dbi
     return (int)hipGetLastError();
 }
 
+// Step 2 for several weight gradients at once: item i is reduced exactly as uaps_conv_bwd_weight_reduce(items[i]...) would
+// (bit-identical), by one launch per kReduceBatch items.  The workspaces must be distinct and stay untouched until this call.
+extern "C" int uaps_conv_bwd_weight_reduce_batch(const uaps_wrw_reduce_item* items, int n, uaps_stream_t stream) {
+    if (n < 0 || (n > 0 && !items)) return UAPS_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const uaps_wrw_reduce_item& it = items[i];
+        if (!it.workspace || !it.dw || it.B <= 0 || it.Cin <= 0 || it.Cout <= 0 || it.H <= 0 || it.W <= 0 || (it.ks != 1 && it.ks != 3)) return UAPS_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += kReduceBatch) {
+        ReduceBatch rb{};
+        unsigned blocks = 0;
+        const int m = n - i0 < kReduceBatch ? n - i0 : kReduceBatch;
+        for (int j = 0; j < m; ++j) {
+            const uaps_wrw_reduce_item& it = items[i0 + j];
+            const int taps = it.ks * it.ks;
+            const WrwPlan p = plan_wrw(it.B, it.Cin, it.Cout, it.H, it.W, it.cfg, it.ks);
+            ReduceDesc& q = rb.d[j];
+            q.slab = (const float*)it.workspace;
+            q.bslab = it.dbias ? q.slab + (size_t)p.nsplit * taps * p.CoutS * p.CinS : nullptr;
+            q.dw = it.dw; q.db = it.dbias;
+            q.nsplit = p.nsplit; q.taps = taps; q.Cout = it.Cout; q.Cin = it.Cin; q.CoutS = p.CoutS; q.CinS = p.CinS;
+            const long ne = (long)taps * p.CoutS * p.CinS + (it.dbias ? p.CoutS : 0);
+            q.el = ne < 32768 ? 16 : 64;
+            q.first = blocks;
+            const long nb = (ne + q.el - 1) / q.el;
+            if (nb + blocks > 0x7fffffffL) return UAPS_ERANGE;
+            blocks += (unsigned)nb;
+        }
+        rb.n = m; rb.blocks = blocks;
+        hipLaunchKernelGGL(conv_wrw_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, rb);
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" int uaps_conv_bwd_weight(const float* dy, const float* x, float* dw, float* dbias, int B, int Cin, int Cout, int H,
                                     int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
     if (!dw) return UAPS_EINVAL;

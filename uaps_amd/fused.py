@@ -306,6 +306,7 @@ class _BnActConv(torch.autograd.Function):
         ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
+        ctx.prefs = _conv.leaf_refs(weight, bias)
         ctx.xb = xb
         ctx.lazy_up = lazybn.marked(y) and y.requires_grad      # y's producer applies a pending BatchNorm transform (and will run): the backward hands d(activation) up
         if want_stats:
@@ -329,7 +330,7 @@ class _BnActConv(torch.autograd.Function):
         L = _lib.lib()
         n = C.c_size_t()
         _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-        cws = _conv._workspace(dev, n.value)
+        cws = _conv._wrw_workspace(dev, n.value, ctx.prefs)
         dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
         want_db = has_bias and ctx.needs_input_grad[13]
         db = _graddest.take(ctx.keys[4], (Cout,), dev) if want_db else None
@@ -351,9 +352,7 @@ class _BnActConv(torch.autograd.Function):
                 if lz is not None and rc == lazybn.ENOFORM:
                     return None
                 _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
-                rc = L.uaps_conv_bwd_weight_reduce(cws.data_ptr(), dw.data_ptr(), db.data_ptr() if want_db else None, B, Cc, Cout, H, W,
-                                                   ks, cfg, st)
-                _lib.check(rc, "uaps_conv_bwd_weight_reduce")
+                _conv._wrw_reduce(cws, dw, db, B, Cc, Cout, H, W, ks, cfg, st, ctx.prefs)
             return bounds.put(out, *lz.bound) if lz is not None else dz
 
         done_w = False

@@ -14,7 +14,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib, lazybn
+from . import _lib, conv, lazybn
 from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
@@ -106,12 +106,20 @@ class UAPSTrainer:
                 self.optimizer.from_step_state = prev
         return self._eager_step(x_l, y_l, x_u, w)
 
+    def _hooks_exchange(self) -> bool:
+        """True when gradient hooks launch the data-parallel exchange from inside the backward (they read .grad there)."""
+        b = self.buckets
+        return b is not None and b.overlap and not (b.defer or b.muted)
+
     def _eager_step(self, x_l, y_l, x_u, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:                      # model.train() walks ~2600 modules: only when the mode changes
             self.model.train()
         cw1, cw2 = self.consistency_weights()
-        with lazybn.scope():                             # forward + backward of a step this trainer drives itself: the two-halves BatchNorm backward may run
-            if self.pair_forward and x_l.shape == x_u.shape:
+        # forward + backward of a step this trainer drives itself: the two-halves BatchNorm backward may run, and the weight-gradient
+        # reductions run batched behind the backward unless gradient hooks launch the data-parallel exchange from inside it
+        pair = self.pair_forward and x_l.shape == x_u.shape       # (two forwards of one model: autograd sums the two gradients of a weight)
+        with lazybn.scope(), conv.deferred_reduces(pair and not self._hooks_exchange()):
+            if pair:
                 both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
                 if w is None:
                     w = self.mix_rng.dirichlet(np.ones(len(both)), size=1)[0]        # :251
@@ -304,7 +312,7 @@ class BaselineTrainer(UAPSTrainer):
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u=None, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:
             self.model.train()
-        with lazybn.scope():
+        with lazybn.scope(), conv.deferred_reduces(not self._hooks_exchange()):
             out = self.model(x_l)                                                 # baseline_train.py:158
             main = out[0] if isinstance(out, (tuple, list)) else out
             s = losses.uaps_sup_loss((main,), y_l)                                # :161-164, 0.5 * (dice + CE)
