@@ -380,3 +380,24 @@ def test_a_failing_backward_drops_the_pending_reductions():
     conv.conv2d(x, w, None).sum().backward()
     ref = torch.nn.grad.conv2d_weight(x.detach().cpu().double(), w.shape, torch.ones(2, 16, 32, 32, dtype=torch.float64), padding=1)
     np.testing.assert_allclose(w.grad.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-4)
+
+
+def test_a_parameter_with_a_foreign_gradient_hook_or_a_derived_weight_is_reduced_at_once():
+    """Deferral is for leaf parameters nobody watches: a post-accumulate hook of the caller's reads the true gradient inside the
+    backward, and the gradient of a non-leaf weight (read by the next autograd node) is complete when it is handed over."""
+    from uaps_amd import conv
+    torch.manual_seed(2)
+    x = torch.randn(2, 8, 32, 32, device=DEV)
+    w = torch.randn(16, 8, 3, 3, device=DEV, requires_grad=True)
+    ref = torch.nn.grad.conv2d_weight(x.cpu().double(), w.shape, torch.ones(2, 16, 32, 32, dtype=torch.float64), padding=1).numpy()
+    seen = []
+    w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.detach().clone()))
+    with conv.deferred_reduces():
+        conv.conv2d(x, w, None).sum().backward()
+        assert not conv._deferred
+    np.testing.assert_allclose(seen[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
+    v = torch.randn(16, 8, 3, 3, device=DEV, requires_grad=True)
+    with conv.deferred_reduces():
+        conv.conv2d(x, v * 2.0, None).sum().backward()          # the weight is a non-leaf: its gradient feeds the multiplication's backward
+        assert not conv._deferred
+    np.testing.assert_allclose(v.grad.cpu().numpy(), 2.0 * ref, rtol=2e-5, atol=4e-4)

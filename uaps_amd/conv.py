@@ -172,11 +172,16 @@ _DEFER = os.environ.get("UAPS_DEFER_WRW_REDUCE", "1") != "0"
 
 
 def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
-    """Weak references to (weight, bias) when their gradients may be written late -- leaf tensors without tensor hooks, whose
-    gradients go straight to AccumulateGrad (a non-leaf weight's gradient, e.g. conv3x3s2's re-arranged kernel, is read by the next
+    """Weak references to (weight, bias) when their gradients may be written late -- leaf tensors without tensor hooks and without
+    foreign post-accumulate hooks (dist.GradBuckets' own are known), whose gradients go straight to AccumulateGrad (a non-leaf weight's gradient, e.g. conv3x3s2's re-arranged kernel, is read by the next
     autograd node at once) -- else None: that convolution reduces immediately whatever the scope."""
     for t in (weight, bias):
-        if t is not None and (not t.is_leaf or t._backward_hooks):
+        if t is None:
+            continue
+        if not t.is_leaf or t._backward_hooks:
+            return None
+        post = getattr(t, "_post_accumulate_grad_hooks", None)      # a foreign hook may read .grad inside the backward
+        if post and any(not getattr(h, "_uaps_bucket", False) for h in post.values()):
             return None
     return (weakref.ref(weight), weakref.ref(bias) if bias is not None else None)
 

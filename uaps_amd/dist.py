@@ -104,6 +104,7 @@ class GradBuckets:
             self._pending[bi] -= 1
             if self._pending[bi] == 0:
                 self._launch(bi)
+        hook._uaps_bucket = True               # conv.leaf_refs: this hook reads .grad only when it launches the exchange (the trainers know when)
         return hook
 
     def _view(self, bi: int, k: int) -> torch.Tensor:
