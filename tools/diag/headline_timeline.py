@@ -27,3 +27,16 @@ for si in range(skip, min(len(starts) - 1, skip + 3)):
     busy = sum(e - s for s, e, _ in seg)
     print(f"step {si}: wall {(t1 - t0) / 1e6:.3f} ms, {len(seg)} kernels, sum of kernel durations {busy / 1e6:.3f} ms, idle {idle / 1e6:.3f} ms, exactly one kernel running {alone / 1e6:.3f} ms")
     print("   longest alone: " + ", ".join(f"{k[:40]} {v / 1e3:.0f} us" for k, v in alone_by.most_common(12)))
+    # phases by marker kernels: encoder forward (.. last fan-out), decoders forward (.. loss forward), decoders backward (loss backward
+    # .. first fan-in), encoder backward + optimizer (first fan-in .. end)
+    def first(name, lo=0): return next((k for k in seg if k[2].startswith(name) and k[0] >= lo), None)
+    def last(name): return next((k for k in reversed(seg) if k[2].startswith(name)), None)
+    fo, pf, pb, fi = last("fanout_perturbed"), first("pair_fwd"), first("pair_bwd"), first("fanin_perturbed")
+    if fo and pf and pb and fi:
+        marks = [("encoder forward", t0, fo[1]), ("decoders forward", fo[1], pf[0]), ("loss", pf[0], pb[1]), ("decoders backward", pb[1], fi[0]),
+                 ("encoder backward + optimizer", fi[0], t1)]
+        out = []
+        for name, a, b in marks:
+            inside = [(max(s_, a), min(e_, b)) for s_, e_, _ in seg if e_ > a and s_ < b]
+            out.append(f"{name} {(b - a) / 1e3:.0f} us ({len([1 for s_, e_, _ in seg if a <= s_ < b])} launches, kernel time {sum(e_ - s_ for s_, e_ in inside) / 1e3:.0f})")
+        print("   phases: " + "; ".join(out))

@@ -210,33 +210,72 @@ def _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs=None) -> None
     _lib.check(rc, "uaps_conv_bwd_weight_reduce")
 
 
+_early: Optional[tuple] = None        # (side stream, items) of the scope's early flush, until the final one has joined the stream
+_reduce_streams: Dict[int, "torch.cuda.Stream"] = {}
+_EARLY = os.environ.get("UAPS_EARLY_WRW_REDUCE", "1") != "0"
+
+
+def _launch_reduces(items: list, dev: torch.device) -> None:
+    arr = (_lib.WrwReduceItem * len(items))()
+    for a, (ws, dwp, _dws, _dev, dbp, _dbs, B, Cin, Cout, H, W, ks, cfg, _prefs) in zip(arr, items):
+        a.workspace, a.dw, a.dbias = ws.data_ptr(), dwp, dbp
+        a.B, a.Cin, a.Cout, a.H, a.W, a.ks, a.cfg = B, Cin, Cout, H, W, ks, cfg
+    with _lib.device_guard(dev):
+        rc = _lib.lib().uaps_conv_bwd_weight_reduce_batch(arr, len(items), _lib.current_stream(dev))
+    _lib.check(rc, "uaps_conv_bwd_weight_reduce_batch")
+
+
+def early_flush() -> int:
+    """Called by the backward of a feature fan-out (perturb._FanOut): when the first of them runs -- the deepest feature's, whose
+    gradient needs every decoder's whole backward -- all decoder weight gradients have their partials queued and the calling stream
+    has been made to wait for the decoder streams by autograd.  Their reductions (most of the step's: 52 of 62 in the U-Net) go to a
+    side stream here and run beside the encoder's backward, where the chip has one kernel at a time, instead of alone behind it; the
+    scope's final flush joins the stream.  Once per scope; nothing outside a scope."""
+    global _early
+    if not _EARLY or not _deferred or _early is not None:
+        return 0
+    dev = _deferred[0][3]
+    if any(it[3] != dev for it in _deferred):
+        return 0
+    side = _reduce_streams.get(dev.index)
+    if side is None:
+        side = _reduce_streams[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    items = list(_deferred)
+    with torch.cuda.stream(side):
+        _launch_reduces(items, dev)
+    _early = (side, items)              # the partials' buffers stay alive until the final flush has joined the side stream
+    _deferred.clear()
+    return len(items)
+
+
 def flush_weight_reduces() -> int:
     """Run the pending reductions on the current stream of each device (after the backward has returned, i.e. after autograd has
-    joined its streams); the number of gradients reduced.  Raises if a parameter's .grad is not the buffer its reduction writes
-    (autograd summed or copied the unwritten gradient: a weight used by two convolutions, gradient accumulation over several
-    backward passes -- such training loops set UAPS_DEFER_WRW_REDUCE=0)."""
-    global _deferred
-    if not _deferred:
-        return 0
-    items, _deferred = _deferred, []
-    by_dev: Dict[torch.device, list] = {}
-    for it in items:
-        by_dev.setdefault(it[3], []).append(it)
-    for dev, its in by_dev.items():
-        arr = (_lib.WrwReduceItem * len(its))()
-        for a, (ws, dwp, _dws, _dev, dbp, _dbs, B, Cin, Cout, H, W, ks, cfg, prefs) in zip(arr, its):
-            for ref, ptr in ((prefs[0], dwp), (prefs[1], dbp)):
-                t = ref() if (ref is not None and ptr is not None) else None
-                if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
-                    raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction writes (the "
-                                       "unwritten gradient was summed or copied by autograd: shared weights, or gradient accumulation over "
-                                       "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
-            a.workspace, a.dw, a.dbias = ws.data_ptr(), dwp, dbp
-            a.B, a.Cin, a.Cout, a.H, a.W, a.ks, a.cfg = B, Cin, Cout, H, W, ks, cfg
-        with _lib.device_guard(dev):
-            rc = _lib.lib().uaps_conv_bwd_weight_reduce_batch(arr, len(its), _lib.current_stream(dev))
-        _lib.check(rc, "uaps_conv_bwd_weight_reduce_batch")
-    return len(items)
+    joined its streams) and join the early flush's side stream; the number of gradients reduced in the scope.  Raises if a
+    parameter's .grad is not the buffer its reduction wrote (autograd summed or copied the unwritten gradient: a weight used by two
+    convolutions, gradient accumulation over several backward passes -- such training loops set UAPS_DEFER_WRW_REDUCE=0)."""
+    global _deferred, _early
+    early, _early = _early, None
+    done = []
+    if early is not None:
+        side, done = early
+        torch.cuda.current_stream(done[0][3]).wait_stream(side)
+    if _deferred:
+        items, _deferred = _deferred, []
+        by_dev: Dict[torch.device, list] = {}
+        for it in items:
+            by_dev.setdefault(it[3], []).append(it)
+        for dev, its in by_dev.items():
+            _launch_reduces(its, dev)
+        done = done + items
+    for (_ws, dwp, _dws, _dev, dbp, _dbs, *_dims, prefs) in done:
+        for ref, ptr in ((prefs[0], dwp), (prefs[1], dbp)):
+            t = ref() if (ref is not None and ptr is not None) else None
+            if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
+                raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction wrote (the "
+                                   "unwritten gradient was summed or copied by autograd: shared weights, or gradient accumulation over "
+                                   "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
+    return len(done)
 
 
 class deferred_reduces:
@@ -256,13 +295,15 @@ class deferred_reduces:
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        global _deferred
+        global _deferred, _early
         if self.enabled and self.outer:
             try:
                 if exc_type is None:
                     flush_weight_reduces()
+                elif _early is not None:          # a failed step: the side stream's launches are joined, nothing else is reduced
+                    torch.cuda.current_stream(_early[1][0][3]).wait_stream(_early[0])
             finally:
-                _deferred = None
+                _deferred, _early = None, None
         return False
 
 

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, bounds
+from . import conv as _conv
 
 
 # Captured steps (trainer graph mode) cannot take a fresh host number per replay: with DEVICE_THRESHOLDS the FeatureDropout
@@ -414,6 +415,7 @@ class _PerturbFan(torch.autograd.Function):
         live = [(g.contiguous(), modes[i], offsets[i], ctx.keeps[i]) for i, g in enumerate(grads) if g is not None]
         if not live:
             return None, None, None, None, None, None
+        _conv.early_flush()                 # (a training step's scope: the decoders' weight-gradient reductions start beside the encoder's backward)
         if live[0][1] == 4:                 # the output buffer takes its shape from the first entry: keep a full-size one first
             live.append(live.pop(0))
         dev = live[0][0].device
