@@ -367,10 +367,28 @@ def stats_parts_per_image(B: int, Cin: int, Cout: int, H: int, W: int, ks: int, 
     return n
 
 
-def pack_all(weights) -> None:
+_pack_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def pack_all_beside(weights, dev: torch.device):
+    """pack_all(weights) on a side stream that starts behind the current one: the caller goes on with work that does not read these
+    weights (UNet_UAPS: the encoder's forward, while the decoders' weights -- 70 % of the step's packing -- are packed) and makes the
+    consumer wait for the returned stream (None: nothing was stale, nothing launched)."""
+    if pack_all(weights, dry=True) == 0:
+        return None
+    side = _pack_streams.get(dev.index)
+    if side is None:
+        side = _pack_streams[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        pack_all(weights)
+    return side
+
+
+def pack_all(weights, dry: bool = False) -> int:
     """Pack every stale weight of `weights` (conv parameters [Cout,Cin,k,k] on one device) with ONE kernel launch
     per 64 convolutions instead of one launch each; pack_weights() then finds them in the cache.  UNet_UAPS calls this
-    at the start of a forward, i.e. once per optimizer step."""
+    at the start of a forward, i.e. once per optimizer step.  Returns the number of stale weights (dry: counts only)."""
     todo = []
     for wt in weights:
         ent = _packed.get(id(wt))
@@ -378,8 +396,8 @@ def pack_all(weights) -> None:
                 and ent[4] is not None:
             continue
         todo.append(wt)
-    if not todo:
-        return
+    if not todo or dry:
+        return len(todo)
     L = _lib.lib()
     dev = todo[0].device
     n = len(todo)
@@ -407,6 +425,7 @@ def pack_all(weights) -> None:
     _lib.check(rc, "uaps_conv_pack_weights_batch")
     for wt, (_, wf, wb) in zip(todo, bufs):
         _remember(wt, wf, wb)
+    return len(todo)
 
 
 def _h16(*bs) -> bool:

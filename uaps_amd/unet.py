@@ -31,6 +31,7 @@ LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
 _EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switches for tools/ab_bench.sh
 _VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 _FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
+_PACK_BESIDE = os.environ.get("UAPS_PACK_BESIDE", "1") != "0"      # the decoders' weights are packed on a side stream beside the encoder's forward
 _FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
 _FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
 # One HIP stream per auxiliary decoder (see UNet_UAPS.forward): +5 % images/s on the bench step, opt-in because kernels of
@@ -234,6 +235,7 @@ class UNet_UAPS(nn.Module):
             setattr(self, f"aux_decoder{i}", Decoder(class_num, feature_chns))
         self._noise = perturb.FeatureNoise()
         self._conv_weights = None
+        self._pack_split = None
         self._bns = None
         self._streams = None
 
@@ -275,10 +277,19 @@ class UNet_UAPS(nn.Module):
     def forward(self, x, perturbations=None, _groups: int = 1):
         """`perturbations`: optional list (one entry per auxiliary decoder) of callables
         feats -> feats replacing the random draws (parity tests inject recorded draws here)."""
+        packing = None
         if x.is_cuda:                            # all conv weights packed by one launch (once per optimizer step)
             if self._conv_weights is None:
                 self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
-            conv.pack_all(self._conv_weights)
+            if _PACK_BESIDE and perturbations is None and self.n_aux > 0 and _FUSED_FAN:
+                # the encoder's weights now, the decoders' (70 % of the packing) on a side stream beside the encoder's forward
+                if self._pack_split is None:
+                    enc = {id(m.weight) for m in self.encoder.modules() if isinstance(m, nn.Conv2d)}
+                    self._pack_split = ([w for w in self._conv_weights if id(w) in enc], [w for w in self._conv_weights if id(w) not in enc])
+                conv.pack_all(self._pack_split[0])
+                packing = conv.pack_all_beside(self._pack_split[1], x.device)
+            else:
+                conv.pack_all(self._conv_weights)
             if self.training:                        # bounds of the train-mode BatchNorm outputs (conv mode 'h16')
                 if self._bns is None:
                     self._bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
@@ -299,6 +310,8 @@ class UNet_UAPS(nn.Module):
                     f = blk.maxpool_conv[1](fan[-1]) if pool else blk(f)
             per_dec = [[fan[d] for fan in fans] for d in range(1 + self.n_aux)]
             decoders = [self.main_decoder] + self.aux_decoders()
+            if packing is not None:
+                torch.cuda.current_stream(x.device).wait_stream(packing)      # the decoders' packed weights
             if not _DECODER_STREAMS:
                 return tuple(dec(per_dec[d]) for d, dec in enumerate(decoders))
             # The decoders are independent chains of ~60 launches each: every auxiliary decoder gets its own HIP stream
