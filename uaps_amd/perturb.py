@@ -10,6 +10,7 @@ forms take recorded draws, for parity tests against the reference.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Dict, Optional, Tuple
@@ -298,6 +299,7 @@ def FeatureDropout(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
 # ---- all decoders' views of one encoder feature map, with a fused backward ---------------------------------
 
 _KIND_MODE = {"noise": 1, "dropout": 2, "feature_dropout": 3}
+_fan_side = None          # set by UNet_UAPS.forward around its encoder loop: the stream the perturbed copies are written on (None: the caller's)
 _FUSED_FANOUT = os.environ.get("UAPS_FUSED_FANOUT", "1") != "0"      # A/B switch for tools/ab_bench.sh
 
 
@@ -349,20 +351,29 @@ class _PerturbFan(torch.autograd.Function):
                         offsets.append([0] * groups); keeps.append(kp[i])
             with _lib.device_guard(dev):
                 st = _lib.current_stream(dev)
-                if ws is not None:
-                    _lib.check(L.uaps_feat_dropout_stats(f.data_ptr(), B, Cc, H, W, ws.data_ptr(), ws.numel(), st), "uaps_feat_dropout_stats")
-                rc = L.uaps_fanout_perturbed(f.data_ptr(), (C.c_void_p * n)(*[y.data_ptr() for y in ys]),
-                                             (C.c_int * n)(*[_KIND_MODE[k] for k in kinds]),
-                                             (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in kp]),
-                                             (C.c_uint64 * (n * groups))(*[o for offs in offsets[1:] for o in offs]),
-                                             (C.c_float * groups)(*us), ws.data_ptr() if ws is not None else None, n, groups, seed,
-                                             float(noise_range), float(drop_p), B, Cc, H, W, st)
-                _lib.check(rc, "uaps_fanout_perturbed")
-                outs.extend(ys)
-                if with_pool:
+                pooled = idx = None
+                if with_pool:                # first: the next encoder level waits for this alone
                     pooled = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=dev)
                     idx = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.uint8, device=dev)
                     _lib.check(L.uaps_maxpool2x2_fwd(f.data_ptr(), B, Cc, H, W, pooled.data_ptr(), idx.data_ptr(), st), "uaps_maxpool2x2_fwd")
+                # the perturbed copies are read by the decoders only: with a side stream set (UNet_UAPS.forward, decoder-stream mode) they
+                # are written beside the encoder's next levels, and the caller makes the decoders wait for that stream
+                side = _fan_side if (_fan_side is not None and _fan_side.device == dev) else None
+                if side is not None:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    st2 = _lib.current_stream(dev)
+                    if ws is not None:
+                        _lib.check(L.uaps_feat_dropout_stats(f.data_ptr(), B, Cc, H, W, ws.data_ptr(), ws.numel(), st2), "uaps_feat_dropout_stats")
+                    rc = L.uaps_fanout_perturbed(f.data_ptr(), (C.c_void_p * n)(*[y.data_ptr() for y in ys]),
+                                                 (C.c_int * n)(*[_KIND_MODE[k] for k in kinds]),
+                                                 (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in kp]),
+                                                 (C.c_uint64 * (n * groups))(*[o for offs in offsets[1:] for o in offs]),
+                                                 (C.c_float * groups)(*us), ws.data_ptr() if ws is not None else None, n, groups, seed,
+                                                 float(noise_range), float(drop_p), B, Cc, H, W, st2)
+                    _lib.check(rc, "uaps_fanout_perturbed")
+                outs.extend(ys)
+                if with_pool:
                     outs.append(pooled); offsets.append([0] * groups); keeps.append(idx)
             ctx.meta = (tuple(kinds), groups, seed, float(noise_range), float(drop_p), offsets, (B, Cc, H, W), bool(with_pool))
             ctx.keeps = keeps

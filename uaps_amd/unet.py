@@ -31,6 +31,7 @@ LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
 _EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switches for tools/ab_bench.sh
 _VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 _FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
+_FAN_BESIDE = os.environ.get("UAPS_FAN_BESIDE", "1") != "0"        # the perturbed feature copies are written on a side stream beside the encoder's next levels
 _PACK_BESIDE = os.environ.get("UAPS_PACK_BESIDE", "1") != "0"      # the decoders' weights are packed on a side stream beside the encoder's forward
 _FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
 _FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
@@ -236,6 +237,7 @@ class UNet_UAPS(nn.Module):
         self._noise = perturb.FeatureNoise()
         self._conv_weights = None
         self._pack_split = None
+        self._fan_stream = None
         self._bns = None
         self._streams = None
 
@@ -300,14 +302,27 @@ class UNet_UAPS(nn.Module):
             # routes the pooled gradient to its arg-max positions and sums (perturb._PerturbFan)
             kinds = [_PERTURBATIONS[i % 3] for i in range(self.n_aux)]
             enc = self.encoder
+            fan_side = None
+            if _DECODER_STREAMS and _FAN_BESIDE:
+                # the perturbed copies of a feature map feed the auxiliary decoders only: written on a side stream beside the encoder's
+                # next levels (the max-pool, which the next level waits for, is launched first on this stream)
+                if self._fan_stream is None or self._fan_stream.device != x.device:
+                    self._fan_stream = torch.cuda.Stream(device=x.device)
+                fan_side = self._fan_stream
             fans, f = [], enc.in_conv(x)
-            for blk in (enc.down1, enc.down2, enc.down3, enc.down4, None):
-                # (the fan-in kernel sums at most 8 gradients: clean + n_aux perturbed + the pooled one)
-                pool = blk is not None and _FUSED_POOL and f.shape[2] % 2 == 0 and f.shape[3] % 8 == 0 and self.n_aux + 2 <= 8
-                fan = perturb.perturbed_fan_out(f, kinds, _groups, self._noise.uniform_range, with_pool=pool)
-                fans.append(fan)
-                if blk is not None:
-                    f = blk.maxpool_conv[1](fan[-1]) if pool else blk(f)
+            perturb._fan_side = fan_side
+            try:
+                for blk in (enc.down1, enc.down2, enc.down3, enc.down4, None):
+                    # (the fan-in kernel sums at most 8 gradients: clean + n_aux perturbed + the pooled one)
+                    pool = blk is not None and _FUSED_POOL and f.shape[2] % 2 == 0 and f.shape[3] % 8 == 0 and self.n_aux + 2 <= 8
+                    fan = perturb.perturbed_fan_out(f, kinds, _groups, self._noise.uniform_range, with_pool=pool)
+                    fans.append(fan)
+                    if blk is not None:
+                        f = blk.maxpool_conv[1](fan[-1]) if pool else blk(f)
+            finally:
+                perturb._fan_side = None
+            if fan_side is not None:
+                torch.cuda.current_stream(x.device).wait_stream(fan_side)
             per_dec = [[fan[d] for fan in fans] for d in range(1 + self.n_aux)]
             decoders = [self.main_decoder] + self.aux_decoders()
             if packing is not None:
