@@ -210,6 +210,7 @@ def _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs=None) -> None
     _lib.check(rc, "uaps_conv_bwd_weight_reduce")
 
 
+_early_hook = None                    # deferred_reduces(on_early=...): called on the side stream behind the early flush's launches
 _early: Optional[tuple] = None        # (side stream, items) of the scope's early flush, until the final one has joined the stream
 _reduce_streams: Dict[int, "torch.cuda.Stream"] = {}
 _EARLY = os.environ.get("UAPS_EARLY_WRW_REDUCE", "1") != "0"
@@ -244,6 +245,8 @@ def early_flush() -> int:
     items = list(_deferred)
     with torch.cuda.stream(side):
         _launch_reduces(items, dev)
+        if _early_hook is not None:     # (UAPSTrainer: Adam for the parameters whose gradients are final now, behind their reductions)
+            _early_hook()
     _early = (side, items)              # the partials' buffers stay alive until the final flush has joined the side stream
     _deferred.clear()
     return len(items)
@@ -282,20 +285,22 @@ class deferred_reduces:
     """Scope of a training step's forward + backward: see the comment above.  Not re-entrant across threads; nested scopes join the
     outer one.  An exception inside drops the pending reductions (their gradients stay unwritten, like the step they belonged to)."""
 
-    def __init__(self, enabled: bool = True):
+    def __init__(self, enabled: bool = True, on_early=None):
         self.enabled = enabled and _DEFER
         self.outer = False
+        self.on_early = on_early
 
     def __enter__(self):
-        global _deferred
+        global _deferred, _early_hook
         if self.enabled:
             self.outer = _deferred is None
             if self.outer:
                 _deferred = []
+                _early_hook = self.on_early
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        global _deferred, _early
+        global _deferred, _early, _early_hook
         if self.enabled and self.outer:
             try:
                 if exc_type is None:
@@ -303,7 +308,7 @@ class deferred_reduces:
                 elif _early is not None:          # a failed step: the side stream's launches are joined, nothing else is reduced
                     torch.cuda.current_stream(_early[1][0][3]).wait_stream(_early[0])
             finally:
-                _deferred, _early = None, None
+                _deferred, _early, _early_hook = None, None, None
         return False
 
 

@@ -122,7 +122,7 @@ class StepGraph:
         """Forward, loss block and backward; every per-step scalar comes from the step state (w = None, cw = NaN)."""
         tr = self.tr
         perturb._RngState.offset = 0                 # the key changes every step: the counters may restart (and must, for replays)
-        with lazybn.scope(), conv.deferred_reduces(not tr._hooks_exchange()):
+        with lazybn.scope(), conv.deferred_reduces(not tr._hooks_exchange(), on_early=tr._early_adam()):
             both = tr.model.forward_pair(x_l, x_u)
             out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
             tr.optimizer.zero_grad(set_to_none=True)

@@ -19,6 +19,8 @@ from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
 
+_EARLY_ADAM = os.environ.get("UAPS_EARLY_ADAM", "1") != "0"      # the decoders' Adam step beside the encoder's backward (world size 1)
+
 
 class UAPSTrainer:
     def __init__(self, model: torch.nn.Module, base_lr: float = 1e-3, consistency1: float = 0.1,
@@ -36,6 +38,7 @@ class UAPSTrainer:
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="max", min_lr=1e-8, patience=50)
         self.c1, self.c2, self.rampup, self.ramp_divisor = consistency1, consistency2, consistency_rampup, ramp_divisor
         self.iter_num = 0
+        self._late_params = None                         # model.decoder_parameters() (_early_adam), asked at the first step
         self.n_heads = len(list(model.aux_decoders())) + 1 if hasattr(model, "aux_decoders") else 1
         # the Dirichlet mixing weights must be the same on every rank: a private, identically seeded stream
         self.mix_rng = np.random.RandomState(seed)
@@ -106,6 +109,20 @@ class UAPSTrainer:
                 self.optimizer.from_step_state = prev
         return self._eager_step(x_l, y_l, x_u, w)
 
+    def _early_adam(self):
+        """deferred_reduces(on_early=...): Adam for the parameters `model.decoder_parameters()` names -- their gradients are final when
+        the encoder's part of the backward begins -- on the early flush's side stream; optimizer.step() then takes the rest.
+        None (no early step) for data-parallel runs (the exchange comes first), models without that method, foreign optimizers."""
+        if not _EARLY_ADAM or self.buckets is not None or not hasattr(self.optimizer, "step_early"):
+            return None
+        if self._late_params is None:
+            m = self.model.module if hasattr(self.model, "module") and not hasattr(self.model, "decoder_parameters") else self.model
+            fn = getattr(m, "decoder_parameters", None)           # the model says which gradients are final at the first fan-in
+            self._late_params = tuple(fn()) if callable(fn) else ()
+        if not self._late_params:
+            return None
+        return lambda: self.optimizer.step_early(self._late_params)
+
     def _hooks_exchange(self) -> bool:
         """True when gradient hooks launch the data-parallel exchange from inside the backward (they read .grad there)."""
         b = self.buckets
@@ -118,7 +135,7 @@ class UAPSTrainer:
         # forward + backward of a step this trainer drives itself: the two-halves BatchNorm backward may run, and the weight-gradient
         # reductions run batched behind the backward unless gradient hooks launch the data-parallel exchange from inside it
         pair = self.pair_forward and x_l.shape == x_u.shape       # (two forwards of one model: autograd sums the two gradients of a weight)
-        with lazybn.scope(), conv.deferred_reduces(pair and not self._hooks_exchange()):
+        with lazybn.scope(), conv.deferred_reduces(pair and not self._hooks_exchange(), on_early=self._early_adam()):
             if pair:
                 both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
                 if w is None:

@@ -241,6 +241,11 @@ class UNet_UAPS(nn.Module):
         self._bns = None
         self._streams = None
 
+    def decoder_parameters(self):
+        """The parameters whose gradients are complete when the backward of the deepest feature's fan-out runs (every decoder's whole
+        backward is in front of it): UAPSTrainer steps them beside the encoder's backward."""
+        return [p for dec in [self.main_decoder] + self.aux_decoders() for p in dec.parameters()]
+
     def aux_decoders(self) -> List[Decoder]:
         return [getattr(self, f"aux_decoder{i}") for i in range(1, self.n_aux + 1)]
 
