@@ -604,7 +604,9 @@ def main():
                          "step_hbm_GBps": round(step_bytes / ms_per_step / 1e6, 1) if step_bytes else None,
                          "step_hbm_frac": round(step_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS, 4) if step_bytes else None})
         step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
-        mode = "single stream" if args.single_stream else "one HIP stream per auxiliary decoder (same kernels as single-stream)"
+        mode = "single stream" if args.single_stream else ("one HIP stream per auxiliary decoder + side streams for work off the critical path (the decoders' "
+                                                           "weight packing and the perturbed feature copies beside the encoder's forward; the decoders' "
+                                                           "weight-gradient reductions and Adam step beside the encoder's backward); same kernels and results as single-stream")
         if graph_used and not graph_split:
             mode = "captured hipGraph of the whole step, replayed once per step (the eager step's kernels and arithmetic; DESIGN.md section 4 on bit reproducibility); " + mode
         elif graph_split:

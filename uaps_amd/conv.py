@@ -235,6 +235,9 @@ def early_flush() -> int:
     global _early
     if not _EARLY or not _deferred or _early is not None:
         return 0
+    from . import unet
+    if not unet._DECODER_STREAMS:        # single-stream mode: every launch on the caller's stream
+        return 0
     dev = _deferred[0][3]
     if any(it[3] != dev for it in _deferred):
         return 0

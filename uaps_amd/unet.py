@@ -288,7 +288,7 @@ class UNet_UAPS(nn.Module):
         if x.is_cuda:                            # all conv weights packed by one launch (once per optimizer step)
             if self._conv_weights is None:
                 self._conv_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d)]
-            if _PACK_BESIDE and perturbations is None and self.n_aux > 0 and _FUSED_FAN:
+            if _PACK_BESIDE and _DECODER_STREAMS and perturbations is None and self.n_aux > 0 and _FUSED_FAN:
                 # the encoder's weights now, the decoders' (70 % of the packing) on a side stream beside the encoder's forward
                 if self._pack_split is None:
                     enc = {id(m.weight) for m in self.encoder.modules() if isinstance(m, nn.Conv2d)}
