@@ -31,6 +31,7 @@ LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
 _EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switches for tools/ab_bench.sh
 _VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
 _FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
+_DECODER_CHAINS = max(2, int(os.environ.get("UAPS_DECODER_CHAINS", "8")))      # diagnosis: decoders are dealt round-robin onto this many streams (main included)
 _FAN_BESIDE = os.environ.get("UAPS_FAN_BESIDE", "1") != "0"        # the perturbed feature copies are written on a side stream beside the encoder's next levels
 _PACK_BESIDE = os.environ.get("UAPS_PACK_BESIDE", "1") != "0"      # the decoders' weights are packed on a side stream beside the encoder's forward
 _FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
@@ -353,8 +354,12 @@ class UNet_UAPS(nn.Module):
             # are simply kept until the next capture (their private-pool addresses are the graph's own anyway).
             capturing = torch.cuda.is_current_stream_capturing()
             keep = []
+            on_main = []
             for d in range(1, len(decoders)):
-                side = self._streams[d - 1]
+                if d % _DECODER_CHAINS == 0:         # (diagnosis: fewer chains than decoders -- this one shares the main stream)
+                    on_main.append(d)
+                    continue
+                side = self._streams[d % _DECODER_CHAINS - 1]
                 side.wait_event(ready)
                 for t in per_dec[d]:
                     if capturing:
@@ -370,6 +375,8 @@ class UNet_UAPS(nn.Module):
             if capturing:
                 _CAPTURE_KEEP[self] = keep              # not an attribute: the model stays deep-copyable
             outs[0] = decoders[0](per_dec[0])
+            for d in on_main:
+                outs[d] = decoders[d](per_dec[d])
             for side in self._streams:
                 main.wait_stream(side)
             return tuple(outs)
