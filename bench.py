@@ -206,7 +206,8 @@ def inference_block(dev, size=256, classes=4, aux=3):
     """Row f-2 (the reference's only published performance figures are inference: README.md:107-111 / fig_data/decoder-effect.jpg,
     notebook cells 11-19): ms per image of (a) the main head alone -- encoder + main decoder + arg-max, what the paper's
     "main decoder only" row times -- and (b) the all-heads ensemble -- every decoder + the mixing kernel's arg-max of the mean
-    softmax -- at batch 1 and 16, eval mode, eager launches on one stream, inputs resident; median of `reps` timed calls."""
+    softmax -- at batch 1 and 16, eval mode, eager launches on one stream, inputs resident; median of `reps` timed calls;
+    `main_head_graph`: (a) as a replayed hipGraph (inference.CapturedMainHead), the copy of the input into the graph's buffer included."""
     import numpy as np
     import torch
     import uaps_amd
@@ -235,6 +236,19 @@ def inference_block(dev, size=256, classes=4, aux=3):
                     torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1))
                 rec[name] = {"ms_per_call": round(float(np.median(ts)), 3), "ms_per_image": round(float(np.median(ts)) / B, 3)}
+            # the main head as a replayed hipGraph (inference.CapturedMainHead): the input is copied into the graph's buffer inside the timed call
+            run = inference.CapturedMainHead(model, x)
+            same = bool(torch.equal(run(x), inference.predict_main(model, x)))
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(10):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(x); e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            rec["main_head_graph"] = {"ms_per_call": round(float(np.median(ts)), 3), "ms_per_image": round(float(np.median(ts)) / B, 3),
+                                      "equals_eager": same}
+            del run
             out[f"batch_{B}"] = rec
     except Exception as e:                                   # never lose the headline line to a side measurement
         out["error"] = f"{type(e).__name__}: {e}"[:300]

@@ -33,6 +33,44 @@ def predict_main(model: torch.nn.Module, images: torch.Tensor) -> torch.Tensor:
     return torch.argmax(logits, dim=1)
 
 
+class CapturedMainHead:
+    """predict_main for ONE input shape as a replayed hipGraph: at batch 1 the eager call is ~90 launches of a few microseconds of
+    work each and is bound by their issue; the replay hands the device the whole chain at once.  Same kernels and arithmetic as
+    predict_main (the main decoder has no perturbation: nothing random is baked in).  The packed weights are read through the
+    graph's pointers: build a new object after the model's parameters changed (a checkpoint load, a training step).
+
+        run = CapturedMainHead(model, example_images)
+        mask = run(images)            # int64 [B,H,W], valid until the next call (clone() it to keep it)
+    """
+
+    def __init__(self, model: torch.nn.Module, example: torch.Tensor, warmup: int = 2):
+        from . import bounds
+        if not example.is_cuda:
+            raise ValueError("CapturedMainHead: a GPU tensor expected")
+        self.model, self.x = model, example.detach().clone()
+        model.eval()
+        cur = torch.cuda.current_stream(example.device)
+        side = torch.cuda.Stream(device=example.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():       # warm-up on a side stream (torch's capture recipe): packs the weights, sizes the workspaces
+            for _ in range(max(1, warmup)):
+                predict_main(model, self.x)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(example.device)
+        bounds.reset_pool()                                  # the zero fill of every max|.| scalar the kernels raise belongs to the graph
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = predict_main(model, self.x)
+        bounds.reset_pool()                                  # eager code must not be handed scalars the replays re-zero
+
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        if images.shape != self.x.shape or images.device != self.x.device or images.dtype != self.x.dtype:
+            raise ValueError(f"CapturedMainHead: captured for {tuple(self.x.shape)} {self.x.dtype} on {self.x.device}")
+        self.x.copy_(images, non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 @torch.no_grad()
 def ensemble_from_heads(heads) -> torch.Tensor:
     """Arg-max of the mean softmax of the given head logits: `uaps_unsup_fwd` (csrc/loss_kernels.hpp) with uniform mixing weights --
