@@ -40,3 +40,19 @@ for si in range(skip, min(len(starts) - 1, skip + 3)):
             inside = [(max(s_, a), min(e_, b)) for s_, e_, _ in seg if e_ > a and s_ < b]
             out.append(f"{name} {(b - a) / 1e3:.0f} us ({len([1 for s_, e_, _ in seg if a <= s_ < b])} launches, kernel time {sum(e_ - s_ for s_, e_ in inside) / 1e3:.0f})")
         print("   phases: " + "; ".join(out))
+    # how much of the step is a short kernel (< 15 us) running alone, or nothing running: the latency-bound part
+    short_alone = sum(v for k, v in alone_by.items() if False) if False else 0
+    evs = sorted([(s_, 1, i) for i, (s_, e_, n_) in enumerate(seg)] + [(e_, -1, i) for i, (s_, e_, n_) in enumerate(seg)])
+    act, last_t, by_len = set(), t0, collections.Counter()
+    for t, d_, i in evs:
+        if len(act) == 1:
+            j = next(iter(act)); dur = seg[j][1] - seg[j][0]
+            by_len["< 8 us" if dur < 8e3 else "8-20 us" if dur < 20e3 else "20-50 us" if dur < 50e3 else ">= 50 us"] += t - last_t
+        last_t = t
+        if d_ == 1: act.add(i)
+        else: act.discard(i)
+    print("   alone time by the lone kernel's duration: " + ", ".join(f"{k} {v / 1e3:.0f} us" for k, v in sorted(by_len.items())))
+    # the first 70 launches in start order (encoder forward and the head of the decoders): start offset, duration, kernel
+    if si == skip:
+        for s_, e_, n_ in seg[:70]:
+            print(f"      +{(s_ - t0) / 1e3:8.1f} us {(e_ - s_) / 1e3:7.1f} us  {n_[:60]}")
