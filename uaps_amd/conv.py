@@ -8,6 +8,7 @@ fallback on this path: CPU tensors are refused.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import weakref
@@ -173,8 +174,9 @@ _DEFER = os.environ.get("UAPS_DEFER_WRW_REDUCE", "1") != "0"
 
 def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     """Weak references to (weight, bias) when their gradients may be written late -- leaf tensors without tensor hooks and without
-    foreign post-accumulate hooks (dist.GradBuckets' own are known), whose gradients go straight to AccumulateGrad (a non-leaf weight's gradient, e.g. conv3x3s2's re-arranged kernel, is read by the next
-    autograd node at once) -- else None: that convolution reduces immediately whatever the scope."""
+    foreign post-accumulate hooks (dist.GradBuckets' own are known), whose gradients go straight to AccumulateGrad (a non-leaf
+    weight's gradient, e.g. conv3x3s2's re-arranged kernel, is read by the next autograd node at once) -- else None: that
+    convolution reduces immediately whatever the scope."""
     for t in (weight, bias):
         if t is None:
             continue
@@ -184,6 +186,11 @@ def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
         if post and any(not getattr(h, "_uaps_bucket", False) for h in post.values()):
             return None
     return (weakref.ref(weight), weakref.ref(bias) if bias is not None else None)
+
+
+# one deferred reduction: the partials' buffer, the addresses (and storages: kept alive) of the gradient tensors, the call's dimensions,
+# the stream the partials were launched on, leaf_refs of the parameters
+_Pending = collections.namedtuple("_Pending", "ws dw dw_storage dev db db_storage dims stream prefs")
 
 
 def _defers(prefs) -> bool:
@@ -202,8 +209,9 @@ def _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs=None) -> None
     if _defers(prefs):
         # addresses and storages, not the tensors: AccumulateGrad takes a gradient over as .grad only while nobody else holds it
         # (it copies otherwise -- here it would copy memory that is not written yet)
-        _deferred.append((ws, dw.data_ptr(), dw.untyped_storage(), dw.device, db.data_ptr() if db is not None else None,
-                          db.untyped_storage() if db is not None else None, B, Cin, Cout, H, W, ks, cfg, prefs))
+        _deferred.append(_Pending(ws, dw.data_ptr(), dw.untyped_storage(), dw.device, db.data_ptr() if db is not None else None,
+                                  db.untyped_storage() if db is not None else None, (B, Cin, Cout, H, W, ks, cfg),
+                                  torch.cuda.current_stream(dw.device), prefs))
         return
     rc = _lib.lib().uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, B, Cin, Cout,
                                                 H, W, ks, cfg, st)
@@ -218,9 +226,9 @@ _EARLY = os.environ.get("UAPS_EARLY_WRW_REDUCE", "1") != "0"
 
 def _launch_reduces(items: list, dev: torch.device) -> None:
     arr = (_lib.WrwReduceItem * len(items))()
-    for a, (ws, dwp, _dws, _dev, dbp, _dbs, B, Cin, Cout, H, W, ks, cfg, _prefs) in zip(arr, items):
-        a.workspace, a.dw, a.dbias = ws.data_ptr(), dwp, dbp
-        a.B, a.Cin, a.Cout, a.H, a.W, a.ks, a.cfg = B, Cin, Cout, H, W, ks, cfg
+    for a, it in zip(arr, items):
+        a.workspace, a.dw, a.dbias = it.ws.data_ptr(), it.dw, it.db
+        a.B, a.Cin, a.Cout, a.H, a.W, a.ks, a.cfg = it.dims
     with _lib.device_guard(dev):
         rc = _lib.lib().uaps_conv_bwd_weight_reduce_batch(arr, len(items), _lib.current_stream(dev))
     _lib.check(rc, "uaps_conv_bwd_weight_reduce_batch")
@@ -238,13 +246,15 @@ def early_flush() -> int:
     from . import unet
     if not unet._DECODER_STREAMS:        # single-stream mode: every launch on the caller's stream
         return 0
-    dev = _deferred[0][3]
-    if any(it[3] != dev for it in _deferred):
+    dev = _deferred[0].dev
+    if any(it.dev != dev for it in _deferred):
         return 0
     side = _reduce_streams.get(dev.index)
     if side is None:
         side = _reduce_streams[dev.index] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
+    for st in {it.stream for it in _deferred}:       # ... and for every stream partials were launched on (the caller's wait covers only
+        side.wait_stream(st)                         # the producers of ITS inputs: true for all of them in UNet_UAPS, not in general)
     items = list(_deferred)
     with torch.cuda.stream(side):
         _launch_reduces(items, dev)
@@ -265,17 +275,17 @@ def flush_weight_reduces() -> int:
     done = []
     if early is not None:
         side, done = early
-        torch.cuda.current_stream(done[0][3]).wait_stream(side)
+        torch.cuda.current_stream(done[0].dev).wait_stream(side)
     if _deferred:
         items, _deferred = _deferred, []
         by_dev: Dict[torch.device, list] = {}
         for it in items:
-            by_dev.setdefault(it[3], []).append(it)
+            by_dev.setdefault(it.dev, []).append(it)
         for dev, its in by_dev.items():
             _launch_reduces(its, dev)
         done = done + items
-    for (_ws, dwp, _dws, _dev, dbp, _dbs, *_dims, prefs) in done:
-        for ref, ptr in ((prefs[0], dwp), (prefs[1], dbp)):
+    for it in done:
+        for ref, ptr in ((it.prefs[0], it.dw), (it.prefs[1], it.db)):
             t = ref() if (ref is not None and ptr is not None) else None
             if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
                 raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction wrote (the "
@@ -309,7 +319,7 @@ class deferred_reduces:
                 if exc_type is None:
                     flush_weight_reduces()
                 elif _early is not None:          # a failed step: the side stream's launches are joined, nothing else is reduced
-                    torch.cuda.current_stream(_early[1][0][3]).wait_stream(_early[0])
+                    torch.cuda.current_stream(_early[1][0].dev).wait_stream(_early[0])
             finally:
                 _deferred, _early, _early_hook = None, None, None
         return False
