@@ -126,7 +126,7 @@ class StepGraph:
             both = tr.model.forward_pair(x_l, x_u)
             out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
             tr.optimizer.zero_grad(set_to_none=True)
-            out.loss.backward()
+            out.loss.backward(gradient=tr._unit_gradient(out.loss))
         return out, both
 
     def _tail(self, both, x_l, y_l):

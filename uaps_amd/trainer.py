@@ -38,6 +38,7 @@ class UAPSTrainer:
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="max", min_lr=1e-8, patience=50)
         self.c1, self.c2, self.rampup, self.ramp_divisor = consistency1, consistency2, consistency_rampup, ramp_divisor
         self.iter_num = 0
+        self._one = None                                 # the unit gradient handed to loss.backward (_unit_gradient)
         self._late_params = None                         # model.decoder_parameters() (_early_adam), asked at the first step
         self.n_heads = len(list(model.aux_decoders())) + 1 if hasattr(model, "aux_decoders") else 1
         # the Dirichlet mixing weights must be the same on every rank: a private, identically seeded stream
@@ -123,6 +124,14 @@ class UAPSTrainer:
             return None
         return lambda: self.optimizer.step_early(self._late_params)
 
+    def _unit_gradient(self, loss: torch.Tensor) -> torch.Tensor:
+        """d loss / d loss = 1 as a tensor kept for the trainer's life: `loss.backward()` would fill a fresh one every step (a
+        launch in front of the loss backward, on the step's critical path)."""
+        one = self._one
+        if one is None or one.device != loss.device or one.shape != loss.shape or one.dtype != loss.dtype:
+            one = self._one = torch.ones_like(loss)
+        return one
+
     def _hooks_exchange(self) -> bool:
         """True when gradient hooks launch the data-parallel exchange from inside the backward (they read .grad there)."""
         b = self.buckets
@@ -154,7 +163,7 @@ class UAPSTrainer:
                 else:
                     out = self.loss_fn(lab, y_l, un, w, cw1, cw2)                     # :186-282
             self.optimizer.zero_grad(set_to_none=True)                                # :285
-            out.loss.backward()                                                       # :287
+            out.loss.backward(gradient=self._unit_gradient(out.loss))                 # :287
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :292
@@ -334,7 +343,7 @@ class BaselineTrainer(UAPSTrainer):
             main = out[0] if isinstance(out, (tuple, list)) else out
             s = losses.uaps_sup_loss((main,), y_l)                                # :161-164, 0.5 * (dice + CE)
             self.optimizer.zero_grad(set_to_none=True)                            # :166
-            s.loss.backward()                                                     # :168
+            s.loss.backward(gradient=self._unit_gradient(s.loss))                 # :168
         if self.buckets is not None:
             self.buckets.finish()
         self.optimizer.step()                                                     # :173
