@@ -186,6 +186,28 @@ def _configure_from_environment(l) -> None:
     l.uaps_conv_set_tuning(flags)
 
 
+class quiet_gc:
+    """Around a hipGraph capture: collect garbage first and keep the cyclic collector off while the stream captures.  The step's
+    capture runs thousands of lines of Python; a collection in the middle of it finalises whatever dead cycles the process holds --
+    other trainers' CUDAGraph objects (hipGraphExecDestroy), tensors of other private pools -- i.e. runtime calls from inside a
+    global-mode capture.  torch.cuda.graph() used to collect before capturing and no longer does (torch.compiler.config.
+    force_cudagraph_gc, off by default); seen as an intermittent segmentation fault in capture_end in a test process that had
+    built and dropped a dozen captured trainers."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class WrwReduceItem(C.Structure):
     """uaps_wrw_reduce_item (include/uaps_hip.h)."""
     _fields_ = [("workspace", C.c_void_p), ("dw", C.c_void_p), ("dbias", C.c_void_p), ("B", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),

@@ -166,8 +166,8 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
 # backward of a step) every weight gradient keeps its partials in a buffer of its own and the reductions of the whole backward run
 # as one launch per 28 gradients when the scope ends (`flush_weight_reduces`), bit-identical to the single launches.  Until then the
 # gradient tensors autograd has been handed are allocated but NOT written: nothing may read a .grad inside the scope -- which is why
-# it is a scope the step owns (like lazybn.scope) and not a global mode; gradient hooks that send .grad somewhere (the overlapped
-# data-parallel exchange) must not be combined with it (UAPSTrainer does not open it then).
+# it is a scope the step owns (like lazybn.scope) and not a global mode.  The one reader inside the backward this package has, the
+# overlapped data-parallel exchange, reduces its bucket's gradients itself in front of the all-reduce (flush_params).
 _deferred: Optional[list] = None
 _DEFER = os.environ.get("UAPS_DEFER_WRW_REDUCE", "1") != "0"
 
@@ -265,6 +265,40 @@ def early_flush() -> int:
     return len(items)
 
 
+def _verify(items) -> None:
+    for it in items:
+        for ref, ptr in ((it.prefs[0], it.dw), (it.prefs[1], it.db)):
+            t = ref() if (ref is not None and ptr is not None) else None
+            if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
+                raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction wrote (the "
+                                   "unwritten gradient was summed or copied by autograd: shared weights, or gradient accumulation over "
+                                   "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
+
+
+def flush_params(param_ids) -> int:
+    """The pending reductions of the convolutions whose weight is one of `param_ids` (ids of parameters), on the current stream:
+    dist.GradBuckets calls this from the gradient hook that completes a bucket, in front of the bucket's all-reduce -- the
+    overlapped data-parallel exchange reads .grad inside the backward, so its reductions cannot wait for the end of the scope;
+    one launch per bucket instead of one per convolution.  The number of gradients reduced."""
+    if not _deferred:
+        return 0
+    mine, rest = [], []
+    for it in _deferred:
+        w = it.prefs[0]()
+        (mine if (w is not None and id(w) in param_ids) else rest).append(it)
+    if not mine:
+        return 0
+    dev = mine[0].dev
+    cur = torch.cuda.current_stream(dev)
+    for st in {it.stream for it in mine}:
+        if st != cur:
+            cur.wait_stream(st)
+    _launch_reduces(mine, dev)
+    _verify(mine)
+    _deferred[:] = rest
+    return len(mine)
+
+
 def flush_weight_reduces() -> int:
     """Run the pending reductions on the current stream of each device (after the backward has returned, i.e. after autograd has
     joined its streams) and join the early flush's side stream; the number of gradients reduced in the scope.  Raises if a
@@ -284,13 +318,7 @@ def flush_weight_reduces() -> int:
         for dev, its in by_dev.items():
             _launch_reduces(its, dev)
         done = done + items
-    for it in done:
-        for ref, ptr in ((it.prefs[0], it.dw), (it.prefs[1], it.db)):
-            t = ref() if (ref is not None and ptr is not None) else None
-            if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
-                raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction wrote (the "
-                                   "unwritten gradient was summed or copied by autograd: shared weights, or gradient accumulation over "
-                                   "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
+    _verify(done)
     return len(done)
 
 

@@ -68,6 +68,7 @@ class GradBuckets:
         order = [k for k in reversed(list(groups.keys())) if k != "encoder"] + [k for k in groups if k == "encoder"]
         self.buckets: List[List[torch.nn.Parameter]] = [groups[k] for k in order]
         self.names = order
+        self._ids = [{id(p) for p in params} for params in self.buckets]
         self._pending = [0] * len(self.buckets)
         self._handles: List = []
         self._flat: List[torch.Tensor] = []
@@ -113,6 +114,8 @@ class GradBuckets:
         return self._flat[bi][o:o + p.numel()].view_as(p)
 
     def _launch(self, bi: int):
+        from . import conv
+        conv.flush_params(self._ids[bi])         # inside a trainer's deferred_reduces scope: this bucket's weight gradients, one launch
         flat = self._flat[bi]
         for k, p in enumerate(self.buckets[bi]):
             v = self._view(bi, k)

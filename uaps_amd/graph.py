@@ -122,7 +122,7 @@ class StepGraph:
         """Forward, loss block and backward; every per-step scalar comes from the step state (w = None, cw = NaN)."""
         tr = self.tr
         perturb._RngState.offset = 0                 # the key changes every step: the counters may restart (and must, for replays)
-        with lazybn.scope(), conv.deferred_reduces(not tr._hooks_exchange(), on_early=tr._early_adam()):
+        with lazybn.scope(), conv.deferred_reduces(on_early=tr._early_adam()):
             both = tr.model.forward_pair(x_l, x_u)
             out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
             tr.optimizer.zero_grad(set_to_none=True)
@@ -234,18 +234,18 @@ class StepGraph:
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         if not self.split:
-            with torch.cuda.graph(g):
+            with _lib.quiet_gc(), torch.cuda.graph(g):
                 out, cm = self._body(self.static["x_l"], self.static["y_l"], self.static["x_u"])
         else:
             # thread_local: the process group's watchdog thread may query its events while this thread captures
             tr.buckets.defer = True                  # the backward hooks launch nothing inside the capture
             try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with _lib.quiet_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out, both = self._head(self.static["x_l"], self.static["y_l"], self.static["x_u"])
                 if not tr.buckets.in_place():
                     raise RuntimeError("a gradient of the captured backward was not written into its bucket slice")
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
+                with _lib.quiet_gc(), torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                     cm = self._tail(both, self.static["x_l"], self.static["y_l"])
             finally:
                 tr.buckets.defer = False

@@ -59,7 +59,8 @@ class CapturedMainHead:
         torch.cuda.synchronize(example.device)
         bounds.reset_pool()                                  # the zero fill of every max|.| scalar the kernels raise belongs to the graph
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        from . import _lib
+        with _lib.quiet_gc(), torch.cuda.graph(self.graph), torch.no_grad():      # (no finaliser runs inside the capture)
             self.out = predict_main(model, self.x)
         bounds.reset_pool()                                  # eager code must not be handed scalars the replays re-zero
 

@@ -132,19 +132,14 @@ class UAPSTrainer:
             one = self._one = torch.ones_like(loss)
         return one
 
-    def _hooks_exchange(self) -> bool:
-        """True when gradient hooks launch the data-parallel exchange from inside the backward (they read .grad there)."""
-        b = self.buckets
-        return b is not None and b.overlap and not (b.defer or b.muted)
-
     def _eager_step(self, x_l, y_l, x_u, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:                      # model.train() walks ~2600 modules: only when the mode changes
             self.model.train()
         cw1, cw2 = self.consistency_weights()
         # forward + backward of a step this trainer drives itself: the two-halves BatchNorm backward may run, and the weight-gradient
-        # reductions run batched behind the backward unless gradient hooks launch the data-parallel exchange from inside it
+        # reductions run batched -- behind the backward, or per bucket in front of its all-reduce (dist.GradBuckets._launch)
         pair = self.pair_forward and x_l.shape == x_u.shape       # (two forwards of one model: autograd sums the two gradients of a weight)
-        with lazybn.scope(), conv.deferred_reduces(pair and not self._hooks_exchange(), on_early=self._early_adam()):
+        with lazybn.scope(), conv.deferred_reduces(pair, on_early=self._early_adam()):
             if pair:
                 both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
                 if w is None:
@@ -338,7 +333,7 @@ class BaselineTrainer(UAPSTrainer):
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u=None, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:
             self.model.train()
-        with lazybn.scope(), conv.deferred_reduces(not self._hooks_exchange()):
+        with lazybn.scope(), conv.deferred_reduces():
             out = self.model(x_l)                                                 # baseline_train.py:158
             main = out[0] if isinstance(out, (tuple, list)) else out
             s = losses.uaps_sup_loss((main,), y_l)                                # :161-164, 0.5 * (dice + CE)
