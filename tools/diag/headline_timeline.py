@@ -31,7 +31,12 @@ for si in range(skip, min(len(starts) - 1, skip + 3)):
     # .. first fan-in), encoder backward + optimizer (first fan-in .. end)
     def first(name, lo=0): return next((k for k in seg if k[2].startswith(name) and k[0] >= lo), None)
     def last(name): return next((k for k in reversed(seg) if k[2].startswith(name)), None)
-    fo, pf, pb, fi = last("fanout_perturbed"), first("pair_fwd"), first("pair_bwd"), first("fanin_perturbed")
+    # the decoders begin with the 1x1 projection of the deepest feature (the fan-out kernels run beside the encoder since round 5)
+    fo, pf, pb, fi = first("conv_fwd_kernel<1, 16, 16"), first("pair_fwd"), first("pair_bwd"), first("fanin_perturbed")
+    if fo is None:
+        fo = last("fanout_perturbed")
+    else:
+        fo = (fo[0], fo[0], fo[2])
     if fo and pf and pb and fi:
         marks = [("encoder forward", t0, fo[1]), ("decoders forward", fo[1], pf[0]), ("loss", pf[0], pb[1]), ("decoders backward", pb[1], fi[0]),
                  ("encoder backward + optimizer", fi[0], t1)]
