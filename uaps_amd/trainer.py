@@ -122,6 +122,7 @@ class UAPSTrainer:
             self._late_params = tuple(fn()) if callable(fn) else ()
         if not self._late_params:
             return None
+        self.optimizer._early_done.clear()       # (a step that raised between its early and its final Adam call leaves nothing behind)
         return lambda: self.optimizer.step_early(self._late_params)
 
     def _unit_gradient(self, loss: torch.Tensor) -> torch.Tensor:
