@@ -226,3 +226,10 @@ def test_bench_starts_its_own_ranks_and_propagates_their_failure():
     assert r.returncode != 0 and r.stdout.strip() == ""
     # (the first rank to fail ends the job: the other one is terminated, with or without having reported itself)
     assert "No HIP GPUs are available" in r.stderr or "Traceback" in r.stderr, r.stderr[-2000:]
+
+
+def test_the_driver_build_hook_runs_against_the_built_library():
+    """__graft_entry__.build() is what the driver runs as its build check: it must accept the library as built (an ABI-version bump
+    once left its assertion behind)."""
+    import __graft_entry__ as g
+    g.build()
