@@ -257,6 +257,72 @@ def inference_block(dev, size=256, classes=4, aux=3):
     return out
 
 
+class PowerLog:
+    """Clock and socket power across the timed regions (round 6): tools/power_sampler.py runs as a child process started BEFORE this
+    process touches the GPU (it makes no HIP call itself: amdsmi's metrics table, or the hwmon files), sampling every 20 ms; the
+    regions are host time stamps taken next to the synchronizes that bracket them.  Never fails the bench: without a sampler the
+    fields are null."""
+
+    def __init__(self, period_s=0.02):
+        import subprocess
+        import tempfile
+        self.proc, self.path, self.regions = None, None, {}
+        try:
+            fd, self.path = tempfile.mkstemp(prefix="uaps_power_", suffix=".jsonl")
+            os.close(fd)
+            self.proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "power_sampler.py"), self.path, str(period_s)],
+                                         stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def mark(self, name, t0, t1):
+        self.regions[name] = (t0, t1)
+
+    def finish(self, bdf=None):
+        """{region: {sclk_mhz mean / min / max, power_w mean / max, samples, ppt_limited_frac}} + power_cap_w, source."""
+        if self.proc is None:
+            return None
+        try:
+            time.sleep(0.05)
+            self.proc.stdin.close()
+            self.proc.wait(timeout=5)
+        except Exception:
+            try:
+                self.proc.kill()
+            except Exception:
+                pass
+        try:
+            lines = [json.loads(l) for l in open(self.path) if l.strip()]
+            os.unlink(self.path)
+        except Exception:
+            return None
+        if not lines or not lines[0].get("header"):
+            return None
+        head, recs = lines[0], lines[1:]
+        gpus = head.get("gpus") or []
+        idx = next((i for i, g in enumerate(gpus) if bdf and g.get("bdf") == bdf), 0 if len(gpus) == 1 else None)
+        if idx is None:      # several GPUs and no BDF match: the one that drew the most power over the run
+            tot = [sum((r["gpus"][i].get("power_w") or 0) for r in recs if i < len(r["gpus"])) for i in range(len(gpus))]
+            idx = max(range(len(gpus)), key=lambda i: tot[i]) if gpus else None
+        if idx is None:
+            return None
+        out = {"source": head.get("source"), "period_s": head.get("period_s"), "gpu_bdf": gpus[idx].get("bdf"),
+               "power_cap_w": gpus[idx].get("power_cap_w"), "regions": {}}
+        for name, (t0, t1) in self.regions.items():
+            rs = [r["gpus"][idx] for r in recs if t0 <= r["t"] <= t1 and idx < len(r["gpus"]) and "error" not in r["gpus"][idx]]
+            clk = [g["sclk_mhz"] for g in rs if g.get("sclk_mhz")]
+            pw = [g["power_w"] for g in rs if g.get("power_w")]
+            reg = {"samples": len(rs), "seconds": round(t1 - t0, 3),
+                   "sclk_mhz": round(sum(clk) / len(clk), 1) if clk else None, "sclk_mhz_min": round(min(clk), 1) if clk else None,
+                   "sclk_mhz_max": round(max(clk), 1) if clk else None,
+                   "power_w": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None}
+            acc = [(g.get("ppt_acc"), g.get("acc")) for g in rs if g.get("ppt_acc") is not None and g.get("acc") is not None]
+            if len(acc) >= 2 and acc[-1][1] > acc[0][1]:      # share of the driver's accumulation ticks in which the PPT (package power) limiter was active
+                reg["ppt_limited_frac"] = round((acc[-1][0] - acc[0][0]) / (acc[-1][1] - acc[0][1]), 4)
+            out["regions"][name] = reg
+        return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N ...` without torch.distributed.run: start N fresh copies of this command, one rank per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as the launcher would), wait for them and return the job's exit code.
@@ -318,6 +384,7 @@ def main():
                     help="steps timed with every convolution on the fp32 matrix instruction after the headline (0 = skip)")
     ap.add_argument("--analysis-steps", type=int, default=6, help="single-stream steps after the timed region for the per-kernel figures")
     ap.add_argument("--no-inference", action="store_true", help="skip the inference block (main head / ensemble ms per image, N = 1 only)")
+    ap.add_argument("--no-power-log", action="store_true", help="do not start tools/power_sampler.py (clock / socket power across the timed regions)")
     ap.add_argument("--other-configs", type=int, default=4,
                     help="N = 1 only: steps timed of each of BASELINE.json configs[3] and the per-GPU shape of configs[4] after everything else (0 = skip)")
     args = ap.parse_args()
@@ -325,6 +392,9 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: this process becomes one (it has touched no GPU and imports no torch) and exits with the job's code
         raise SystemExit(spawn_ranks(args.gpus))
+
+    # rank 0 samples clock and socket power for the whole run: the child process starts before anything here touches the GPU
+    plog = PowerLog(0.01) if int(os.environ.get("RANK", "0")) == 0 and not args.no_power_log else None
 
     import numpy as np
     import torch
@@ -427,6 +497,7 @@ def main():
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread (median, p10 / p90)
     t0 = time.perf_counter()
+    w0 = time.time()
     marks[0].record()
     for i in range(args.steps):
         trainer.train_step(*data.next())
@@ -436,6 +507,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if plog is not None:
+        plog.mark("timed_region", w0, time.time())
     if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -471,11 +544,14 @@ def main():
         losses.KERNEL_EVENTS = {}
         conv.KERNEL_EVENTS, conv.EVENT_FILTER = {}, ({dominant} if dominant else None)
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        w0 = time.time()
         a0.record()
         for i in range(args.analysis_steps):
             trainer.train_step(*data.next())
         a1.record()
         torch.cuda.synchronize()
+        if plog is not None:
+            plog.mark("analysis_pass", w0, time.time())
         single_ms = a0.elapsed_time(a1) / args.analysis_steps
         ev, losses.KERNEL_EVENTS = losses.KERNEL_EVENTS, None
         cev, conv.KERNEL_EVENTS, conv.EVENT_FILTER = conv.KERNEL_EVENTS, None, None
@@ -643,6 +719,32 @@ def main():
                           "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5),
                           "launch_mode": mode},
                "roofline": roof, "kernels": kern}
+        # clock and socket power across the timed region and the analysis pass (tools/power_sampler.py)
+        power = None
+        if plog is not None:
+            try:
+                pr = torch.cuda.get_device_properties(dev)
+                bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            except Exception:
+                bdf = None
+            power = plog.finish(bdf)
+        if power is not None:
+            res["power"] = power
+            tr_, an_ = power["regions"].get("timed_region") or {}, power["regions"].get("analysis_pass") or {}
+            if roof is not None:
+                roof["sclk_mhz_under_load"] = tr_.get("sclk_mhz")
+                roof["power_w"] = tr_.get("power_w")
+                roof["power_cap_w"] = power.get("power_cap_w")
+                roof["ppt_limited_frac"] = tr_.get("ppt_limited_frac")
+                roof["sclk_mhz_analysis_pass"] = an_.get("sclk_mhz")
+                clk = an_.get("sclk_mhz") or tr_.get("sclk_mhz")
+                if clk and roof.get("bound") == "mfma":
+                    # the dominant kernel is measured in the analysis pass: its fraction of the matrix peak at the clock the chip held there
+                    roof["frac_at_measured_clock"] = round(roof["achieved"] / (roof["peak"] * clk / 2400.0), 4)
+                    roof["power_note"] = ("sclk = mean over samples of the mean of the 8 XCDs' current_gfxclks (amdsmi metrics table, sampled by a child "
+                                          "process every 10 ms); peak is quoted at the nominal 2400 MHz, frac_at_measured_clock rescales it to the sampled "
+                                          "clock of the single-stream analysis pass; ppt_limited_frac = share of the driver's accumulation ticks with the "
+                                          "package-power limiter active (ppt_residency_acc)")
         res["step_ms"] = {"p10": round(float(np.percentile(step_ms, 10)), 3), "p50": round(float(np.percentile(step_ms, 50)), 3),
                           "p90": round(float(np.percentile(step_ms, 90)), 3), "note": "GPU time between per-step HIP events on rank 0 (headline mode)"}
         if single_ms:

@@ -16,8 +16,11 @@
  *                      to the device-resident step state (uaps_set_step_state: NULL outside a state-mode step; two trainers in
  *                      one process each bracket their steps with set / clear, see uaps_amd/graph.py) and, per device, the pointer
  *                      to that device's sticky error word (uaps_set_error_word);
- *       per thread     the one-shot side arguments of the NEXT call (uaps_next_call_hints, uaps_next_launch_events), consumed
- *                      and cleared by that call;
+ *       per thread     LEGACY: the one-shot side arguments of the NEXT call (uaps_next_call_hints), consumed and cleared by that call.
+ *                      Every entry point that reads them also exists as `<name>_h(const uaps_call_hints* hints, same arguments)`
+ *                      (round 6, ABI 3): the hints of THAT call as its first argument (NULL = none), nothing thread-local read or
+ *                      written -- safe from any thread, e.g. PyTorch's autograd thread.  The Python package calls only the *_h forms
+ *                      and uaps_conv_ex.  (uaps_next_launch_events, a measurement aid of bench.py, stays per thread.)
  *   - return value: 0 on success, a negative UAPS_E* code for bad arguments, a positive hipError_t
  *     if a launch failed.  Nothing throws.
  *   - number of heads D in [1,8] (main + auxiliary decoders), classes C in [2,8].
@@ -566,8 +569,11 @@ typedef struct uaps_conv_call {
     const void* xf; float xf_slope; int xf_groups;      /* staging-time BatchNorm + LeakyReLU of x (uaps_bn_finalize_train) or NULL */
     int want_bias;                       /* BWD_WEIGHT: also the bias gradient's partials */
     void* workspace; size_t workspace_bytes;            /* BWD_WEIGHT (uaps_conv_wrw_workspace_bytes) */
-    uaps_call_hints hints;               /* the operands' bounds, statistics shift, dyt_* ...; hints.struct_size may be 0 = none */
-    uaps_stream_t stream;
+    uaps_stream_t stream;                /* ABI 3: in FRONT of the hints -- the record below is the part of this struct that grows, and a
+                                          * client built against a shorter uaps_call_hints must still have its stream where the library
+                                          * reads it (ABI 2 had it behind the hints) */
+    uaps_call_hints hints;               /* the operands' bounds, statistics shift, dyt_* ...; hints.struct_size may be 0 = none, and
+                                          * must not exceed what struct_size leaves for it */
 } uaps_conv_call;
 int uaps_conv_ex(const uaps_conv_call* call);
 
@@ -665,6 +671,59 @@ int uaps_adam_step(float* const* params_host, const float* const* grads_host, fl
  * ------------------------------------------------------------------------------------------- */
 int uaps_seg_confusion(const float* logits, const int64_t* labels, int B, int C, int H, int W,
                        int64_t* counts, uaps_stream_t stream);
+
+/* ---- Explicit-hints forms (round 6, ABI 3) -------------------------------------------------------------------------------------
+ * `<name>_h(hints, args...)` == `<name>(args...)` with `hints` (NULL or struct_size 0 = none) instead of the thread's pending
+ * uaps_next_call_hints record, which is neither read nor cleared.  Same kernels, same results, same return codes; the record is
+ * copied size-versioned like uaps_next_call_hints does.  These are what uaps_amd/ (ctypes) binds. */
+int uaps_conv_fwd_h(const uaps_call_hints* hints, const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout,
+                    int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_fwd_stats_h(const uaps_call_hints* hints, const float* x, const float* wf, const float* bias, float* y, void* stats, int B,
+                          int Cin, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_fwd_bn_h(const uaps_call_hints* hints, const float* x_raw, const void* xf, float slope, int groups, const float* wf,
+                       const float* bias, float* y, void* stats, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
+                       uaps_stream_t stream);
+int uaps_conv_fwd_cat_h(const uaps_call_hints* hints, const float* x1, int C1, const float* x2, int C2, const float* wf, const float* bias,
+                        float* y, void* stats, int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_bwd_data_h(const uaps_call_hints* hints, const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H, int W,
+                         int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_bwd_data_cat_h(const uaps_call_hints* hints, const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2, int B,
+                             int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
+int uaps_conv_bwd_weight_partial_h(const uaps_call_hints* hints, const float* dy, const float* x, int want_bias, int B, int Cin, int Cout,
+                                   int H, int W, int ks, int cfg, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_conv_bwd_weight_partial_bn_h(const uaps_call_hints* hints, const float* dy, const float* x_raw, const void* xf, float slope,
+                                      int groups, int want_bias, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
+                                      void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_conv_bwd_weight_partial_cat_h(const uaps_call_hints* hints, const float* dy, const float* x1, int C1, const float* x2, int C2,
+                                       int want_bias, int B, int Cout, int H, int W, int ks, int cfg, void* workspace,
+                                       size_t workspace_bytes, uaps_stream_t stream);
+int uaps_bn_act_fwd_train_partials_h(const uaps_call_hints* hints, const void* partials, int parts_per_image, const float* y,
+                                     const float* conv_bias, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, int64_t* num_batches_tracked, float momentum, float eps, float slope,
+                                     float drop_p, uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* out,
+                                     float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_bn_finalize_train_h(const uaps_call_hints* hints, const void* partials, int parts_per_image, const float* conv_bias,
+                             const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float momentum, float eps, int B, int C, int H, int W, int groups,
+                             float* save_mean, float* save_invstd, void* xf, uaps_stream_t stream);
+int uaps_bn_act_bwd_grouped_h(const uaps_call_hints* hints, const float* dout, const float* y, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                              uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma, float* dbeta,
+                              void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_bn_act_bwd_grouped_bias_h(const uaps_call_hints* hints, const float* dout, const float* y, const float* gamma, const float* beta,
+                                   const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                                   uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma, float* dbeta,
+                                   float* dconv_bias, void* workspace, size_t workspace_bytes, uaps_stream_t stream);
+int uaps_bn_act_bwd_apply_h(const uaps_call_hints* hints, const float* dout, const float* y, const float* coef, float slope, int B, int C,
+                            int H, int W, int groups, float* dy, uaps_stream_t stream);
+int uaps_up_cat_fwd_h(const uaps_call_hints* hints, const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w,
+                      uaps_stream_t stream);
+int uaps_cat2_h(const uaps_call_hints* hints, const float* a, const float* b, float* out, long n, uaps_stream_t stream);
+int uaps_add_relu_h(const uaps_call_hints* hints, const float* a, const float* b, float* out, long n, uaps_stream_t stream);
+int uaps_pairloss_bwd_h(const uaps_call_hints* hints, const float* const* lab_logits_host, const float* const* un_logits_host,
+                        const int64_t* labels, const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1,
+                        float cw2, const float* grad_scale, int D, int B, int C, int H, int W, long n_pixels_loss,
+                        float* const* dlab_host, float* const* dun_host, int cfg, uaps_stream_t stream);
 
 #ifdef __cplusplus
 }

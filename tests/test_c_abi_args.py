@@ -169,3 +169,32 @@ def test_process_wide_switches_and_the_round3_plans(L):
     assert L.uaps_space_to_depth2(fake, fake, 1, 8, 8, 12, 1, None) == ERANGE            # rows of 8-float groups
     assert L.uaps_subsample2_fwd(None, fake, 4, 8, 8, None) == EINVAL and L.uaps_subsample2_bwd(fake, None, 4, 8, 8, None) == EINVAL
     assert L.uaps_subsample2_fwd(fake, fake, 0, 8, 8, None) == EINVAL
+
+
+def test_explicit_hints_forms_validate_their_record(L):
+    """The *_h entry points (include/uaps_hip.h, "Explicit-hints forms"): the hints record is an argument, validated like
+    uaps_next_call_hints validates it, and a pending thread-local record is not consumed by them."""
+    assert set(_lib.HINTED) <= set(_lib.SIGNATURES) and all(n + "_h" in _lib.SIGNATURES for n in _lib.HINTED)
+    h = _lib.CallHints()
+    h.struct_size = C.sizeof(_lib.CallHints) + 8                                         # a client newer than the library
+    assert L.uaps_conv_fwd_h(C.byref(h), None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL
+    h.struct_size = C.sizeof(_lib.CallHints)
+    h.bound[0], h.mul[0] = 1 << 20, -1.0                                                 # a bound needs a positive finite factor
+    assert L.uaps_conv_bwd_data_h(C.byref(h), None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL
+    h.mul[0] = 1.0
+    fake = C.c_void_p(1 << 20)
+    big = (1, 16, 16, 8192, 8192)
+    assert L.uaps_conv_fwd_h(C.byref(h), fake, fake, None, fake, *big, 3, 0, None) == ERANGE      # argument checks as in the legacy form
+    assert L.uaps_conv_fwd_h(None, None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL   # NULL hints = none
+    h.struct_size = 0                                                                    # struct_size 0 = no hints either
+    assert L.uaps_cat2_h(C.byref(h), None, None, None, 4, None) == EINVAL                # (then the NULL tensors are refused)
+    # a pending legacy record survives explicit calls and is consumed by the next legacy call only
+    p = _lib.CallHints()
+    p.struct_size = C.sizeof(_lib.CallHints)
+    assert L.uaps_next_call_hints(C.byref(p)) == OK
+    assert L.uaps_conv_fwd_h(None, None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL
+    assert L.uaps_conv_fwd(None, None, None, None, 1, 8, 8, 8, 8, 3, 0, None) == EINVAL
+    assert L.uaps_next_call_hints(None) == OK
+    # uaps_conv_call: `stream` sits in front of the growable hints record (ABI 3)
+    assert _lib.ConvCall.stream.offset < _lib.ConvCall.hints.offset
+    assert _lib.ConvCall.hints.offset + C.sizeof(_lib.CallHints) == C.sizeof(_lib.ConvCall)

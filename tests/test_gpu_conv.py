@@ -404,9 +404,9 @@ def test_launch_timer_reads_the_kernel_dispatch(conv_mode):
 
 
 def test_the_explicit_conv_call_equals_the_hinted_entry_points():
-    """uaps_conv_ex (one size-versioned struct per call, include/uaps_hip.h) against uaps_conv_fwd / uaps_conv_bwd_data /
-    uaps_conv_bwd_weight_partial behind uaps_next_call_hints: the same kernels, bit-identical results; pending thread-local
-    hints are dropped, not consumed by it; an old client's shorter struct is accepted."""
+    """uaps_conv_ex (one size-versioned struct per call, include/uaps_hip.h) against the *_h entry points the package calls and
+    against the legacy pair uaps_next_call_hints + uaps_conv_fwd: the same kernels, bit-identical results; a pending thread-local
+    record is neither used nor consumed by the explicit forms; an old client's shorter struct is accepted."""
     import ctypes as C
     from uaps_amd import _lib, bounds, conv
     DEV = "cuda:0"
@@ -439,11 +439,35 @@ def test_the_explicit_conv_call_equals_the_hinted_entry_points():
         return c
 
     y = torch.empty_like(y_ref)
-    _lib.hints((None,))                                   # a pending record of the classic protocol: uaps_conv_ex must not use it
+    # a pending record of the legacy protocol with a bound that is far too small (fp16 overflow if anything used it): the explicit
+    # forms must neither use nor consume it
+    tiny = (bounds.from_value(torch.tensor(1e-20, device=DEV)), 1.0)
+    pending = _lib.CallHints()
+    pending.struct_size = C.sizeof(_lib.CallHints)
+    pending.bound[0], pending.mul[0] = tiny[0].data_ptr(), 1.0
+    assert L.uaps_next_call_hints(C.byref(pending)) == 0
     with _lib.device_guard(x.device):
         rc = L.uaps_conv_ex(C.byref(with_bound(call(0, x=x.data_ptr(), w_packed=wf.data_ptr(), y=y.data_ptr()), xb)))
     _lib.check(rc, "uaps_conv_ex fwd")
     assert torch.equal(y, y_ref)
+    y.zero_()
+    with _lib.device_guard(x.device):        # the *_h form with the record as its first argument
+        _lib.check(L.uaps_conv_fwd_h(_lib.mk_hints((xb,)), x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), B, Cin, Cout, H, W, ks, 0, st), "uaps_conv_fwd_h")
+    assert torch.equal(y, y_ref)
+    # ... and the pending record is still there for the legacy entry point that follows: replace it with the true bound and compare
+    assert L.uaps_next_call_hints(None) == 0
+    good = _lib.CallHints()
+    good.struct_size = C.sizeof(_lib.CallHints)
+    good.bound[0], good.mul[0] = xb[0].data_ptr(), xb[1]
+    y.zero_()
+    with _lib.device_guard(x.device):
+        assert L.uaps_next_call_hints(C.byref(good)) == 0
+        _lib.check(L.uaps_conv_fwd(x.data_ptr(), wf.data_ptr(), None, y.data_ptr(), B, Cin, Cout, H, W, ks, 0, st), "uaps_conv_fwd (legacy hints)")
+    assert torch.equal(y, y_ref)
+    # a hints record that claims more bytes than the caller's struct leaves for it
+    c = with_bound(call(0, x=x.data_ptr(), w_packed=wf.data_ptr(), y=y.data_ptr()), xb)
+    c.struct_size = _lib.ConvCall.hints.offset + 32
+    assert L.uaps_conv_ex(C.byref(c)) == -1
     dx = torch.empty_like(dx_ref)
     with _lib.device_guard(x.device):
         rc = L.uaps_conv_ex(C.byref(with_bound(call(1, x=dy.data_ptr(), w_packed=wb.data_ptr(), y=dx.data_ptr()), dyb)))

@@ -335,7 +335,7 @@ def test_deferred_weight_gradient_reductions_give_the_same_step_bit_for_bit(stre
     convolution) against the immediate reductions: same gradients, hence the same parameters after three steps, bit for bit --
     eagerly, with decoder streams, and through the captured graph."""
     import uaps_amd
-    from uaps_amd import conv
+    from uaps_amd import conv, stepctx
     import uaps_amd.unet as _unet
     monkeypatch.setattr(_unet, "_DECODER_STREAMS", streams)
     data = _batches(3, 2, 64, 64)
@@ -346,13 +346,13 @@ def test_deferred_weight_gradient_reductions_give_the_same_step_bit_for_bit(stre
         tr = uaps_amd.UAPSTrainer(m, base_lr=1e-3, seed=11, step_state=True, use_graph=graph)
         flushed = []
         orig = conv.flush_weight_reduces
-        monkeypatch.setattr(conv, "flush_weight_reduces", lambda: flushed.append(orig()) or flushed[-1])
+        monkeypatch.setattr(conv, "flush_weight_reduces", lambda step=None: flushed.append(orig(step)) or flushed[-1])
         for xl, y, xu in data + data:
             tr.train_step(xl, y, xu)
         monkeypatch.setattr(conv, "flush_weight_reduces", orig)
         torch.cuda.synchronize()
         tr.check_errors()
-        assert conv._deferred is None                       # no scope left open
+        assert stepctx.current() is None                    # no scope left open on this thread
         if defer:
             assert flushed and all(n > 40 for n in flushed)   # every convolution of the net rode in the batch
         else:
@@ -365,16 +365,16 @@ def test_deferred_weight_gradient_reductions_give_the_same_step_bit_for_bit(stre
 
 def test_a_failing_backward_drops_the_pending_reductions():
     import uaps_amd
-    from uaps_amd import conv
+    from uaps_amd import conv, stepctx
     x = torch.randn(2, 8, 32, 32, device=DEV, requires_grad=True)
     w = torch.randn(16, 8, 3, 3, device=DEV, requires_grad=True)
     with pytest.raises(RuntimeError, match="boom"):
-        with conv.deferred_reduces():
+        with conv.deferred_reduces() as step:
             y = conv.conv2d(x, w, None)
             y.sum().backward()
-            assert conv._deferred and len(conv._deferred) == 1
+            assert step is stepctx.current() and step.deferred and len(step.deferred) == 1
             raise RuntimeError("boom")
-    assert conv._deferred is None
+    assert stepctx.current() is None and step.deferred is None
     # outside a scope the reduction is immediate and the gradient is the oracle's
     w.grad = None
     conv.conv2d(x, w, None).sum().backward()
@@ -392,12 +392,12 @@ def test_a_parameter_with_a_foreign_gradient_hook_or_a_derived_weight_is_reduced
     ref = torch.nn.grad.conv2d_weight(x.cpu().double(), w.shape, torch.ones(2, 16, 32, 32, dtype=torch.float64), padding=1).numpy()
     seen = []
     w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.detach().clone()))
-    with conv.deferred_reduces():
+    with conv.deferred_reduces() as step:
         conv.conv2d(x, w, None).sum().backward()
-        assert not conv._deferred
+        assert not step.deferred
     np.testing.assert_allclose(seen[0].cpu().numpy(), ref, rtol=2e-5, atol=2e-4)
     v = torch.randn(16, 8, 3, 3, device=DEV, requires_grad=True)
-    with conv.deferred_reduces():
+    with conv.deferred_reduces() as step:
         conv.conv2d(x, v * 2.0, None).sum().backward()          # the weight is a non-leaf: its gradient feeds the multiplication's backward
-        assert not conv._deferred
+        assert not step.deferred
     np.testing.assert_allclose(v.grad.cpu().numpy(), 2.0 * ref, rtol=2e-5, atol=4e-4)

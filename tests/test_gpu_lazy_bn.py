@@ -123,7 +123,7 @@ def test_chain_gradients_with_and_without_the_pending_transform(C0, C1, H, W, B,
 
 def test_a_pending_transform_that_nobody_applies_is_an_error():
     from uaps_amd import lazybn
-    lazybn._outstanding = 1
+    lazybn._loose.outstanding = 1
     with pytest.raises(RuntimeError, match="pending BatchNorm transform"):
         lazybn.assert_none_pending()
     lazybn.assert_none_pending()
@@ -174,7 +174,7 @@ def test_a_failed_backward_leaves_nothing_behind_for_a_plain_user_backward():
     ref = _block(13, 16, 16, 32, 256, 4, False, True, scope=False)
     with pytest.raises(RuntimeError, match="injected failure"):
         _block(13, 16, 16, 32, 256, 4, True, True, scope=True, fail_in_backward=True)
-    assert lazybn._depth == 0
+    assert lazybn.current() is None
     got = _block(13, 16, 16, 32, 256, 4, True, True, scope=False)
     for u, v in zip(got, ref):
         assert torch.equal(u, v)

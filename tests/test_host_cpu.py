@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in uaps_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     L = _lib.lib()
-    assert L.uaps_abi_version() == 2
+    assert L.uaps_abi_version() == 3
     assert b"range" in L.uaps_error_string(-2) and b"no form" in L.uaps_error_string(-4)
 
 
@@ -233,3 +233,23 @@ def test_the_driver_build_hook_runs_against_the_built_library():
     once left its assertion behind)."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_a_model_behind_a_foreign_gradient_reducer_is_not_deferred():
+    """torch's DistributedDataParallel hangs its reducer on the AccumulateGrad nodes, where no Python-side check of
+    the parameter can see it; a trainer therefore refuses to defer for such a model as a whole."""
+    import torch.nn as nn
+    from uaps_amd import conv
+
+    class FakeDDP(nn.parallel.DistributedDataParallel):      # the class test is what matters; no process group is needed for it
+        def __init__(self, module):
+            nn.Module.__init__(self)
+            self.module = module
+
+    m = nn.Conv2d(3, 8, 3)
+    assert conv.defer_allowed(m) and conv.defer_allowed(nn.DataParallel(m))
+    assert not conv.defer_allowed(FakeDDP(m))
+    with conv.deferred_reduces(model=FakeDDP(m)) as step:
+        assert step is None
+    with conv.deferred_reduces(model=m) as step:
+        assert step is not None

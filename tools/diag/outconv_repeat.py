@@ -38,7 +38,7 @@ def pair():
     if ctx:
         CV.conv_fwd_raw(xc, wfc, None, 8, 3, 0, want_stats=True)
     s = _lib.current_stream(dev)
-    _lib.hints((), None, (rm, cb))
+    L.uaps_next_call_hints(_lib.mk_hints((), None, (rm, cb)))
     _lib.check(L.uaps_bn_finalize_train(st.data_ptr(), int(st.shape[2]), cb.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
                                         rv.data_ptr(), nbt.data_ptr(), 0.1, 1e-5, B, Cc, H, W, G, stats[0].data_ptr(), stats[1].data_ptr(),
                                         xf.data_ptr(), s), "finalize")

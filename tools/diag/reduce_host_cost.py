@@ -36,7 +36,7 @@ def timed(fn, reps=200):
 
 
 def partial():
-    _lib.hints((dyb, xb))
+    L.uaps_next_call_hints(_lib.mk_hints((dyb, xb)))
     L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), 0, B, Cin, Cout, H, W, ks, cfg, ws.data_ptr(), ws.numel(), st)
 
 

@@ -10,13 +10,15 @@ import os
 import subprocess
 import threading
 
+from . import config
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UAPS_HIP_LIB selects another build of the same ABI (tools/ab_bench.sh compares two kernel builds on one GPU box)
-LIB_PATH = os.environ.get("UAPS_HIP_LIB") or os.path.join(_HERE, "lib", "libuaps_hip.so")
+LIB_PATH = config.text("UAPS_HIP_LIB") or os.path.join(_HERE, "lib", "libuaps_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()
-_tls = threading.local()      # one reusable uaps_call_hints per thread (uaps_next_call_hints copies it)
+_tls = threading.local()      # one reusable uaps_call_hints ARGUMENT buffer per Python thread (the *_h entry points copy it during the call)
 _lib = None
 
 c_float_p = C.POINTER(C.c_float)
@@ -125,6 +127,17 @@ SIGNATURES = {
 }
 
 
+# The explicit-hints forms (include/uaps_hip.h, "Explicit-hints forms"): `<name>_h(const uaps_call_hints*, same arguments)`.  These are
+# what the package calls; the base names stay bound for the C-ABI tests and foreign callers.
+HINTED = ("uaps_conv_fwd", "uaps_conv_fwd_stats", "uaps_conv_fwd_bn", "uaps_conv_fwd_cat", "uaps_conv_bwd_data", "uaps_conv_bwd_data_cat",
+          "uaps_conv_bwd_weight_partial", "uaps_conv_bwd_weight_partial_bn", "uaps_conv_bwd_weight_partial_cat",
+          "uaps_bn_act_fwd_train_partials", "uaps_bn_finalize_train", "uaps_bn_act_bwd_grouped", "uaps_bn_act_bwd_grouped_bias",
+          "uaps_bn_act_bwd_apply", "uaps_up_cat_fwd", "uaps_cat2", "uaps_add_relu", "uaps_pairloss_bwd")
+for _n in HINTED:
+    SIGNATURES[_n + "_h"] = (SIGNATURES[_n][0], [_PTR] + list(SIGNATURES[_n][1]))
+del _n
+
+
 class UapsHipError(RuntimeError):
     pass
 
@@ -173,14 +186,14 @@ _TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, 
 
 
 def _configure_from_environment(l) -> None:
-    mode = os.environ.get("UAPS_CONV_MODE")
+    mode = config.text("UAPS_CONV_MODE")
     if mode:                                    # "0" / "exact" / "f32";  "1" / "bf16" / "split";  "2" / "h16"
         m = 0 if mode[0] in "0ef" else (1 if mode[0] in "1bs" else 2)
         if l.uaps_conv_set_mode(m) != 0:
             raise UapsHipError(f"UAPS_CONV_MODE={mode}: uaps_conv_set_mode failed")
     flags = 0
     for name, bit, on_value in _TUNE_ENV:
-        v = os.environ.get(name)
+        v = config.text(name)
         if v is not None and (on_value is None or v == on_value):
             flags |= bit
     l.uaps_conv_set_tuning(flags)
@@ -215,7 +228,7 @@ class WrwReduceItem(C.Structure):
 
 
 class CallHints(C.Structure):
-    """uaps_call_hints (include/uaps_hip.h): one-shot side arguments of the next entry point called on this thread."""
+    """uaps_call_hints (include/uaps_hip.h): the optional operands of ONE call, handed to the *_h entry points as their first argument."""
     _fields_ = [("struct_size", C.c_uint), ("bound", C.c_void_p * 3), ("mul", C.c_float * 3), ("out_amax", C.c_void_p),
                 ("stats_mean", C.c_void_p), ("stats_bias", C.c_void_p), ("residual", C.c_void_p),
                 ("dyt_y", C.c_void_p), ("dyt_coef", C.c_void_p), ("dyt_out", C.c_void_p), ("dyt_slope", C.c_float), ("dyt_groups", C.c_int),
@@ -230,13 +243,16 @@ class ConvCall(C.Structure):
                 ("W", C.c_int), ("ks", C.c_int), ("cfg", C.c_int), ("x", C.c_void_p), ("C1", C.c_int), ("x2", C.c_void_p),
                 ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("y2", C.c_void_p), ("y_grad", C.c_void_p),
                 ("stats", C.c_void_p), ("xf", C.c_void_p), ("xf_slope", C.c_float), ("xf_groups", C.c_int), ("want_bias", C.c_int),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("hints", CallHints), ("stream", C.c_void_p)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p), ("hints", CallHints)]
 
 
-def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None, bsum=None) -> None:
-    """bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
+def mk_hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None, bsum=None):
+    """The uaps_call_hints argument of a *_h entry point (a ctypes byref; pass None for "no hints").
+    bounds: up to three (bound tensor, host factor) pairs or None; out_amax: a zeroed bound tensor; stats: (running_mean or
     None, conv bias or None) = the per-channel shift BatchNorm partial sums are formed about / were formed about; residual: the
-    tensor a BatchNorm apply pass adds before its ReLU (residual joins)."""
+    tensor a BatchNorm apply pass adds before its ReLU (residual joins).
+    The record is an ARGUMENT: the library copies it inside the call it is passed to and keeps nothing.  The buffer behind the returned
+    reference is this Python thread's and is rewritten by the next mk_hints of the thread, so build it in the call expression."""
     h = getattr(_tls, "hints", None)
     if h is None:
         h = _tls.hints = CallHints()
@@ -266,7 +282,7 @@ def hints(bounds=(), out_amax=None, stats=None, residual=None, dyt=None, bsum=No
             h.bound[i], h.mul[i] = b[0].data_ptr(), float(b[1])
     if out_amax is not None:
         h.out_amax = out_amax.data_ptr()
-    check(lib().uaps_next_call_hints(C.byref(h)), "uaps_next_call_hints")
+    return C.byref(h)
 
 
 class LaunchTimer:

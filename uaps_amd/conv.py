@@ -17,7 +17,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
-from . import _graddest, lazybn, _lib, bounds
+from . import _graddest, lazybn, _lib, bounds, config, stepctx
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 # packed weights per parameter: id(weight) -> (weakref, version, generation, wf, wb)
@@ -168,8 +168,21 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
 # gradient tensors autograd has been handed are allocated but NOT written: nothing may read a .grad inside the scope -- which is why
 # it is a scope the step owns (like lazybn.scope) and not a global mode.  The one reader inside the backward this package has, the
 # overlapped data-parallel exchange, reduces its bucket's gradients itself in front of the all-reduce (flush_params).
-_deferred: Optional[list] = None
-_DEFER = os.environ.get("UAPS_DEFER_WRW_REDUCE", "1") != "0"
+#
+# Round 6: the scope's state is a stepctx.StepContext, not module globals.  The forward of every convolution Function keeps the
+# context of the scope it ran in (`ctx.step`), so its backward -- on whichever autograd thread -- queues into the step it belongs to;
+# two trainers stepping from two threads never see each other's entries (tests/test_gpu_threads.py).
+_DEFER = config.flag("UAPS_DEFER_WRW_REDUCE", True)
+
+
+def _foreign_grad_hooks(t: torch.Tensor) -> bool:
+    """Does something this package does not know read t.grad INSIDE the backward?  Python-side tensor hooks and post-accumulate
+    hooks are visible here; hooks that C++ code attaches to the parameter's AccumulateGrad node (torch.nn.parallel.
+    DistributedDataParallel's reducer, FSDP) are NOT -- models wrapped that way are refused as a whole by `defer_allowed`."""
+    if t._backward_hooks:
+        return True
+    post = getattr(t, "_post_accumulate_grad_hooks", None)
+    return bool(post) and any(not getattr(h, "_uaps_bucket", False) for h in post.values())
 
 
 def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
@@ -180,12 +193,26 @@ def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
     for t in (weight, bias):
         if t is None:
             continue
-        if not t.is_leaf or t._backward_hooks:
-            return None
-        post = getattr(t, "_post_accumulate_grad_hooks", None)      # a foreign hook may read .grad inside the backward
-        if post and any(not getattr(h, "_uaps_bucket", False) for h in post.values()):
+        if not t.is_leaf or _foreign_grad_hooks(t):
             return None
     return (weakref.ref(weight), weakref.ref(bias) if bias is not None else None)
+
+
+def defer_allowed(model) -> bool:
+    """May a trainer open `deferred_reduces` for `model`?  Not for a model behind a gradient reducer this package cannot see:
+    torch.nn.parallel.DistributedDataParallel and FSDP hang their hooks on the AccumulateGrad NODES (C++ side), read or copy the
+    still unwritten .grad inside the backward, and nothing on the Python side of the parameter shows it (a DDP-wrapped
+    model would train silently on unsynchronised gradients).  nn.DataParallel replicas and plain modules are fine; this package's own
+    exchange (dist.GradBuckets) is handled through flush_params."""
+    import torch.nn as nn
+    refuse = [nn.parallel.DistributedDataParallel]
+    try:
+        from torch.distributed.fsdp import FullyShardedDataParallel
+        refuse.append(FullyShardedDataParallel)
+    except Exception:
+        pass
+    mods = model.modules() if isinstance(model, nn.Module) else ()
+    return not any(isinstance(m, tuple(refuse)) for m in mods)
 
 
 # one deferred reduction: the partials' buffer, the addresses (and storages: kept alive) of the gradient tensors, the call's dimensions,
@@ -193,35 +220,38 @@ def leaf_refs(weight: torch.Tensor, bias: Optional[torch.Tensor]):
 _Pending = collections.namedtuple("_Pending", "ws dw dw_storage dev db db_storage dims stream prefs")
 
 
-def _defers(prefs) -> bool:
-    return _deferred is not None and prefs is not None
+def step_of(prefs) -> Optional[stepctx.StepContext]:
+    """The forward of a convolution Function: the step context its backward will queue its reduction into (None: reduce at once)."""
+    return stepctx.current() if prefs is not None else None
 
 
-def _wrw_workspace(dev: torch.device, nbytes: int, prefs=None) -> torch.Tensor:
-    if _defers(prefs):
+def _defers(prefs, step) -> bool:
+    return step is not None and step.deferred is not None and prefs is not None
+
+
+def _wrw_workspace(dev: torch.device, nbytes: int, prefs=None, step=None) -> torch.Tensor:
+    if _defers(prefs, step):
         return torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     return _workspace(dev, nbytes)
 
 
-def _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs=None) -> None:
-    """The reduction of one weight gradient's partials: now, or at the end of the enclosing deferred_reduces() scope (prefs =
-    leaf_refs(weight, bias) of the convolution, same value as given to _wrw_workspace)."""
-    if _defers(prefs):
+def _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs=None, step=None) -> None:
+    """The reduction of one weight gradient's partials: now, or at the end of the deferred_reduces() scope `step` belongs to (prefs =
+    leaf_refs(weight, bias) of the convolution, step = step_of(prefs) taken in the forward; same values as given to _wrw_workspace)."""
+    if _defers(prefs, step):
         # addresses and storages, not the tensors: AccumulateGrad takes a gradient over as .grad only while nobody else holds it
         # (it copies otherwise -- here it would copy memory that is not written yet)
-        _deferred.append(_Pending(ws, dw.data_ptr(), dw.untyped_storage(), dw.device, db.data_ptr() if db is not None else None,
-                                  db.untyped_storage() if db is not None else None, (B, Cin, Cout, H, W, ks, cfg),
-                                  torch.cuda.current_stream(dw.device), prefs))
+        step.deferred.append(_Pending(ws, dw.data_ptr(), dw.untyped_storage(), dw.device, db.data_ptr() if db is not None else None,
+                                      db.untyped_storage() if db is not None else None, (B, Cin, Cout, H, W, ks, cfg),
+                                      torch.cuda.current_stream(dw.device), prefs))
         return
     rc = _lib.lib().uaps_conv_bwd_weight_reduce(ws.data_ptr(), dw.data_ptr(), db.data_ptr() if db is not None else None, B, Cin, Cout,
                                                 H, W, ks, cfg, st)
     _lib.check(rc, "uaps_conv_bwd_weight_reduce")
 
 
-_early_hook = None                    # deferred_reduces(on_early=...): called on the side stream behind the early flush's launches
-_early: Optional[tuple] = None        # (side stream, items) of the scope's early flush, until the final one has joined the stream
 _reduce_streams: Dict[int, "torch.cuda.Stream"] = {}
-_EARLY = os.environ.get("UAPS_EARLY_WRW_REDUCE", "1") != "0"
+_EARLY = config.flag("UAPS_EARLY_WRW_REDUCE", True)
 
 
 def _launch_reduces(items: list, dev: torch.device) -> None:
@@ -234,56 +264,59 @@ def _launch_reduces(items: list, dev: torch.device) -> None:
     _lib.check(rc, "uaps_conv_bwd_weight_reduce_batch")
 
 
-def early_flush() -> int:
-    """Called by the backward of a feature fan-out (perturb._FanOut): when the first of them runs -- the deepest feature's, whose
-    gradient needs every decoder's whole backward -- all decoder weight gradients have their partials queued and the calling stream
-    has been made to wait for the decoder streams by autograd.  Their reductions (most of the step's: 52 of 62 in the U-Net) go to a
-    side stream here and run beside the encoder's backward, where the chip has one kernel at a time, instead of alone behind it; the
-    scope's final flush joins the stream.  Once per scope; nothing outside a scope."""
-    global _early
-    if not _EARLY or not _deferred or _early is not None:
+def early_flush(step: Optional[stepctx.StepContext]) -> int:
+    """Called by the backward of a feature fan-out (perturb._FanOut, with the step context its forward saw): when the first of them
+    runs -- the deepest feature's, whose gradient needs every decoder's whole backward -- all decoder weight gradients have their
+    partials queued and the calling stream has been made to wait for the decoder streams by autograd.  Their reductions (most of the
+    step's: 52 of 62 in the U-Net) go to a side stream here and run beside the encoder's backward, where the chip has one kernel at a
+    time, instead of alone behind it; the scope's final flush joins the stream.  Once per scope; nothing outside a scope."""
+    if step is None or not _EARLY or not step.deferred or step.early is not None or step.early_done:
         return 0
     from . import unet
     if not unet._DECODER_STREAMS:        # single-stream mode: every launch on the caller's stream
         return 0
-    dev = _deferred[0].dev
-    if any(it.dev != dev for it in _deferred):
+    dev = step.deferred[0].dev
+    if any(it.dev != dev for it in step.deferred):
         return 0
     side = _reduce_streams.get(dev.index)
     if side is None:
         side = _reduce_streams[dev.index] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
-    for st in {it.stream for it in _deferred}:       # ... and for every stream partials were launched on (the caller's wait covers only
+    for st in {it.stream for it in step.deferred}:   # ... and for every stream partials were launched on (the caller's wait covers only
         side.wait_stream(st)                         # the producers of ITS inputs: true for all of them in UNet_UAPS, not in general)
-    items = list(_deferred)
+    items = list(step.deferred)
+    _verify(items, early=True)          # (before the hook below updates parameters from these gradients: ADVICE r5)
     with torch.cuda.stream(side):
         _launch_reduces(items, dev)
-        if _early_hook is not None:     # (UAPSTrainer: Adam for the parameters whose gradients are final now, behind their reductions)
-            _early_hook()
-    _early = (side, items)              # the partials' buffers stay alive until the final flush has joined the side stream
-    _deferred.clear()
+        if step.early_hook is not None:     # (UAPSTrainer: Adam for the parameters whose gradients are final now, behind their reductions)
+            step.early_hook()
+    step.early = (side, items)          # the partials' buffers stay alive until the final flush has joined the side stream
+    step.early_done = True
+    step.deferred.clear()
     return len(items)
 
 
-def _verify(items) -> None:
+def _verify(items, early: bool = False) -> None:
+    """early: called from inside the backward (early_flush) -- a parameter whose AccumulateGrad has not run yet has no .grad; that is
+    not an error there (the early hook leaves it to the final optimizer step), a .grad at ANOTHER address is."""
     for it in items:
         for ref, ptr in ((it.prefs[0], it.dw), (it.prefs[1], it.db)):
             t = ref() if (ref is not None and ptr is not None) else None
-            if t is not None and t.requires_grad and (t.grad is None or t.grad.data_ptr() != ptr):
+            if t is not None and t.requires_grad and ((t.grad is None and not early) or (t.grad is not None and t.grad.data_ptr() != ptr)):
                 raise RuntimeError("deferred weight-gradient reduction: a parameter's .grad is not the buffer its reduction wrote (the "
                                    "unwritten gradient was summed or copied by autograd: shared weights, or gradient accumulation over "
                                    "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
 
 
-def flush_params(param_ids) -> int:
+def flush_params(step: Optional[stepctx.StepContext], param_ids) -> int:
     """The pending reductions of the convolutions whose weight is one of `param_ids` (ids of parameters), on the current stream:
     dist.GradBuckets calls this from the gradient hook that completes a bucket, in front of the bucket's all-reduce -- the
     overlapped data-parallel exchange reads .grad inside the backward, so its reductions cannot wait for the end of the scope;
     one launch per bucket instead of one per convolution.  The number of gradients reduced."""
-    if not _deferred:
+    if step is None or not step.deferred:
         return 0
     mine, rest = [], []
-    for it in _deferred:
+    for it in step.deferred:
         w = it.prefs[0]()
         (mine if (w is not None and id(w) in param_ids) else rest).append(it)
     if not mine:
@@ -295,23 +328,27 @@ def flush_params(param_ids) -> int:
             cur.wait_stream(st)
     _launch_reduces(mine, dev)
     _verify(mine)
-    _deferred[:] = rest
+    step.deferred[:] = rest
     return len(mine)
 
 
-def flush_weight_reduces() -> int:
-    """Run the pending reductions on the current stream of each device (after the backward has returned, i.e. after autograd has
-    joined its streams) and join the early flush's side stream; the number of gradients reduced in the scope.  Raises if a
-    parameter's .grad is not the buffer its reduction wrote (autograd summed or copied the unwritten gradient: a weight used by two
-    convolutions, gradient accumulation over several backward passes -- such training loops set UAPS_DEFER_WRW_REDUCE=0)."""
-    global _deferred, _early
-    early, _early = _early, None
+def flush_weight_reduces(step: Optional[stepctx.StepContext] = None) -> int:
+    """Run the pending reductions of `step` (default: the calling thread's open scope) on the current stream of each device (after
+    the backward has returned, i.e. after autograd has joined its streams) and join the early flush's side stream; the number of
+    gradients reduced in the scope.  Raises if a parameter's .grad is not the buffer its reduction wrote (autograd summed or copied the
+    unwritten gradient: a weight used by two convolutions, gradient accumulation over several backward passes -- such training loops
+    set UAPS_DEFER_WRW_REDUCE=0)."""
+    if step is None:
+        step = stepctx.current()
+    if step is None:
+        return 0
+    early, step.early = step.early, None
     done = []
     if early is not None:
         side, done = early
         torch.cuda.current_stream(done[0].dev).wait_stream(side)
-    if _deferred:
-        items, _deferred = _deferred, []
+    if step.deferred:
+        items, step.deferred = step.deferred, []
         by_dev: Dict[torch.device, list] = {}
         for it in items:
             by_dev.setdefault(it.dev, []).append(it)
@@ -323,34 +360,55 @@ def flush_weight_reduces() -> int:
 
 
 class deferred_reduces:
-    """Scope of a training step's forward + backward: see the comment above.  Not re-entrant across threads; nested scopes join the
-    outer one.  An exception inside drops the pending reductions (their gradients stay unwritten, like the step they belonged to)."""
+    """Scope of a training step's forward + backward: see the comment above.  `with deferred_reduces(...) as step:` -- step is the
+    StepContext (None when deferral is off).  The scope belongs to the thread that opens it; nested scopes join the outer one.  An
+    exception inside drops the pending reductions (their gradients stay unwritten, like the step they belonged to).
+    model: refused (the scope then defers nothing) when it is wrapped in a gradient reducer this package cannot see
+    (`defer_allowed`: torch DistributedDataParallel / FSDP)."""
 
-    def __init__(self, enabled: bool = True, on_early=None):
-        self.enabled = enabled and _DEFER
+    def __init__(self, enabled: bool = True, on_early=None, model=None):
+        self.enabled = bool(enabled) and _DEFER and (model is None or _allowed_cached(model))
         self.outer = False
         self.on_early = on_early
+        self.step = None
+        self.prev = None
 
     def __enter__(self):
-        global _deferred, _early_hook
         if self.enabled:
-            self.outer = _deferred is None
+            cur = stepctx.current()
+            self.outer = cur is None
             if self.outer:
-                _deferred = []
-                _early_hook = self.on_early
-        return self
+                self.step = stepctx.StepContext(self.on_early)
+                self.prev = stepctx.push(self.step)
+            else:
+                self.step = cur
+        return self.step
 
     def __exit__(self, exc_type, exc, tb):
-        global _deferred, _early, _early_hook
         if self.enabled and self.outer:
+            step = self.step
             try:
                 if exc_type is None:
-                    flush_weight_reduces()
-                elif _early is not None:          # a failed step: the side stream's launches are joined, nothing else is reduced
-                    torch.cuda.current_stream(_early[1][0].dev).wait_stream(_early[0])
+                    flush_weight_reduces(step)
+                elif step.early is not None:          # a failed step: the side stream's launches are joined, nothing else is reduced
+                    torch.cuda.current_stream(step.early[1][0].dev).wait_stream(step.early[0])
             finally:
-                _deferred, _early, _early_hook = None, None, None
+                step.deferred, step.early, step.early_hook = None, None, None
+                stepctx.pop(self.prev)
         return False
+
+
+_allowed: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _allowed_cached(model) -> bool:
+    try:
+        ok = _allowed.get(model)
+        if ok is None:
+            ok = _allowed[model] = defer_allowed(model)
+        return ok
+    except TypeError:                                # (not weak-referenceable: decide every time)
+        return defer_allowed(model)
 
 
 def _remember(weight: torch.Tensor, wf, wb) -> None:
@@ -493,29 +551,33 @@ def plan_cfg(ks: int, cfg: int, plain: bool, *tensors) -> int:
 
 # ---- the up-sampled half of an UpBlock's concatenation formed in the consuming kernels' staging (round 5) ----------------------
 X2_UP2 = 1 << 10                  # UAPS_CONV_X2_UP2 (include/uaps_hip.h)
-_FUSED_UP2 = os.environ.get("UAPS_FUSED_UP2", "1") != "0"
-_amax_request = False             # the next forward convolution of this thread's model code raises a bound to max|its output|
-_last_out_amax = None
+_FUSED_UP2 = config.flag("UAPS_FUSED_UP2", True)
+# "the next forward convolution of this thread's model code raises a bound to max|its output|": per THREAD (stepctx.fwd()), a
+# forward runs on one thread from the request to the take
 
 
 def request_out_amax() -> None:
     """The next conv2d / bn_act_conv forward tracks max|output| (uaps_call_hints::out_amax; the fp32-instruction kernels have it):
     the 1x1 projection in front of an up-sampling has no BatchNorm behind it to bound its output.  Fetch it with take_out_amax()."""
-    global _amax_request, _last_out_amax
-    _amax_request, _last_out_amax = True, None
+    f = stepctx.fwd()
+    f.amax_request, f.last_out_amax = True, None
 
 
 def _claim_amax(dev):
-    global _amax_request
-    if not _amax_request:
+    f = stepctx.fwd()
+    if not f.amax_request:
         return None
-    _amax_request = False
+    f.amax_request = False
     return bounds.new_amax(dev) if bounds.enabled() else None
 
 
+def _set_out_amax(am) -> None:
+    stepctx.fwd().last_out_amax = am
+
+
 def take_out_amax():
-    global _amax_request, _last_out_amax
-    am, _last_out_amax, _amax_request = _last_out_amax, None, False
+    f = stepctx.fwd()
+    am, f.last_out_amax, f.amax_request = f.last_out_amax, None, False
     return am
 
 
@@ -542,32 +604,32 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     if want_stats:
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
-    global _last_out_amax
     am = _claim_amax(x.device)
     for attempt in range(2):
         with _lib.device_guard(x.device), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(xb), want_stats) as tm:
+            hh = None
             if xb is not None or (want_stats and stat_shift is not None) or am is not None:
-                _lib.hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
+                hh = _lib.mk_hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
             if want_stats:
-                rc = L.uaps_conv_fwd_stats(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
-                                           _lib.current_stream(x.device))
+                rc = L.uaps_conv_fwd_stats_h(hh, x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), stats.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
+                                             _lib.current_stream(x.device))
             else:
-                rc = L.uaps_conv_fwd(x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
-                                     _lib.current_stream(x.device))
+                rc = L.uaps_conv_fwd_h(hh, x.data_ptr(), wf.data_ptr(), bp, y.data_ptr(), B, Cin, Cout, H, W, ks, cfg,
+                                       _lib.current_stream(x.device))
             if rc == ENOFORM:
                 tm.on = False
         if rc != ENOFORM or am is None:
             break
         am = None                                     # this layer's kernel cannot track max|y|: run it without (the caller falls back)
     _lib.check(rc, "uaps_conv_fwd")
-    _last_out_amax = am
+    _set_out_amax(am)
     return (y, stats, ppi) if want_stats else y
 
 
 # BatchNorm-backward sums in the input-gradient kernel's epilogue (uaps_call_hints::bsum_*): built and measured in round 5 -- the
 # sums pass it removes (46 us at 5.8 TB/s) costs the row kernel 38 us (it moves bytes at 4.0 TB/s): a wash, so OFF unless asked for
 # (profiles/r05_bn_sums_epilogue_ab.txt)
-_FUSED_BSUM = os.environ.get("UAPS_FUSED_BN_SUMS", "0") == "1"
+_FUSED_BSUM = config.flag("UAPS_FUSED_BN_SUMS", False)
 
 
 def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg: int = 0, dyb=None, bsum=None):
@@ -587,8 +649,8 @@ def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg
         with _lib.device_guard(dev):
             _lib.check(L.uaps_zero_bounds(maxes.data_ptr(), maxes.numel(), _lib.current_stream(dev)), "uaps_zero_bounds")
             with _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, True, name="conv_hr16_bs_kernel") as tm:
-                _lib.hints((dyb,), bsum=(bsum[0], bsum[1], bsum[2], bsum[3], bsum[4], partials, maxes, bsum[5], bsum[6]))
-                rc = L.uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(dev))
+                rc = L.uaps_conv_bwd_data_h(_lib.mk_hints((dyb,), bsum=(bsum[0], bsum[1], bsum[2], bsum[3], bsum[4], partials, maxes, bsum[5], bsum[6])),
+                                            dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(dev))
                 if rc == ENOFORM:
                     tm.on = False
         if rc != ENOFORM:
@@ -596,15 +658,14 @@ def conv_bwd_data_raw(dy: torch.Tensor, wb: torch.Tensor, Cin: int, ks: int, cfg
             return dx, partials, maxes
         partials = maxes = None
     with _lib.device_guard(dev), _timed("bwd_data", B, Cin, Cout, H, W, ks, cfg, _h16(dyb)):
-        if dyb is not None:
-            _lib.hints((dyb,))
-        rc = L.uaps_conv_bwd_data(dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(dev))
+        rc = L.uaps_conv_bwd_data_h(_lib.mk_hints((dyb,)) if dyb is not None else None,
+                                    dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), B, Cin, Cout, H, W, ks, cfg, _lib.current_stream(dev))
     _lib.check(rc, "uaps_conv_bwd_data")
     return (dx, None, None) if bsum is not None else dx
 
 
 def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: bool, cfg: int = 0, wkey=None, bkey=None,
-                        dyb=None, xb=None, lz=None, prefs=None):
+                        dyb=None, xb=None, lz=None, prefs=None, step=None):
     """wkey / bkey: id() of the weight / bias parameter, for a registered gradient destination (_graddest).
     lz (lazybn.Lazy): `dy` is d(activation) behind the BatchNorm that follows this convolution; the kernel forms the true dy while
     staging and writes it through -- returned as a third value (with its bound) -- or the stand-alone pass does, where the layer's
@@ -616,7 +677,7 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
     n = C.c_size_t()
     cfg = plan_cfg(ks, cfg, True, dy, x)
     _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cin, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-    ws = _wrw_workspace(dev, n.value, prefs)
+    ws = _wrw_workspace(dev, n.value, prefs, step)
     dw = _graddest.take(wkey, (Cout, Cin, ks, ks), dev)
     db = _graddest.take(bkey, (Cout,), dev) if want_bias else None
     dy_true = None
@@ -626,9 +687,9 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
         if lz is not None and xb is not None:
             dy_true = torch.empty_like(dy)
             with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, True, dt=True) as tm:
-                _lib.hints((lz.bound, xb), dyt=(lz.y, lz.coef, dy_true, lz.slope, lz.groups))
-                rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
-                                                    ws.data_ptr(), ws.numel(), st)
+                rc = L.uaps_conv_bwd_weight_partial_h(_lib.mk_hints((lz.bound, xb), dyt=(lz.y, lz.coef, dy_true, lz.slope, lz.groups)),
+                                                      dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
+                                                      ws.data_ptr(), ws.numel(), st)
                 tm.on = tm.on and rc != lazybn.ENOFORM
             if rc != lazybn.ENOFORM:
                 bounds.put(dy_true, *lz.bound)
@@ -637,12 +698,11 @@ def conv_bwd_weight_raw(dy: torch.Tensor, x: torch.Tensor, ks: int, want_bias: b
             dyb = bounds.get(dy)
         if lz is None or rc == lazybn.ENOFORM:
             with _timed("wrw", B, Cin, Cout, H, W, ks, cfg, _h16(dyb, xb)):
-                if dyb is not None and xb is not None:
-                    _lib.hints((dyb, xb))
-                rc = L.uaps_conv_bwd_weight_partial(dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
-                                                    ws.data_ptr(), ws.numel(), st)
+                rc = L.uaps_conv_bwd_weight_partial_h(_lib.mk_hints((dyb, xb)) if (dyb is not None and xb is not None) else None,
+                                                      dy.data_ptr(), x.data_ptr(), int(want_bias), B, Cin, Cout, H, W, ks, cfg,
+                                                      ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "uaps_conv_bwd_weight_partial")
-        _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs)
+        _wrw_reduce(ws, dw, db, B, Cin, Cout, H, W, ks, cfg, st, prefs, step)
     if lz is not None:
         return dw, db, dy_true
     return dw, db
@@ -672,6 +732,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.meta = (Cin, Cout, ks, bias is not None, cfg)
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
         ctx.prefs = leaf_refs(weight, bias)
+        ctx.step = step_of(ctx.prefs)             # the trainer scope this forward ran in: the backward queues its reduction there
         ctx.xb = xb = bounds.get(x)
         if want_stats:
             y, stats, _ppi = conv_fwd_raw(x, wf, bias, Cout, ks, cfg, want_stats=True, xb=xb, stat_shift=stat_shift)
@@ -695,11 +756,11 @@ class _Conv2d(torch.autograd.Function):
             dy, lz = lazybn.materialize(dy, lz), None
             dyb = bounds.get(dy)
         if lz is not None:
-            dw, db, dy = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, xb=ctx.xb, lz=lz, prefs=ctx.prefs)
+            dw, db, dy = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, xb=ctx.xb, lz=lz, prefs=ctx.prefs, step=ctx.step)
             dyb = bounds.get(dy)
         dx = conv_bwd_data_raw(dy, wb, Cin, ks, cfg, dyb=dyb) if ctx.needs_input_grad[0] else None
         if lz is None and want_w:
-            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb, prefs=ctx.prefs)
+            dw, db = conv_bwd_weight_raw(dy, x, ks, has_bias and ctx.needs_input_grad[2], cfg, *ctx.keys, dyb=dyb, xb=ctx.xb, prefs=ctx.prefs, step=ctx.step)
         return dx, dw, db, None, None, None
 
 
@@ -757,16 +818,18 @@ class _Conv2dCat(torch.autograd.Function):
         ctx.xb = (b1, b2)
         ucfg = cfg | (X2_UP2 if up2 else 0)
         with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(b1, b2), name="conv_hr16_up_kernel" if up2 else None):
+            hh = None
             if (b1 is not None and b2 is not None) or (want_stats and stat_shift is not None):
-                _lib.hints((b1, b2) if (b1 is not None and b2 is not None) else (), None, stat_shift if want_stats else None)
-            rc = _lib.lib().uaps_conv_fwd_cat(x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
-                                              bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                                              stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, ucfg, _lib.current_stream(dev))
+                hh = _lib.mk_hints((b1, b2) if (b1 is not None and b2 is not None) else (), None, stat_shift if want_stats else None)
+            rc = _lib.lib().uaps_conv_fwd_cat_h(hh, x1.data_ptr(), C1, x2.data_ptr(), C2, wf.data_ptr(),
+                                                bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                                stats.data_ptr() if want_stats else None, B, Cout, H, W, ks, ucfg, _lib.current_stream(dev))
         _lib.check(rc, "uaps_conv_fwd_cat")
         ctx.save_for_backward(x1, x2, wb)
         ctx.meta = (C1, C2, Cout, ks, bias is not None, cfg)
         ctx.keys = (id(weight), id(bias) if bias is not None else None)
         ctx.prefs = leaf_refs(weight, bias)
+        ctx.step = step_of(ctx.prefs)
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -803,24 +866,25 @@ class _Conv2dCat(torch.autograd.Function):
             """(dw, db, dy): with a pending transform the kernel writes the true dy through (None: it has no such form here)"""
             n = C.c_size_t()
             _lib.check(L.uaps_conv_wrw_workspace_bytes(B, C1 + C2, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-            ws = _wrw_workspace(dev, n.value, ctx.prefs)
+            ws = _wrw_workspace(dev, n.value, ctx.prefs, ctx.step)
             dw = _graddest.take(ctx.keys[0], (Cout, C1 + C2, ks, ks), dev)
             db = _graddest.take(ctx.keys[1], (Cout,), dev) if want_db else None
             out = torch.empty_like(dy) if lz is not None else None
             with _timed("wrw", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb, b1, b2), dt=lz is not None,
                         name="conv_hrwrw_up_kernel" if ucfg != cfg else None) as tm:
+                hh = None
                 if lz is not None:
-                    _lib.hints((dyb, b1, b2), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
+                    hh = _lib.mk_hints((dyb, b1, b2), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
                 elif dyb is not None and b1 is not None and b2 is not None:
-                    _lib.hints((dyb, b1, b2))
-                rc = L.uaps_conv_bwd_weight_partial_cat(dy.data_ptr(), x1.data_ptr(), C1, x2w.data_ptr(), C2, int(want_db), B, Cout,
-                                                        H, W, ks, ucfg, ws.data_ptr(), ws.numel(), st)
+                    hh = _lib.mk_hints((dyb, b1, b2))
+                rc = L.uaps_conv_bwd_weight_partial_cat_h(hh, dy.data_ptr(), x1.data_ptr(), C1, x2w.data_ptr(), C2, int(want_db), B, Cout,
+                                                          H, W, ks, ucfg, ws.data_ptr(), ws.numel(), st)
                 if lz is not None and rc == lazybn.ENOFORM:
                     tm.on = False
             if lz is not None and rc == lazybn.ENOFORM:
                 return None, None, None
             _lib.check(rc, "uaps_conv_bwd_weight_partial_cat")
-            _wrw_reduce(ws, dw, db, B, C1 + C2, Cout, H, W, ks, cfg, st, ctx.prefs)
+            _wrw_reduce(ws, dw, db, B, C1 + C2, Cout, H, W, ks, cfg, st, ctx.prefs, ctx.step)
             return dw, db, (bounds.put(out, *lz.bound) if lz is not None else dy)
 
         with _lib.device_guard(dev):
@@ -838,10 +902,9 @@ class _Conv2dCat(torch.autograd.Function):
                 dx1 = torch.empty_like(x1)
                 dx2 = torch.empty((B, C2, H, W), dtype=torch.float32, device=dev) if up2 else torch.empty_like(x2)
                 with _timed("bwd_data", B, C1 + C2, Cout, H, W, ks, cfg, _h16(dyb)):
-                    if dyb is not None:
-                        _lib.hints((dyb,))
-                    rc = L.uaps_conv_bwd_data_cat(dy.data_ptr(), wb.data_ptr(), dx1.data_ptr(), C1, dx2.data_ptr(), C2, B, Cout, H, W,
-                                                  ks, cfg, st)
+                    rc = L.uaps_conv_bwd_data_cat_h(_lib.mk_hints((dyb,)) if dyb is not None else None,
+                                                    dy.data_ptr(), wb.data_ptr(), dx1.data_ptr(), C1, dx2.data_ptr(), C2, B, Cout, H, W,
+                                                    ks, cfg, st)
                 _lib.check(rc, "uaps_conv_bwd_data_cat")
             if want_w and not done_w:
                 dw, db, _ = weight_gradient(dy, dyb, None)

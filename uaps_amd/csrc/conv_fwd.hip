@@ -333,10 +333,9 @@ int launch_s32d(ConvFwdArgs a, int dil, hipStream_t s) {
 
 // x [B,Cin,H,W] * packed weights [taps][CinP][CoutP] -> y [B,Cout,H,W]
 // x2 / Csplit: optional second input tensor holding channels [Csplit, Cin); y2 / Osplit likewise for the output
-int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
+int conv_fwd_any(const uaps_call_hints& hints, const float* x, const float* wp, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int ks,
                  int cfg, hipStream_t s, float2* stats = nullptr, const float* x2 = nullptr, int Csplit = -1,
                  float* y2 = nullptr, int Osplit = -1, const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
-    const uaps_call_hints hints = take_hints();
     if (!x || !wp || !y) return UAPS_EINVAL;
     // UAPS_CONV_X2_UP2: x2 is [B, Cin - Csplit, H / 2, W / 2] and is up-sampled x2 (bilinear, align_corners) while staged
     const bool up2 = (cfg & UAPS_CONV_X2_UP2) != 0;
@@ -395,7 +394,10 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
         uaps::account_bytes(4.0 * B * H * W * Cout);      // the BatchNorm's raw input, once more
     }
     // the up-sampling form exists in ONE kernel: up4's first convolution on a 256-wide map (16 + 16 -> 16 channels, bounded operands)
-    if (up2 && !(row16 && x2 && Csplit == 16 && Cin == 32 && W == 256 && !xf && p.vec && up2_pattern_ok(W / 2)))
+    // (every condition of the branch below that reaches launch_hr16_up is part of this test -- the 32-pixel-wide tile plan, no 32x32 /
+    // GEMM-tiled plan -- so that no other kernel can ever be handed the low-resolution x2 as if it were a full-resolution tensor)
+    if (up2 && !(row16 && wide && !p.s32 && !p.g1 && p.dil == 1 && x2 && Csplit == 16 && Cin == 32 && W == 256 && !xf && p.vec &&
+                 up2_pattern_ok(W / 2)))
         return UAPS_ENOFORM;
     if (!no_small && !row16 && p.small && p.vec && !stats && !x2 && !y2 && (p.small == 1 || !xf)) return launch_small(a, p.small, s);
     if (p.split) {
@@ -432,9 +434,11 @@ int conv_fwd_any(const float* x, const float* wp, const float* bias, float* y, i
             if (W % 256 == 0 && H % 16 == 0 && !(g_conv_tuning & UAPS_TUNE_NO_ROW16)) return launch_hr16(a, s);
             return launch_hp16(a, s);
         }
+        if (up2) return UAPS_ENOFORM;      // (unreachable by the test above; kept so that a future edit of either cannot launch a wrong form)
         if (ks == 3) return wide ? dispatch_sfwd<3, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<3, 16, 16>(a, p.sbn, p.sck, s);
         return wide ? dispatch_sfwd<1, 8, 32>(a, p.sbn, p.sck, s) : dispatch_sfwd<1, 16, 16>(a, p.sbn, p.sck, s);
     }
+    if (up2) return UAPS_ENOFORM;
     if (p.dil == 2) return dispatch_dilated<2>(a, p.bn, p.vec, p.extra_lds, s);
     if (p.dil == 4) return dispatch_dilated<4>(a, p.bn, p.vec, p.extra_lds, s);
     if (ks == 3) return wide ? dispatch_bn_ck<3, 8, 32>(a, p.bn, p.ck, p.vec, p.extra_lds, s) : dispatch_bn_ck<3, 16, 16>(a, p.bn, p.ck, p.vec, p.extra_lds, s);
@@ -511,27 +515,51 @@ extern "C" int uaps_debug_set_stamp_buffer(unsigned long long* buf, unsigned lon
 }
 #endif
 
+// Every entry point below exists twice: `uaps_X(args)` takes its optional operands (bounds, statistics shift, ...) from the calling
+// thread's pending uaps_next_call_hints record (the legacy form), `uaps_X_h(hints, args)` takes them as its first argument (NULL =
+// none) and reads nothing thread-local (round 6: the form the Python package calls).
+extern "C" int uaps_conv_fwd_h(const uaps_call_hints* hints, const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout,
+                               int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return conv_fwd_any(h, x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream);
+}
 extern "C" int uaps_conv_fwd(const float* x, const float* wf, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                              int ks, int cfg, uaps_stream_t stream) {
-    return conv_fwd_any(x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream);
+    return conv_fwd_any(take_hints(), x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream);
 }
 
 // Forward convolution that also writes, per output channel, image and pixel tile, the (sum, sum of squares) of
 // its output: the first pass of the train-mode BatchNorm that follows every 3x3 conv of a ConvBlock
 // (UAPS_unet.py:37-38, 41-42), for uaps_bn_act_fwd_train_partials.  stats: float2 [Cout][B][parts_per_image].
+extern "C" int uaps_conv_fwd_stats_h(const uaps_call_hints* hints, const float* x, const float* wf, const float* bias, float* y, void* stats,
+                                     int B, int Cin, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!stats) return UAPS_EINVAL;
+    return conv_fwd_any(h, x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats);
+}
 extern "C" int uaps_conv_fwd_stats(const float* x, const float* wf, const float* bias, float* y, void* stats, int B, int Cin,
                                    int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    const uaps_call_hints h = take_hints();
     if (!stats) return UAPS_EINVAL;
-    return conv_fwd_any(x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats);
+    return conv_fwd_any(h, x, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats);
 }
 
 // y = conv(leaky_relu(batch_norm_train(x_raw))) where x_raw is a previous conv's raw output and the normalisation
 // coefficients xf [groups][Cin] float2 (scale, shift) come from uaps_bn_finalize_train: the activated
 // tensor between the two convs of a ConvBlock (UAPS_unet.py:38-41) is never written.  stats may be NULL.
+extern "C" int uaps_conv_fwd_bn_h(const uaps_call_hints* hints, const float* x_raw, const void* xf, float slope, int groups, const float* wf,
+                                  const float* bias, float* y, void* stats, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
+                                  uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!xf) return UAPS_EINVAL;
+    return conv_fwd_any(h, x_raw, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, nullptr, -1, nullptr, -1,
+                        xf, slope, groups);
+}
 extern "C" int uaps_conv_fwd_bn(const float* x_raw, const void* xf, float slope, int groups, const float* wf, const float* bias,
                                 float* y, void* stats, int B, int Cin, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    const uaps_call_hints h = take_hints();
     if (!xf) return UAPS_EINVAL;
-    return conv_fwd_any(x_raw, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, nullptr, -1, nullptr, -1,
+    return conv_fwd_any(h, x_raw, wf, bias, y, B, Cin, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, nullptr, -1, nullptr, -1,
                         xf, slope, groups);
 }
 
@@ -546,23 +574,43 @@ extern "C" int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W,
 
 // Convolution of the never-materialised concatenation torch.cat([x1, x2], dim=1) (UpBlock, UAPS_unet.py:84-85):
 // x1 [B,C1,H,W], x2 [B,C2,H,W], weights packed for Cin = C1 + C2; C1 % 8 == 0.  stats may be NULL.
+extern "C" int uaps_conv_fwd_cat_h(const uaps_call_hints* hints, const float* x1, int C1, const float* x2, int C2, const float* wf,
+                                   const float* bias, float* y, void* stats, int B, int Cout, int H, int W, int ks, int cfg,
+                                   uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!x2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
+    return conv_fwd_any(h, x1, wf, bias, y, B, C1 + C2, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, x2, C1);
+}
 extern "C" int uaps_conv_fwd_cat(const float* x1, int C1, const float* x2, int C2, const float* wf, const float* bias, float* y,
                                  void* stats, int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    const uaps_call_hints h = take_hints();
     if (!x2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
-    return conv_fwd_any(x1, wf, bias, y, B, C1 + C2, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, x2, C1);
+    return conv_fwd_any(h, x1, wf, bias, y, B, C1 + C2, Cout, H, W, ks, cfg, (hipStream_t)stream, (float2*)stats, x2, C1);
 }
 
 // Input gradient of that convolution, written as two tensors: dx1 [B,C1,H,W] and dx2 [B,C2,H,W].
+extern "C" int uaps_conv_bwd_data_cat_h(const uaps_call_hints* hints, const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2,
+                                        int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!dx2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
+    return conv_fwd_any(h, dy, wb, nullptr, dx1, B, Cout, C1 + C2, H, W, ks, cfg, (hipStream_t)stream, nullptr, nullptr, -1, dx2, C1);
+}
 extern "C" int uaps_conv_bwd_data_cat(const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2, int B, int Cout,
                                       int H, int W, int ks, int cfg, uaps_stream_t stream) {
+    const uaps_call_hints h = take_hints();
     if (!dx2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
-    return conv_fwd_any(dy, wb, nullptr, dx1, B, Cout, C1 + C2, H, W, ks, cfg, (hipStream_t)stream, nullptr, nullptr, -1, dx2, C1);
+    return conv_fwd_any(h, dy, wb, nullptr, dx1, B, Cout, C1 + C2, H, W, ks, cfg, (hipStream_t)stream, nullptr, nullptr, -1, dx2, C1);
 }
 
 // dx = conv(dy, W^T flipped): the same kernel with the roles of the channel counts exchanged
+extern "C" int uaps_conv_bwd_data_h(const uaps_call_hints* hints, const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H,
+                                    int W, int ks, int cfg, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return conv_fwd_any(h, dy, wb, nullptr, dx, B, Cout, Cin, H, W, ks, cfg, (hipStream_t)stream);
+}
 extern "C" int uaps_conv_bwd_data(const float* dy, const float* wb, float* dx, int B, int Cin, int Cout, int H, int W, int ks,
                                   int cfg, uaps_stream_t stream) {
-    return conv_fwd_any(dy, wb, nullptr, dx, B, Cout, Cin, H, W, ks, cfg, (hipStream_t)stream);
+    return conv_fwd_any(take_hints(), dy, wb, nullptr, dx, B, Cout, Cin, H, W, ks, cfg, (hipStream_t)stream);
 }
 
 // Name of the kernel instantiation uaps_conv_fwd / uaps_conv_bwd_data launch for these dimensions, as

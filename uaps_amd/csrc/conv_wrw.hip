@@ -162,10 +162,9 @@ extern "C" int uaps_conv_wrw_workspace_bytes(int B, int Cin, int Cout, int H, in
 }
 
 // Step 1: per-split partial gradients into the workspace (the MFMA kernel).
-static int wrw_partial_impl(const float* dy, const float* x, const float* x2, int Csplit, int want_bias, int B, int Cin, int Cout,
+static int wrw_partial_impl(const uaps_call_hints& hints, const float* dy, const float* x, const float* x2, int Csplit, int want_bias, int B, int Cin, int Cout,
                             int H, int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream,
                             const void* xf = nullptr, float xf_slope = 0.f, int groups = 1) {
-    const uaps_call_hints hints = uaps::take_hints();
     if (!dy || !x || !ws || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     // UAPS_CONV_X2_UP2 (include/uaps_hip.h): x2 is [B, Cin - Csplit, H / 2, W / 2], up-sampled x2 while staged
     const bool up2 = (cfg & UAPS_CONV_X2_UP2) != 0;
@@ -325,28 +324,51 @@ static int wrw_partial_impl(const float* dy, const float* x, const float* x2, in
     return ks == 3 ? dispatch_wrw<3>(a, p, vec, s) : dispatch_wrw<1>(a, p, vec, s);
 }
 
+// (each entry point twice: the legacy form reads the thread's pending uaps_next_call_hints record, the *_h form takes the record as
+// its first argument and reads nothing thread-local -- see conv_fwd.hip)
+extern "C" int uaps_conv_bwd_weight_partial_h(const uaps_call_hints* hints, const float* dy, const float* x, int want_bias, int B, int Cin,
+                                              int Cout, int H, int W, int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return wrw_partial_impl(h, dy, x, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+}
 extern "C" int uaps_conv_bwd_weight_partial(const float* dy, const float* x, int want_bias, int B, int Cin, int Cout, int H, int W,
                                             int ks, int cfg, void* ws, size_t ws_bytes, uaps_stream_t stream) {
-    return wrw_partial_impl(dy, x, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+    return wrw_partial_impl(uaps::take_hints(), dy, x, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
 }
 
 // Weight gradient of a convolution whose input is leaky_relu(batch_norm_train(y)) of a previous conv's raw output y
 // (ConvBlock, UAPS_unet.py:38-41): the activation is recomputed while staging from xf [groups][Cin] float2
 // (scale, shift) as uaps_bn_finalize_train wrote it.  W % 4 == 0, 16-byte aligned tensors.
+extern "C" int uaps_conv_bwd_weight_partial_bn_h(const uaps_call_hints* hints, const float* dy, const float* y, const void* xf, float slope,
+                                                 int groups, int want_bias, int B, int Cin, int Cout, int H, int W, int ks, int cfg,
+                                                 void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!xf) return UAPS_EINVAL;
+    return wrw_partial_impl(h, dy, y, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream, xf, slope, groups);
+}
 extern "C" int uaps_conv_bwd_weight_partial_bn(const float* dy, const float* y, const void* xf, float slope, int groups,
                                                int want_bias, int B, int Cin, int Cout, int H, int W, int ks, int cfg, void* ws,
                                                size_t ws_bytes, uaps_stream_t stream) {
+    const uaps_call_hints h = uaps::take_hints();
     if (!xf) return UAPS_EINVAL;
-    return wrw_partial_impl(dy, y, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream, xf, slope, groups);
+    return wrw_partial_impl(h, dy, y, nullptr, Cin, want_bias, B, Cin, Cout, H, W, ks, cfg, ws, ws_bytes, stream, xf, slope, groups);
 }
 
 // Weight gradient of a convolution whose input is the never-materialised concatenation of x1 [B,C1,H,W] and
 // x2 [B,C2,H,W] (C1 % 16 == 0); follow with uaps_conv_bwd_weight_reduce(..., Cin = C1 + C2, ...).
+extern "C" int uaps_conv_bwd_weight_partial_cat_h(const uaps_call_hints* hints, const float* dy, const float* x1, int C1, const float* x2, int C2,
+                                                  int want_bias, int B, int Cout, int H, int W, int ks, int cfg, void* ws, size_t ws_bytes,
+                                                  uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!x2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
+    return wrw_partial_impl(h, dy, x1, x2, C1, want_bias, B, C1 + C2, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+}
 extern "C" int uaps_conv_bwd_weight_partial_cat(const float* dy, const float* x1, int C1, const float* x2, int C2, int want_bias,
                                                 int B, int Cout, int H, int W, int ks, int cfg, void* ws, size_t ws_bytes,
                                                 uaps_stream_t stream) {
+    const uaps_call_hints h = uaps::take_hints();
     if (!x2 || C1 <= 0 || C2 <= 0) return UAPS_EINVAL;
-    return wrw_partial_impl(dy, x1, x2, C1, want_bias, B, C1 + C2, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
+    return wrw_partial_impl(h, dy, x1, x2, C1, want_bias, B, C1 + C2, Cout, H, W, ks, cfg, ws, ws_bytes, stream);
 }
 
 // Step 2: fixed-order sum of the partials into dw (and dbias).

@@ -21,6 +21,17 @@ uaps_call_hints take_hints() {
     else memset(&h, 0, sizeof h);
     return h;
 }
+int read_hints(const uaps_call_hints* in, uaps_call_hints& out) {
+    memset(&out, 0, sizeof out);
+    if (!in || in->struct_size == 0) return UAPS_OK;
+    // size-versioned: a client built against an older, shorter struct is read only as far as ITS struct goes
+    const unsigned n = in->struct_size;
+    if (n < offsetof(uaps_call_hints, out_amax) || n > sizeof(uaps_call_hints)) return UAPS_EINVAL;
+    memcpy(&out, in, n);
+    for (int i = 0; i < 3; ++i)
+        if (out.bound[i] && !(out.mul[i] > 0.f && out.mul[i] < 3.0e38f)) return UAPS_EINVAL;
+    return UAPS_OK;
+}
 LaunchEvents& launch_events() { return g_launch; }
 unsigned* error_word() { const int d = current_device(); return d >= 0 ? g_error_word[d] : nullptr; }
 }  // namespace uaps
@@ -75,14 +86,10 @@ extern "C" int uaps_next_launch_events(void* start, void* stop) {
 
 extern "C" int uaps_next_call_hints(const uaps_call_hints* h) {
     if (!h) { g_have = false; return UAPS_OK; }
-    // size-versioned: a client built against an older, shorter struct is read only as far as ITS struct goes
-    const unsigned n = h->struct_size;
-    if (n < offsetof(uaps_call_hints, out_amax) || n > sizeof(uaps_call_hints)) return UAPS_EINVAL;
+    if (h->struct_size == 0) return UAPS_EINVAL;
     uaps_call_hints t;
-    memset(&t, 0, sizeof t);
-    memcpy(&t, h, n);
-    for (int i = 0; i < 3; ++i)
-        if (t.bound[i] && !(t.mul[i] > 0.f && t.mul[i] < 3.0e38f)) return UAPS_EINVAL;
+    const int rc = uaps::read_hints(h, t);
+    if (rc) return rc;
     g_hints = t; g_have = true;
     return UAPS_OK;
 }

@@ -8,6 +8,15 @@ namespace uaps {
 // returns the pending hints (all-null when none) and clears them: every entry point that understands hints calls this
 // first, so that a hint never outlives the call it was meant for
 uaps_call_hints take_hints();
+// The explicit form (round 6: the *_h entry points, uaps_conv_ex): the caller's record of THIS call, copied size-versioned and validated
+// exactly like uaps_next_call_hints does; `in` == NULL or struct_size == 0 = no hints.  Nothing thread-local is read or written.
+int read_hints(const uaps_call_hints* in, uaps_call_hints& out);
+#define UAPS_READ_HINTS(in, name)                              \
+    uaps_call_hints name;                                       \
+    {                                                           \
+        const int rc_hints_ = uaps::read_hints(in, name);       \
+        if (rc_hints_) return rc_hints_;                        \
+    }
 
 // uaps_next_launch_events (include/uaps_hip.h): a pair of events the calling thread's next MAIN kernel launch (the convolution /
 // loss kernel of an entry point, not its packing, reduce or finalize launches) attaches to its dispatch, so that their

@@ -2,7 +2,7 @@
 #include "loss_dispatch.hpp"
 using namespace uaps;
 
-extern "C" int uaps_abi_version(void) { return 2; }      // 2 (round 5): uaps_call_hints::struct_size, UAPS_ENOFORM, uaps_conv_ex
+extern "C" int uaps_abi_version(void) { return 3; }      // 3 (round 6): the *_h entry points (explicit hints), uaps_conv_call::stream in front of the hints; 2: struct_size, UAPS_ENOFORM, uaps_conv_ex
 
 // Process-wide pointer to the device-resident step state (philox.hpp); every launch wrapper that has per-step scalars or
 // random draws passes it to its kernel.  NULL = by-value arguments only (the default; eager execution needs nothing else).
@@ -142,11 +142,30 @@ extern "C" int uaps_pairloss_finalize_sums(const double* sums, int D, int C, lon
     return (int)hipGetLastError();
 }
 
+static int pairloss_bwd_impl(float* amax_out, const float* const* lab_logits, const float* const* un_logits, const int64_t* labels,
+                             const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1, float cw2,
+                             const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss, float* const* dlab,
+                             float* const* dun, int cfg, uaps_stream_t stream);
 extern "C" int uaps_pairloss_bwd(const float* const* lab_logits, const float* const* un_logits, const int64_t* labels,
                                  const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1, float cw2,
                                  const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss, float* const* dlab,
                                  float* const* dun, int cfg, uaps_stream_t stream) {
-    float* amax_out = uaps::take_hints().out_amax;
+    return pairloss_bwd_impl(uaps::take_hints().out_amax, lab_logits, un_logits, labels, pseudo, sup_scalars, unsup_scalars, cw1, cw2, gscale,
+                             D, B, C, H, W, n_pixels_loss, dlab, dun, cfg, stream);
+}
+// (the *_h form: the hints of THIS call -- out_amax: raise this bound to max|d logits| -- as the first argument, nothing thread-local)
+extern "C" int uaps_pairloss_bwd_h(const uaps_call_hints* hints, const float* const* lab_logits, const float* const* un_logits,
+                                   const int64_t* labels, const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars,
+                                   float cw1, float cw2, const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss,
+                                   float* const* dlab, float* const* dun, int cfg, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return pairloss_bwd_impl(h.out_amax, lab_logits, un_logits, labels, pseudo, sup_scalars, unsup_scalars, cw1, cw2, gscale,
+                             D, B, C, H, W, n_pixels_loss, dlab, dun, cfg, stream);
+}
+static int pairloss_bwd_impl(float* amax_out, const float* const* lab_logits, const float* const* un_logits, const int64_t* labels,
+                             const int64_t* pseudo, const float* sup_scalars, const float* unsup_scalars, float cw1, float cw2,
+                             const float* gscale, int D, int B, int C, int H, int W, long n_pixels_loss, float* const* dlab,
+                             float* const* dun, int cfg, uaps_stream_t stream) {
     int rc = check_dims(D, B, C, H, W);
     if (rc) return rc;
     if ((rc = check_heads(lab_logits, D)) || (rc = check_heads(un_logits, D))) return rc;

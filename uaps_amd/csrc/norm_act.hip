@@ -530,12 +530,11 @@ extern "C" int uaps_bn_workspace_bytes(int B, int C, int H, int W, size_t* out) 
     return UAPS_OK;
 }
 
-static int bn_fwd_train_impl(const float2* given_partials, int given_parts_per_image, const float* y, const float* conv_bias, const float* gamma, const float* beta,
+static int bn_fwd_train_impl(const uaps_call_hints& hints, const float2* given_partials, int given_parts_per_image, const float* y, const float* conv_bias, const float* gamma, const float* beta,
                                              float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                              float momentum, float eps, float slope, float drop_p, uint64_t seed, uint64_t offset,
                                              int B, int C, int H, int W, int groups, float* out, float* save_mean,
                                              float* save_invstd, void* ws, size_t ws_bytes, uaps_stream_t stream) {
-    const uaps_call_hints hints = uaps::take_hints();
     // given partials: formed about the shift the caller names; own statistics pass: about running_mean - conv_bias
     const float* shm = given_partials ? hints.stats_mean : running_mean;
     const float* shb = given_partials ? hints.stats_bias : conv_bias;
@@ -574,38 +573,62 @@ extern "C" int uaps_bn_act_fwd_train_grouped(const float* y, const float* conv_b
                                              float momentum, float eps, float slope, float drop_p, uint64_t seed, uint64_t offset,
                                              int B, int C, int H, int W, int groups, float* out, float* save_mean,
                                              float* save_invstd, void* ws, size_t ws_bytes, uaps_stream_t stream) {
-    return bn_fwd_train_impl(nullptr, 0, y, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+    return bn_fwd_train_impl(uaps::take_hints(), nullptr, 0, y, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                              slope, drop_p, seed, offset, B, C, H, W, groups, out, save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
 // The statistics pass is skipped: `partials` (float2 [C][B][parts_per_image], e.g. from uaps_conv_fwd_stats) already
 // holds per-image partial (sum, sum of squares) of y.
-extern "C" int uaps_bn_act_fwd_train_partials(const void* partials, int parts_per_image, const float* y, const float* conv_bias,
-                                              const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                              int64_t* num_batches_tracked, float momentum, float eps, float slope, float drop_p,
-                                              uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* out,
-                                              float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                                              uaps_stream_t stream) {
+#define UAPS_BN_PARTIALS_PARAMS const void* partials, int parts_per_image, const float* y, const float* conv_bias,                        \
+                                              const float* gamma, const float* beta, float* running_mean, float* running_var,               \
+                                              int64_t* num_batches_tracked, float momentum, float eps, float slope, float drop_p,           \
+                                              uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* out,           \
+                                              float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, uaps_stream_t stream
+#define UAPS_BN_PARTIALS_ARGS (const float2*)partials, parts_per_image, y, conv_bias, gamma, beta, running_mean, running_var,                \
+                             num_batches_tracked, momentum, eps, slope, drop_p, seed, offset, B, C, H, W, groups, out, save_mean,            \
+                             save_invstd, ws, ws_bytes, stream
+extern "C" int uaps_bn_act_fwd_train_partials(UAPS_BN_PARTIALS_PARAMS) {
+    const uaps_call_hints h = uaps::take_hints();
     if (!partials || parts_per_image <= 0) return UAPS_EINVAL;
-    return bn_fwd_train_impl((const float2*)partials, parts_per_image, y, conv_bias, gamma, beta, running_mean, running_var,
-                             num_batches_tracked, momentum, eps, slope, drop_p, seed, offset, B, C, H, W, groups, out, save_mean,
-                             save_invstd, ws, ws_bytes, stream);
+    return bn_fwd_train_impl(h, UAPS_BN_PARTIALS_ARGS);
 }
+// (the *_h forms: the hints of THIS call as the first argument, nothing thread-local -- see conv_fwd.hip)
+extern "C" int uaps_bn_act_fwd_train_partials_h(const uaps_call_hints* hints, UAPS_BN_PARTIALS_PARAMS) {
+    UAPS_READ_HINTS(hints, h);
+    if (!partials || parts_per_image <= 0) return UAPS_EINVAL;
+    return bn_fwd_train_impl(h, UAPS_BN_PARTIALS_ARGS);
+}
+#undef UAPS_BN_PARTIALS_PARAMS
+#undef UAPS_BN_PARTIALS_ARGS
 
 // Statistics finalize only (no apply pass): per group and channel the batch mean / inverse std from the conv
 // epilogue's partials, the running-statistics update, and xf [groups][C] float2 = (scale, shift) = (gamma*invstd, beta - mean*scale),
 // the coefficients uaps_conv_fwd_bn / uaps_conv_bwd_weight_partial_bn apply while staging their input.
-extern "C" int uaps_bn_finalize_train(const void* partials, int parts_per_image, const float* conv_bias, const float* gamma,
+static int bn_finalize_train_impl(const uaps_call_hints& hints, const void* partials, int parts_per_image, const float* conv_bias, const float* gamma,
                                       const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                       float momentum, float eps, int B, int C, int H, int W, int groups, float* save_mean,
                                       float* save_invstd, void* xf, uaps_stream_t stream) {
-    const uaps_call_hints hints = uaps::take_hints();
     if (!partials || parts_per_image <= 0 || !gamma || !beta || !save_mean || !save_invstd || !xf || ((uintptr_t)xf % 8)) return UAPS_EINVAL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;
     hipLaunchKernelGGL(bn_finalize_fwd, dim3(C), dim3(kThreads * (groups < 4 ? groups : 4)), 0, (hipStream_t)stream, (const float2*)partials, B, B / groups,
                        parts_per_image, (double)H * W, conv_bias, gamma, beta, running_mean, running_var, num_batches_tracked,
                        momentum, eps, save_mean, save_invstd, (float*)nullptr, C, (float2*)xf, hints.stats_mean, hints.stats_bias);
     return (int)hipGetLastError();
+}
+extern "C" int uaps_bn_finalize_train(const void* partials, int parts_per_image, const float* conv_bias, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                      float momentum, float eps, int B, int C, int H, int W, int groups, float* save_mean,
+                                      float* save_invstd, void* xf, uaps_stream_t stream) {
+    return bn_finalize_train_impl(uaps::take_hints(), partials, parts_per_image, conv_bias, gamma, beta, running_mean, running_var,
+                                  num_batches_tracked, momentum, eps, B, C, H, W, groups, save_mean, save_invstd, xf, stream);
+}
+extern "C" int uaps_bn_finalize_train_h(const uaps_call_hints* hints, const void* partials, int parts_per_image, const float* conv_bias,
+                                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, float momentum, float eps, int B, int C, int H, int W, int groups,
+                                        float* save_mean, float* save_invstd, void* xf, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return bn_finalize_train_impl(h, partials, parts_per_image, conv_bias, gamma, beta, running_mean, running_var,
+                                  num_batches_tracked, momentum, eps, B, C, H, W, groups, save_mean, save_invstd, xf, stream);
 }
 
 extern "C" int uaps_bn_act_fwd_train(const float* y, const float* conv_bias, const float* gamma, const float* beta,
@@ -636,11 +659,10 @@ extern "C" int uaps_bn_act_fwd_eval(const float* y, const float* conv_bias, cons
     return (int)hipGetLastError();
 }
 
-static int bn_bwd_impl(const float* dout, const float* y, const float* gamma, const float* beta,
+static int bn_bwd_impl(float* amax_out, const float* dout, const float* y, const float* gamma, const float* beta,
                                        const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
                                        uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
                                        float* dbeta, float* dconv_bias, void* ws, size_t ws_bytes, uaps_stream_t stream) {
-    float* amax_out = uaps::take_hints().out_amax;
     int rc = check(dout, dy, B, C, H, W);
     if (rc) return rc;
     if (!y || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !ws || !(drop_p >= 0.f && drop_p < 1.f)) return UAPS_EINVAL;
@@ -669,7 +691,15 @@ extern "C" int uaps_bn_act_bwd_grouped(const float* dout, const float* y, const 
                                        const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
                                        uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
                                        float* dbeta, void* ws, size_t ws_bytes, uaps_stream_t stream) {
-    return bn_bwd_impl(dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
+    return bn_bwd_impl(uaps::take_hints().out_amax, dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
+                       dbeta, nullptr, ws, ws_bytes, stream);
+}
+extern "C" int uaps_bn_act_bwd_grouped_h(const uaps_call_hints* hints, const float* dout, const float* y, const float* gamma, const float* beta,
+                                         const float* save_mean, const float* save_invstd, float slope, float drop_p, uint64_t seed,
+                                         uint64_t offset, int B, int C, int H, int W, int groups, float* dy, float* dgamma,
+                                         float* dbeta, void* ws, size_t ws_bytes, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return bn_bwd_impl(h.out_amax, dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
                        dbeta, nullptr, ws, ws_bytes, stream);
 }
 
@@ -680,8 +710,19 @@ extern "C" int uaps_bn_act_bwd_grouped_bias(const float* dout, const float* y, c
                                             uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* dy,
                                             float* dgamma, float* dbeta, float* dconv_bias, void* ws, size_t ws_bytes,
                                             uaps_stream_t stream) {
+    float* amax_out = uaps::take_hints().out_amax;
     if (!dconv_bias) return UAPS_EINVAL;
-    return bn_bwd_impl(dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
+    return bn_bwd_impl(amax_out, dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
+                       dbeta, dconv_bias, ws, ws_bytes, stream);
+}
+extern "C" int uaps_bn_act_bwd_grouped_bias_h(const uaps_call_hints* hints, const float* dout, const float* y, const float* gamma,
+                                              const float* beta, const float* save_mean, const float* save_invstd, float slope, float drop_p,
+                                              uint64_t seed, uint64_t offset, int B, int C, int H, int W, int groups, float* dy,
+                                              float* dgamma, float* dbeta, float* dconv_bias, void* ws, size_t ws_bytes,
+                                              uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    if (!dconv_bias) return UAPS_EINVAL;
+    return bn_bwd_impl(h.out_amax, dout, y, gamma, beta, save_mean, save_invstd, slope, drop_p, seed, offset, B, C, H, W, groups, dy, dgamma,
                        dbeta, dconv_bias, ws, ws_bytes, stream);
 }
 
@@ -737,9 +778,19 @@ extern "C" int uaps_bn_act_bwd_finalize(const void* partials, int parts_per_imag
     return (int)hipGetLastError();
 }
 
+static int bn_bwd_apply_impl(float* amax_out, const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W,
+                             int groups, float* dy, uaps_stream_t stream);
 extern "C" int uaps_bn_act_bwd_apply(const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W,
                                      int groups, float* dy, uaps_stream_t stream) {
-    float* amax_out = uaps::take_hints().out_amax;
+    return bn_bwd_apply_impl(uaps::take_hints().out_amax, dout, y, coef, slope, B, C, H, W, groups, dy, stream);
+}
+extern "C" int uaps_bn_act_bwd_apply_h(const uaps_call_hints* hints, const float* dout, const float* y, const float* coef, float slope, int B,
+                                       int C, int H, int W, int groups, float* dy, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return bn_bwd_apply_impl(h.out_amax, dout, y, coef, slope, B, C, H, W, groups, dy, stream);
+}
+static int bn_bwd_apply_impl(float* amax_out, const float* dout, const float* y, const float* coef, float slope, int B, int C, int H, int W,
+                             int groups, float* dy, uaps_stream_t stream) {
     int rc = check(dout, dy, B, C, H, W);
     if (rc) return rc;
     if (!y || !coef || groups < 1 || groups > kMaxGroups || B % groups) return UAPS_EINVAL;

@@ -339,8 +339,16 @@ inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 // The two batches of a training step as one (UAPS_train.py:177 + :185 run as one pass, unet.UNet_UAPS.forward_pair): out [2n] =
 // a [n] followed by b [n]; with uaps_call_hints::out_amax the bound of the result is raised to max|out| on the way, so the first
 // convolution's weight gradient can take the fp16 form.
+static int cat2_impl(float* amax, const float* a, const float* b, float* out, long n, uaps_stream_t stream);
 extern "C" int uaps_cat2(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
-    float* amax = uaps::take_hints().out_amax;
+    return cat2_impl(uaps::take_hints().out_amax, a, b, out, n, stream);
+}
+// (the *_h forms: the hints of THIS call as the first argument, nothing thread-local -- see conv_fwd.hip)
+extern "C" int uaps_cat2_h(const uaps_call_hints* hints, const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return cat2_impl(h.out_amax, a, b, out, n, stream);
+}
+static int cat2_impl(float* amax, const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
     if (!a || !b || !out || n <= 0) return UAPS_EINVAL;
     uaps::account_bytes(16.0 * n);                        // both halves read, the joined batch written
     const long n4 = (al16p(a) && al16p(b) && al16p(out) && n % 4 == 0) ? n / 4 : 0;
@@ -359,8 +367,15 @@ extern "C" int uaps_relu_bwd_sum(const float* const* dout_host, int k, const flo
     return (int)hipGetLastError();
 }
 
+static int add_relu_impl(float* amax, const float* a, const float* b, float* out, long n, uaps_stream_t stream);
 extern "C" int uaps_add_relu(const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
-    float* amax = uaps::take_hints().out_amax;
+    return add_relu_impl(uaps::take_hints().out_amax, a, b, out, n, stream);
+}
+extern "C" int uaps_add_relu_h(const uaps_call_hints* hints, const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, h);
+    return add_relu_impl(h.out_amax, a, b, out, n, stream);
+}
+static int add_relu_impl(float* amax, const float* a, const float* b, float* out, long n, uaps_stream_t stream) {
     if (!a || !b || !out || n <= 0) return UAPS_EINVAL;
     const long n4 = (al16p(a) && al16p(b) && al16p(out)) ? n / 4 : 0;
     hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(kThreads), 0, (hipStream_t)stream, a, b, out, n4, n, amax);

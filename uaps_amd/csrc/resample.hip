@@ -254,9 +254,18 @@ __global__ __launch_bounds__(kThreads) void slice_channels_kernel(const float* _
 }
 }  // namespace
 
+static int up_cat_fwd_impl(float* amax_out, const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w, uaps_stream_t stream);
 extern "C" int uaps_up_cat_fwd(const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w,
                                uaps_stream_t stream) {
-    float* amax_out = uaps::take_hints().out_amax;
+    return up_cat_fwd_impl(uaps::take_hints().out_amax, skip, low, out, B, Cs, Cl, h, w, stream);
+}
+// (the *_h form: the hints of THIS call as the first argument, nothing thread-local -- see conv_fwd.hip)
+extern "C" int uaps_up_cat_fwd_h(const uaps_call_hints* hints, const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h,
+                                 int w, uaps_stream_t stream) {
+    UAPS_READ_HINTS(hints, hh);
+    return up_cat_fwd_impl(hh.out_amax, skip, low, out, B, Cs, Cl, h, w, stream);
+}
+static int up_cat_fwd_impl(float* amax_out, const float* skip, const float* low, float* out, int B, int Cs, int Cl, int h, int w, uaps_stream_t stream) {
     if (!skip || !low || !out || B <= 0 || Cs < 0 || Cl <= 0 || h <= 0 || w <= 0) return UAPS_EINVAL;
     const int H = 2 * h, W = 2 * w;
     const float rh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;

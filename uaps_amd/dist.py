@@ -84,6 +84,8 @@ class GradBuckets:
             for p, o in zip(params, offs):
                 _graddest.register(p, flat, o)
         self._hooks = []
+        self.step = None                       # the trainer's open step scope (conv.deferred_reduces), set by the trainer for each step:
+                                               # the hook that completes a bucket reduces that bucket's deferred weight gradients first
         self.defer = False
         self.muted = False                     # hooks do nothing (a caller that steps without any exchange: bench.py's no-exchange leg)
         if self.world > 1 and overlap:
@@ -115,7 +117,7 @@ class GradBuckets:
 
     def _launch(self, bi: int):
         from . import conv
-        conv.flush_params(self._ids[bi])         # inside a trainer's deferred_reduces scope: this bucket's weight gradients, one launch
+        conv.flush_params(self.step, self._ids[bi])      # inside a trainer's deferred_reduces scope: this bucket's weight gradients, one launch
         flat = self._flat[bi]
         for k, p in enumerate(self.buckets[bi]):
             v = self._view(bi, k)

@@ -9,31 +9,31 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import _graddest, lazybn, _lib, bounds
-from .perturb import _RngState
+from . import _graddest, lazybn, _lib, bounds, stepctx
+from . import perturb as _perturb
 
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 
-# Number of statistics groups of the train-mode BatchNorms: the batch is `STAT_GROUPS` consecutive blocks, each
+# Number of statistics groups of the train-mode BatchNorms: the batch is `_groups()` consecutive blocks, each
 # normalised on its own (UNet_UAPS.forward_pair runs the labelled and the unlabelled batch of a step as one
 # 2-group batch, which is what the reference's two separate forwards compute, UAPS_train.py:177,185).
-STAT_GROUPS = 1
+def _groups() -> int:
+    return stepctx.fwd().stat_groups
 
 
 class stat_groups:
-    """Context manager: `with stat_groups(2): model(x)`."""
+    """Context manager: `with stat_groups(2): model(x)`.  Per thread (a forward runs on one thread)."""
 
     def __init__(self, n: int):
         self.n = int(n)
 
     def __enter__(self):
-        global STAT_GROUPS
-        self.prev, STAT_GROUPS = STAT_GROUPS, self.n
+        f = stepctx.fwd()
+        self.prev, f.stat_groups = f.stat_groups, self.n
         return self
 
     def __exit__(self, *a):
-        global STAT_GROUPS
-        STAT_GROUPS = self.prev
+        stepctx.fwd().stat_groups = self.prev
         return False
 
 
@@ -70,12 +70,12 @@ class _BnActTrain(torch.autograd.Function):
         if stats_partials is not None:
             if stats_partials.shape[:2] != (Cc, B) or stats_partials.shape[-1] != 2 or not stats_partials.is_contiguous():
                 raise ValueError("bn_act: stats must be the [C, B, parts, 2] tensor conv2d_with_stats returned for this y")
-            fn, head = _lib.lib().uaps_bn_act_fwd_train_partials, (stats_partials.data_ptr(), int(stats_partials.shape[2]))
+            fn, head = _lib.lib().uaps_bn_act_fwd_train_partials_h, (stats_partials.data_ptr(), int(stats_partials.shape[2]))
         else:
             fn, head = _lib.lib().uaps_bn_act_fwd_train_grouped, ()
         with _lib.device_guard(dev):
-            if stats_partials is not None and getattr(stats_partials, "_uaps_shifted", False):
-                _lib.hints((), None, (running_mean, conv_bias))      # the shift the producing conv formed its sums about
+            if stats_partials is not None:       # hints: the shift the producing conv formed its sums about
+                head = (_lib.mk_hints((), None, (running_mean, conv_bias)) if getattr(stats_partials, "_uaps_shifted", False) else None,) + head
             rc = fn(
                 *head, y.data_ptr(), conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
@@ -103,9 +103,7 @@ class _BnActTrain(torch.autograd.Function):
         ws = _bn_ws(dev, B, Cc, H, W)
         am = bounds.new_amax(dev) if bounds.enabled() else None      # max|dy|: the operand bound of the convolution's backward
         with _lib.device_guard(dev):
-            if am is not None:
-                _lib.hints((), am)
-            rc = _lib.lib().uaps_bn_act_bwd_grouped_bias(dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+            rc = _lib.lib().uaps_bn_act_bwd_grouped_bias_h(_lib.mk_hints((), am) if am is not None else None, dout.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                          stats[0].data_ptr(), stats[1].data_ptr(), slope, drop_p, seed, offset, B,
                                                          Cc, H, W, groups, dy.data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(),
                                                          dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
@@ -138,9 +136,8 @@ class _BnAddRelu(torch.autograd.Function):
         ws = _bn_ws(dev, B, Cc, H, W)
         with _lib.device_guard(dev):
             shifted = getattr(stats_partials, "_uaps_shifted", False)
-            _lib.hints((), am, (running_mean, None) if shifted else None, residual=identity)
-            rc = _lib.lib().uaps_bn_act_fwd_train_partials(
-                stats_partials.data_ptr(), int(stats_partials.shape[2]), y.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(),
+            rc = _lib.lib().uaps_bn_act_fwd_train_partials_h(
+                _lib.mk_hints((), am, (running_mean, None) if shifted else None, residual=identity), stats_partials.data_ptr(), int(stats_partials.shape[2]), y.data_ptr(), None, gamma.data_ptr(), beta.data_ptr(),
                 running_mean.data_ptr() if running_mean is not None else None,
                 running_var.data_ptr() if running_var is not None else None, nbt.data_ptr() if nbt is not None else None,
                 float(momentum), float(eps), 1.0, 0.0, 0, 0, B, Cc, H, W, groups, out.data_ptr(), stats[0].data_ptr(),
@@ -169,9 +166,7 @@ class _BnAddRelu(torch.autograd.Function):
             st = _lib.current_stream(dev)
             arr = (C.c_void_p * len(gs))(*[g.data_ptr() for g in gs])
             _lib.check(L.uaps_relu_bwd_sum(arr, len(gs), out.data_ptr(), d.data_ptr(), out.numel(), st), "uaps_relu_bwd_sum")
-            if am is not None:
-                _lib.hints((), am)
-            rc = L.uaps_bn_act_bwd_grouped(d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+            rc = L.uaps_bn_act_bwd_grouped_h(_lib.mk_hints((), am) if am is not None else None, d.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
                                            stats[1].data_ptr(), 1.0, 0.0, 0, 0, B, Cc, H, W, ctx.groups, dy.data_ptr(), dgb[0].data_ptr(),
                                            dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), st)
         _lib.check(rc, "uaps_bn_act_bwd_grouped")
@@ -186,7 +181,7 @@ def bn_add_relu(y: torch.Tensor, stats: torch.Tensor, bn: nn.BatchNorm2d, identi
     mom = 0.1 if bn.momentum is None else bn.momentum
     am = bounds.new_amax(y.device) if bounds.enabled() else None      # max(out), raised by the apply pass: the join feeds the next block's convolutions
     outs = tuple(bounds.put(o, am) for o in _BnAddRelu.apply(y, identity, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                                            bn.num_batches_tracked, mom, bn.eps, STAT_GROUPS, stats, n, am))
+                                                            bn.num_batches_tracked, mom, bn.eps, _groups(), stats, n, am))
     return outs[0] if n == 1 else outs
 
 
@@ -234,12 +229,12 @@ def bn_act(y: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2
     (UAPS_unet.py:38-40), as three streaming kernels."""
     if training or not bn.track_running_stats:
         p = float(drop_p) if training else 0.0
-        seed, off = _RngState.reserve(y.numel()) if p > 0 else (0, 0)
+        seed, off = _perturb.rng().reserve(y.numel()) if p > 0 else (0, 0)
         mom = 0.1 if bn.momentum is None else bn.momentum
         out = _BnActTrain.apply(y, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                mom, bn.eps, slope, p, seed, off, STAT_GROUPS, stats)
+                                mom, bn.eps, slope, p, seed, off, _groups(), stats)
         if y.is_cuda and slope <= 1.0:             # |gamma x_hat + beta| <= sqrt(n) max(|gamma| + |beta|), dropout scales by 1 / (1 - p)
-            b = bounds.bn_output_bound(bn, y.shape[0] // STAT_GROUPS * y.shape[2] * y.shape[3], 1.0 / (1.0 - p))
+            b = bounds.bn_output_bound(bn, y.shape[0] // _groups() * y.shape[2] * y.shape[3], 1.0 / (1.0 - p))
             if b is not None:
                 bounds.put(out, *b)
         return out
@@ -279,9 +274,8 @@ class _BnActConv(torch.autograd.Function):
             zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg), 2), dtype=torch.float32, device=dev)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
-            if getattr(stats_partials, "_uaps_shifted", False):
-                _lib.hints((), None, (running_mean, conv_bias))
-            rc = L.uaps_bn_finalize_train(stats_partials.data_ptr(), int(stats_partials.shape[2]),
+            rc = L.uaps_bn_finalize_train_h(_lib.mk_hints((), None, (running_mean, conv_bias)) if getattr(stats_partials, "_uaps_shifted", False) else None,
+                                            stats_partials.data_ptr(), int(stats_partials.shape[2]),
                                           conv_bias.data_ptr() if conv_bias is not None else None, gamma.data_ptr(),
                                           beta.data_ptr(), running_mean.data_ptr() if running_mean is not None else None,
                                           running_var.data_ptr() if running_var is not None else None,
@@ -291,9 +285,10 @@ class _BnActConv(torch.autograd.Function):
             am = _conv._claim_amax(dev)               # conv.request_out_amax(): track max|z| (the 1x1 projection in front of an up-sampling)
             for attempt in range(2):
                 with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, cfg, _conv._h16(xb)) as tm:
+                    hh = None
                     if xb is not None or (want_stats and stat_shift is not None) or am is not None:
-                        _lib.hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
-                    rc = L.uaps_conv_fwd_bn(y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
+                        hh = _lib.mk_hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
+                    rc = L.uaps_conv_fwd_bn_h(hh, y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
                                             bias.data_ptr() if bias is not None else None, z.data_ptr(),
                                             zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, cfg, st)
                     if rc == _conv.ENOFORM:
@@ -307,7 +302,9 @@ class _BnActConv(torch.autograd.Function):
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
         ctx.prefs = _conv.leaf_refs(weight, bias)
+        ctx.step = _conv.step_of(ctx.prefs)
         ctx.xb = xb
+        ctx.lazy_scope = lazybn.current()
         ctx.lazy_up = lazybn.marked(y) and y.requires_grad      # y's producer applies a pending BatchNorm transform (and will run): the backward hands d(activation) up
         if want_stats:
             zstats._uaps_shifted = stat_shift is not None
@@ -330,7 +327,7 @@ class _BnActConv(torch.autograd.Function):
         L = _lib.lib()
         n = C.c_size_t()
         _lib.check(L.uaps_conv_wrw_workspace_bytes(B, Cc, Cout, H, W, ks, cfg, C.byref(n)), "uaps_conv_wrw_workspace_bytes")
-        cws = _conv._wrw_workspace(dev, n.value, ctx.prefs)
+        cws = _conv._wrw_workspace(dev, n.value, ctx.prefs, ctx.step)
         dw = _graddest.take(ctx.keys[3], (Cout, Cc, ks, ks), dev)
         want_db = has_bias and ctx.needs_input_grad[13]
         db = _graddest.take(ctx.keys[4], (Cout,), dev) if want_db else None
@@ -341,18 +338,19 @@ class _BnActConv(torch.autograd.Function):
             with _lib.device_guard(dev):
                 st = _lib.current_stream(dev)
                 with _conv._timed("wrw_bn", B, Cc, Cout, H, W, ks, cfg, _conv._h16(dzb, xb), dt=lz is not None) as tm:
+                    hh = None
                     if lz is not None:
-                        _lib.hints((dzb, xb), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
+                        hh = _lib.mk_hints((dzb, xb), dyt=(lz.y, lz.coef, out, lz.slope, lz.groups))
                     elif dzb is not None and xb is not None:
-                        _lib.hints((dzb, xb))
-                    rc = L.uaps_conv_bwd_weight_partial_bn(dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
+                        hh = _lib.mk_hints((dzb, xb))
+                    rc = L.uaps_conv_bwd_weight_partial_bn_h(hh, dz.data_ptr(), y.data_ptr(), xf.data_ptr(), slope, groups, int(want_db), B, Cc,
                                                            Cout, H, W, ks, cfg, cws.data_ptr(), cws.numel(), st)
                     if lz is not None and rc == lazybn.ENOFORM:
                         tm.on = False
                 if lz is not None and rc == lazybn.ENOFORM:
                     return None
                 _lib.check(rc, "uaps_conv_bwd_weight_partial_bn")
-                _conv._wrw_reduce(cws, dw, db, B, Cc, Cout, H, W, ks, cfg, st, ctx.prefs)
+                _conv._wrw_reduce(cws, dw, db, B, Cc, Cout, H, W, ks, cfg, st, ctx.prefs, ctx.step)
             return bounds.put(out, *lz.bound) if lz is not None else dz
 
         done_w = False
@@ -374,18 +372,16 @@ class _BnActConv(torch.autograd.Function):
         if lazy_up:
             # the reductions only; d(activation) goes up as it is, its transform pending (lazybn): y's producer forms dy in its weight gradient
             if partials is not None:
-                lazybn.prepare_from_partials(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], partials, maxes)
+                lazybn.prepare_from_partials(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], partials, maxes, scope=ctx.lazy_scope)
             else:
-                lazybn.prepare(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], ws)
+                lazybn.prepare(da, y, gamma, beta, stats[0], stats[1], slope, groups, dgb[0], dgb[1], dgb[2], ws, scope=ctx.lazy_scope)
             dy = da
         else:
             dy = torch.empty_like(y)
             with _lib.device_guard(dev):
                 st = _lib.current_stream(dev)
                 am = bounds.new_amax(dev) if bounds.enabled() else None
-                if am is not None:
-                    _lib.hints((), am)
-                rc = L.uaps_bn_act_bwd_grouped_bias(da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                rc = L.uaps_bn_act_bwd_grouped_bias_h(_lib.mk_hints((), am) if am is not None else None, da.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
                                                     stats[1].data_ptr(), slope, 0.0, 0, 0, B, Cc, H, W, groups, dy.data_ptr(),
                                                     dgb[0].data_ptr(), dgb[1].data_ptr(), dgb[2].data_ptr(), ws.data_ptr(), ws.numel(), st)
                 _lib.check(rc, "uaps_bn_act_bwd_grouped_bias")
@@ -395,7 +391,7 @@ class _BnActConv(torch.autograd.Function):
 
 def can_fuse_bn_into_conv(y: torch.Tensor, weight: torch.Tensor) -> bool:
     """The staging-time BatchNorm of bn_act_conv needs 16-byte rows and the 8-channel-chunk kernels."""
-    return y.is_cuda and y.shape[3] % 4 == 0 and y.shape[1] > 4 and weight.shape[2] in (1, 3) and STAT_GROUPS <= 8
+    return y.is_cuda and y.shape[3] % 4 == 0 and y.shape[1] > 4 and weight.shape[2] in (1, 3) and _groups() <= 8
 
 
 def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.Tensor], bn: nn.BatchNorm2d, slope: float,
@@ -403,9 +399,9 @@ def bn_act_conv(y: torch.Tensor, stats: torch.Tensor, conv_bias: Optional[torch.
     """conv2d(leaky_relu(bn_train(y + conv_bias)), weight, bias) (+ the epilogue statistics of the result) where `y`,
     `stats` come from conv2d_with_stats: train-mode only, no dropout between the two (decoder ConvBlocks)."""
     mom = 0.1 if bn.momentum is None else bn.momentum
-    xb = bounds.bn_output_bound(bn, y.shape[0] // STAT_GROUPS * y.shape[2] * y.shape[3]) if slope <= 1.0 else None
+    xb = bounds.bn_output_bound(bn, y.shape[0] // _groups() * y.shape[2] * y.shape[3]) if slope <= 1.0 else None
     res = _BnActConv.apply(y, stats, conv_bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                           mom, bn.eps, slope, STAT_GROUPS, weight, bias, want_stats, xb, stat_shift)
+                           mom, bn.eps, slope, _groups(), weight, bias, want_stats, xb, stat_shift)
     if want_stats:
         res[1]._uaps_shifted = stat_shift is not None
         lazybn.mark(res[0], weight)        # z feeds a BatchNorm of its own: its gradient may arrive with that transform pending
@@ -493,14 +489,11 @@ def cat_batches(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
     am = bounds.new_amax(a.device) if bounds.enabled() else None
     with _lib.device_guard(a.device):
-        if am is not None:
-            _lib.hints((), am)
-        rc = _lib.lib().uaps_cat2(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
+        rc = _lib.lib().uaps_cat2_h(_lib.mk_hints((), am) if am is not None else None, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
     _lib.check(rc, "uaps_cat2")
     return bounds.put(out, am) if am is not None else out
 
 
-_last_up2x_amax = None
 
 
 class _Up2x(torch.autograd.Function):
@@ -516,14 +509,11 @@ class _Up2x(torch.autograd.Function):
         # max|out| for the convolution that reads the up-sampled tensor (the LDS-tiled kernel of 16-byte rows tracks it)
         am = bounds.new_amax(low.device) if bounds.enabled() and (2 * w) % 4 == 0 and out.data_ptr() % 16 == 0 else None
         with _lib.device_guard(low.device):
-            if am is not None:
-                _lib.hints((), am)
-            rc = _lib.lib().uaps_up_cat_fwd(low.data_ptr(), low.data_ptr(), out.data_ptr(), B, 0, Cl, h, w,
+            rc = _lib.lib().uaps_up_cat_fwd_h(_lib.mk_hints((), am) if am is not None else None, low.data_ptr(), low.data_ptr(), out.data_ptr(), B, 0, Cl, h, w,
                                             _lib.current_stream(low.device))
         _lib.check(rc, "uaps_up_cat_fwd")
         ctx.meta = (B, Cl, h, w)
-        global _last_up2x_amax
-        _last_up2x_amax = am
+        stepctx.fwd().last_up2x_amax = am
         return out
 
     @staticmethod
@@ -538,7 +528,7 @@ class _Up2x(torch.autograd.Function):
 
 
 def upsample2x(low: torch.Tensor) -> torch.Tensor:
-    global _last_up2x_amax
     out = _Up2x.apply(low)
-    am, _last_up2x_amax = _last_up2x_amax, None
+    f = stepctx.fwd()
+    am, f.last_up2x_amax = f.last_up2x_amax, None
     return bounds.put(out, am)

@@ -121,8 +121,10 @@ class StepGraph:
     def _head(self, x_l, y_l, x_u):
         """Forward, loss block and backward; every per-step scalar comes from the step state (w = None, cw = NaN)."""
         tr = self.tr
-        perturb._RngState.offset = 0                 # the key changes every step: the counters may restart (and must, for replays)
-        with lazybn.scope(), conv.deferred_reduces(on_early=tr._early_adam()):
+        perturb.rng().offset = 0                 # the key changes every step: the counters may restart (and must, for replays)
+        with lazybn.scope(), conv.deferred_reduces(on_early=tr._early_adam(), model=tr.model) as step:
+            if tr.buckets is not None:
+                tr.buckets.step = step
             both = tr.model.forward_pair(x_l, x_u)
             out = losses.uaps_pair_loss(both, y_l, None, NAN, NAN)
             tr.optimizer.zero_grad(set_to_none=True)

@@ -26,46 +26,67 @@ from typing import Optional
 
 import torch
 
-from . import _lib, bounds
+from . import _lib, bounds, config, stepctx
 
-_ON = os.environ.get("UAPS_LAZY_BN_BWD", "1") != "0"
+_ON = config.flag("UAPS_LAZY_BN_BWD", True)
 _OK = "_uaps_lazy_ok"
 _REC = "_uaps_lazy"
-_depth = 0             # open scopes (forward runs on the caller's thread; autograd's worker threads only touch _outstanding)
-_outstanding = 0       # records handed up and not yet taken
 _prepared = 0          # records ever handed up (tests)
 
 
-class Lazy:
-    __slots__ = ("y", "coef", "slope", "groups", "bound", "version", "ptr")
+class Scope:
+    """One `with lazybn.scope():` block.  The forward (one thread) asks `current()` for it; the nodes that hand gradients up keep it
+    on their ctx, so the count of records handed up and not yet taken belongs to THIS step whichever autograd thread runs its
+    backward and whatever other trainers do meanwhile (round 6; the count was a module global)."""
+    __slots__ = ("outstanding", "depth")
 
-    def __init__(self, y, coef, slope, groups, bound, version=0, ptr=0):
+    def __init__(self):
+        self.outstanding = 0
+        self.depth = 0
+
+
+_loose = Scope()       # records prepared by direct calls outside any scope (tests, tools)
+
+
+def current() -> Optional[Scope]:
+    """The scope open on the calling thread, or None."""
+    return stepctx.fwd().lazy_scope
+
+
+class Lazy:
+    __slots__ = ("y", "coef", "slope", "groups", "bound", "version", "ptr", "scope")
+
+    def __init__(self, y, coef, slope, groups, bound, version=0, ptr=0, scope=None):
         self.y, self.coef, self.slope, self.groups, self.bound = y, coef, float(slope), int(groups), bound
-        self.version, self.ptr = version, ptr
+        self.version, self.ptr, self.scope = version, ptr, scope
 
 
 @contextlib.contextmanager
 def scope():
     """Forward + backward of one training step of a caller that drives both itself (the trainers): inside, marked conv outputs get
     the two-halves backward.  On a clean exit every handed-up gradient must have been taken by its producer; an exception drops
-    what a failed backward left behind."""
-    global _depth, _outstanding
-    if _depth == 0:
-        _outstanding = 0
-    _depth += 1
+    what a failed backward left behind.  Belongs to the calling thread; nested scopes join the outer one."""
+    f = stepctx.fwd()
+    sc = f.lazy_scope
+    outer = sc is None
+    if outer:
+        sc = f.lazy_scope = Scope()
+    sc.depth += 1
     try:
-        yield
+        yield sc
     except BaseException:
-        _outstanding = 0
+        sc.outstanding = 0
         raise
     finally:
-        _depth -= 1
-    if _depth == 0:
-        assert_none_pending()
+        sc.depth -= 1
+        if outer:
+            f.lazy_scope = None
+    if outer:
+        assert_none_pending(sc)
 
 
 def enabled() -> bool:
-    return _ON and _depth > 0 and bounds.enabled()
+    return _ON and stepctx.fwd().lazy_scope is not None and bounds.enabled()
 
 
 def mark(y: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -88,9 +109,11 @@ def marked(y: torch.Tensor) -> bool:
     return enabled() and bool(getattr(y, _OK, False)) and not observed(y)
 
 
-def prepare(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dconv_bias, ws) -> Lazy:
-    """The reductions of the BatchNorm backward of (dout = d(activation), y); attaches the pending record to dout and returns it."""
-    global _outstanding, _prepared
+def prepare(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dconv_bias, ws, scope: Optional[Scope] = None) -> Lazy:
+    """The reductions of the BatchNorm backward of (dout = d(activation), y); attaches the pending record to dout and returns it.
+    scope: the Scope the owning node's forward ran in (kept on its ctx), else the loose count."""
+    global _prepared
+    scope = scope or _loose
     B, Cc, H, W = y.shape
     dev = y.device
     coef = torch.empty((groups, Cc, 8), dtype=torch.float32, device=dev)
@@ -102,17 +125,19 @@ def prepare(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dc
                                                 dconv_bias.data_ptr() if dconv_bias is not None else None, bnd.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), _lib.current_stream(dev))
     _lib.check(rc, "uaps_bn_act_bwd_prepare")
-    lz = Lazy(y, coef, slope, groups, (bnd, 1.0), dout._version, dout.data_ptr())
+    lz = Lazy(y, coef, slope, groups, (bnd, 1.0), dout._version, dout.data_ptr(), scope)
     setattr(dout, _REC, lz)
-    _outstanding += 1
+    scope.outstanding += 1
     _prepared += 1
     return lz
 
 
-def prepare_from_partials(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dconv_bias, partials, maxes) -> Lazy:
+def prepare_from_partials(dout, y, gamma, beta, mean, invstd, slope, groups, dgamma, dbeta, dconv_bias, partials, maxes,
+                          scope: Optional[Scope] = None) -> Lazy:
     """`prepare` whose reductions were formed in the epilogue of the kernel that wrote dout (conv.conv_bwd_data_raw bsum:
     partials float2 [C][B][parts], maxes = max|d| and max|x_hat|): the finalize alone."""
-    global _outstanding, _prepared
+    global _prepared
+    scope = scope or _loose
     B, Cc, H, W = y.shape
     dev = y.device
     coef = torch.empty((groups, Cc, 8), dtype=torch.float32, device=dev)
@@ -123,9 +148,9 @@ def prepare_from_partials(dout, y, gamma, beta, mean, invstd, slope, groups, dga
                                                  dbeta.data_ptr(), dconv_bias.data_ptr() if dconv_bias is not None else None, bnd.data_ptr(),
                                                  _lib.current_stream(dev))
     _lib.check(rc, "uaps_bn_act_bwd_finalize")
-    lz = Lazy(y, coef, slope, groups, (bnd, 1.0), dout._version, dout.data_ptr())
+    lz = Lazy(y, coef, slope, groups, (bnd, 1.0), dout._version, dout.data_ptr(), scope)
     setattr(dout, _REC, lz)
-    _outstanding += 1
+    scope.outstanding += 1
     _prepared += 1
     return lz
 
@@ -137,14 +162,14 @@ def prepared_total() -> int:
 def take(dz: Optional[torch.Tensor]) -> Optional[Lazy]:
     """The pending transform of the gradient tensor dz (call before anything that could copy it), or None.  Raises when dz is
     no longer the tensor that was handed up (summed in place with another consumer's gradient, resized, re-pointed)."""
-    global _outstanding
     if dz is None:
         return None
     lz = getattr(dz, _REC, None)
     if lz is None:
         return None
     delattr(dz, _REC)
-    _outstanding = max(0, _outstanding - 1)
+    if lz.scope is not None:
+        lz.scope.outstanding = max(0, lz.scope.outstanding - 1)
     if dz._version != lz.version or dz.data_ptr() != lz.ptr or dz.shape != lz.y.shape or dz.device != lz.y.device:
         raise RuntimeError("a gradient with a pending BatchNorm transform was modified before its producer saw it (a second "
                            "consumer of a raw conv output inside lazybn.scope()?); set UAPS_LAZY_BN_BWD=0")
@@ -158,9 +183,7 @@ def materialize(dz: torch.Tensor, lz: Lazy) -> torch.Tensor:
     dy = torch.empty_like(lz.y)
     am = bounds.new_amax(dz.device) if bounds.enabled() else None
     with _lib.device_guard(dz.device):
-        if am is not None:
-            _lib.hints((), am)
-        rc = _lib.lib().uaps_bn_act_bwd_apply(dz.data_ptr(), lz.y.data_ptr(), lz.coef.data_ptr(), lz.slope, B, Cc, H, W, lz.groups,
+        rc = _lib.lib().uaps_bn_act_bwd_apply_h(_lib.mk_hints((), am) if am is not None else None, dz.data_ptr(), lz.y.data_ptr(), lz.coef.data_ptr(), lz.slope, B, Cc, H, W, lz.groups,
                                               dy.data_ptr(), _lib.current_stream(dz.device))
     _lib.check(rc, "uaps_bn_act_bwd_apply")
     return bounds.put(dy, am)
@@ -168,15 +191,18 @@ def materialize(dz: torch.Tensor, lz: Lazy) -> torch.Tensor:
 
 def reset() -> None:
     """Forget what a failed backward may have left behind (records live on their gradient tensors and die with them; only the
-    count is global)."""
-    global _outstanding
-    _outstanding = 0
+    counts remain: the calling thread's open scope and the loose one)."""
+    _loose.outstanding = 0
+    sc = current()
+    if sc is not None:
+        sc.outstanding = 0
 
 
-def assert_none_pending() -> None:
-    global _outstanding
-    if _outstanding:
-        n, _outstanding = _outstanding, 0
+def assert_none_pending(sc: Optional[Scope] = None) -> None:
+    """Raises when `sc` (default: the calling thread's open scope, else the loose count) still has records nobody took."""
+    sc = sc or current() or _loose
+    if sc.outstanding:
+        n, sc.outstanding = sc.outstanding, 0
         raise RuntimeError(f"{n} gradient(s) with a pending BatchNorm transform reached a node that does not apply it "
                            "(uaps_amd/lazybn.py); set UAPS_LAZY_BN_BWD=0")
 

@@ -15,7 +15,7 @@ from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, config
 
 MAX_HEADS, MAX_CLASSES = 8, 8
 
@@ -43,7 +43,7 @@ KERNEL_EVENTS: Optional[Dict[str, list]] = None
 
 
 # tuning knob of the pair-loss kernels (cap on the blocks per branch; 0 = one group of pixels per thread)
-PAIR_CFG = int(os.environ.get("UAPS_PAIR_CFG", "0"))
+PAIR_CFG = config.integer("UAPS_PAIR_CFG", 0)
 
 
 class _timed:
@@ -353,9 +353,7 @@ class _PairLoss(torch.autograd.Function):
         row_wrw = W % 256 == 0 and H % 16 == 0
         am = bounds.new_amax(dev) if bounds.enabled() and (row_wrw or not (Cc <= 4 and W >= 64 and W % 4 == 0)) else None
         with _lib.device_guard(dev), _timed("uaps_pair_bwd"):
-            if am is not None:
-                _lib.hints((), am)
-            rc = L.uaps_pairloss_bwd(lab_p, un_p, y.data_ptr(), pseudo.data_ptr(), sscal.data_ptr(), uscal.data_ptr(), cw1, cw2,
+            rc = L.uaps_pairloss_bwd_h(_lib.mk_hints((), am) if am is not None else None, lab_p, un_p, y.data_ptr(), pseudo.data_ptr(), sscal.data_ptr(), uscal.data_ptr(), cw1, cw2,
                                      g.data_ptr(), D, B, Cc, H, W, n_loss, dlab_p, dun_p, PAIR_CFG, st)
         _lib.check(rc, "uaps_pairloss_bwd")
         for t in dz:

@@ -88,4 +88,11 @@ class Adam(torch.optim.Adam):
             ps = [p for p in group["params"] if p.grad is not None and id(p) not in done]
             if ps:
                 self._launch(group, ps)
+            if done and ps:
+                # the early half and this half are ONE optimizer step: a parameter of each must now carry the same count (a step
+                # abandoned between its halves would leave the early parameters one ahead for good: ADVICE r5)
+                early = next((p for p in group["params"] if id(p) in done and p in self.state), None)
+                if early is not None and int(self.state[early]["step"]) != int(self.state[ps[0]]["step"]):
+                    raise RuntimeError(f"uaps_amd.optim.Adam: step counts {int(self.state[early]['step'])} (early half) and "
+                                       f"{int(self.state[ps[0]]['step'])} (final half) differ: a previous step was abandoned between its halves")
         return loss

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _lib, bounds
+from . import _lib, bounds, config, stepctx
 from . import conv as _conv
 
 
@@ -28,29 +28,63 @@ from . import conv as _conv
 DEVICE_THRESHOLDS = False
 
 
-class _RngState:
-    """(seed, running Philox counter offset).  One per process; ranks use different seeds."""
-    seed = 0x5EED_0A95
-    offset = 0
+class RngState:
+    """(seed, running Philox counter offset) of the perturbation draws."""
 
-    @classmethod
-    def reserve(cls, n_elements: int) -> Tuple[int, int]:
-        off = cls.offset
-        cls.offset += (n_elements + 3) // 4 + 1
-        return cls.seed, off
+    def __init__(self, seed: int = 0x5EED_0A95, offset: int = 0):
+        self.seed, self.offset = int(seed), int(offset)
+
+    def reserve(self, n_elements: int) -> Tuple[int, int]:
+        off = self.offset
+        self.offset += (n_elements + 3) // 4 + 1
+        return self.seed, off
+
+
+# One stream per process (ranks use different seeds), as the reference has one torch / numpy global RNG.  A thread that drives a
+# model of its own beside other threads can give itself a private stream (`local_rng`): the draws of its forwards then do not
+# depend on how the threads interleave (tests/test_gpu_threads.py).
+_RngState = RngState()
+
+
+def rng() -> RngState:
+    """The stream the calling thread's forward draws from: its private one inside `local_rng`, else the process's."""
+    return stepctx.fwd().rng or _RngState
+
+
+def _mix(seed: int, rank: int) -> int:
+    return (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
 
 
 def manual_seed(seed: int, rank: int = 0) -> None:
-    _RngState.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
-    _RngState.offset = 0
+    r = rng()
+    r.seed, r.offset = _mix(seed, rank), 0
+
+
+class local_rng:
+    """`with local_rng(seed, rank):` -- the calling thread's forwards draw their perturbations from a private stream (the one
+    manual_seed(seed, rank) would start) until the block ends."""
+
+    def __init__(self, seed: int, rank: int = 0):
+        self.state = RngState(_mix(seed, rank), 0)
+
+    def __enter__(self):
+        f = stepctx.fwd()
+        self.prev, f.rng = f.rng, self.state
+        return self.state
+
+    def __exit__(self, *a):
+        stepctx.fwd().rng = self.prev
+        return False
 
 
 def get_rng_state() -> Tuple[int, int]:
-    return _RngState.seed, _RngState.offset
+    r = rng()
+    return r.seed, r.offset
 
 
 def set_rng_state(state: Tuple[int, int]) -> None:
-    _RngState.seed, _RngState.offset = int(state[0]), int(state[1])
+    r = rng()
+    r.seed, r.offset = int(state[0]), int(state[1])
 
 
 def _prep(x: torch.Tensor, what: str) -> torch.Tensor:
@@ -151,7 +185,7 @@ class FeatureNoise(nn.Module):
     def forward(self, x: torch.Tensor, return_noise: bool = False, groups: int = 1):
         offs = []
         for _ in range(groups):
-            seed, off = _RngState.reserve(x[0].numel())
+            seed, off = rng().reserve(x[0].numel())
             offs.append(off)
         return _NoiseRng.apply(x, seed, tuple(offs), self.uniform_range, return_noise)
 
@@ -224,7 +258,7 @@ def dropout_with(x: torch.Tensor, keep: torch.Tensor, p: float = 0.5) -> torch.T
 
 def Dropout(x: torch.Tensor, p: float = 0.5, return_keep: bool = False):
     """UAPS_unet.py:156-158: F.dropout(x, p) with training=True unconditionally (also in eval())."""
-    seed, off = _RngState.reserve(x.numel())
+    seed, off = rng().reserve(x.numel())
     return _Bernoulli.apply(x, seed, off, p, return_keep)
 
 
@@ -299,8 +333,8 @@ def FeatureDropout(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
 # ---- all decoders' views of one encoder feature map, with a fused backward ---------------------------------
 
 _KIND_MODE = {"noise": 1, "dropout": 2, "feature_dropout": 3}
-_fan_side = None          # set by UNet_UAPS.forward around its encoder loop: the stream the perturbed copies are written on (None: the caller's)
-_FUSED_FANOUT = os.environ.get("UAPS_FUSED_FANOUT", "1") != "0"      # A/B switch for tools/ab_bench.sh
+# (stepctx.fwd().fan_side, set by UNet_UAPS.forward around its encoder loop: the stream the perturbed copies are written on; None: the caller's)
+_FUSED_FANOUT = config.flag("UAPS_FUSED_FANOUT", True)      # A/B switch for tools/ab_bench.sh
 
 
 class _PerturbFan(torch.autograd.Function):
@@ -312,6 +346,7 @@ class _PerturbFan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f, kinds, groups, noise_range, drop_p, with_pool=False):
         ctx.set_materialize_grads(False)
+        ctx.step = stepctx.current()       # the trainer scope this forward runs in: the backward starts its early flush (conv.early_flush)
         f = _prep(f, "perturbed feature fan-out")
         B, Cc, H, W = f.shape
         if B % groups:
@@ -319,7 +354,7 @@ class _PerturbFan(torch.autograd.Function):
         Bg, chw, dev = B // groups, Cc * H * W, f.device
         L = _lib.lib()
         outs, offsets, keeps = [f.view_as(f)], [[0] * groups], [None]
-        seed = _RngState.seed
+        seed = rng().seed
         n = len(kinds)
         # the one-pass kernel carries one set of FeatureDropout thresholds: with two FeatureDropout decoders (n_aux >= 6) the
         # per-perturbation kernels below run instead (decided before any random number is reserved)
@@ -332,9 +367,9 @@ class _PerturbFan(torch.autograd.Function):
             ws = None
             for i, kind in enumerate(kinds):
                 if kind == "noise":
-                    offsets.append([_RngState.reserve(chw)[1] for _ in range(groups)]); keeps.append(None)
+                    offsets.append([rng().reserve(chw)[1] for _ in range(groups)]); keeps.append(None)
                 elif kind == "dropout":
-                    offsets.append([_RngState.reserve(f.numel())[1]] * groups); keeps.append(None)
+                    offsets.append([rng().reserve(f.numel())[1]] * groups); keeps.append(None)
                 else:
                     need = C.c_size_t()
                     _lib.check(L.uaps_feat_dropout_workspace_bytes(B, Cc, H, W, C.byref(need)), "uaps_feat_dropout_workspace_bytes")
@@ -345,7 +380,7 @@ class _PerturbFan(torch.autograd.Function):
                     kp[i] = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
                     if DEVICE_THRESHOLDS:
                         us = [-1.0] * groups
-                        offsets.append([_RngState.reserve(4)[1] for _ in range(groups)]); keeps.append(kp[i])
+                        offsets.append([rng().reserve(4)[1] for _ in range(groups)]); keeps.append(kp[i])
                     else:
                         us = [float(np.random.uniform(0.7, 0.9)) for _ in range(groups)]
                         offsets.append([0] * groups); keeps.append(kp[i])
@@ -358,7 +393,8 @@ class _PerturbFan(torch.autograd.Function):
                     _lib.check(L.uaps_maxpool2x2_fwd(f.data_ptr(), B, Cc, H, W, pooled.data_ptr(), idx.data_ptr(), st), "uaps_maxpool2x2_fwd")
                 # the perturbed copies are read by the decoders only: with a side stream set (UNet_UAPS.forward, decoder-stream mode) they
                 # are written beside the encoder's next levels, and the caller makes the decoders wait for that stream
-                side = _fan_side if (_fan_side is not None and _fan_side.device == dev) else None
+                fs = stepctx.fwd().fan_side
+                side = fs if (fs is not None and fs.device == dev) else None
                 if side is not None:
                     side.wait_stream(torch.cuda.current_stream(dev))
                 with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -383,13 +419,13 @@ class _PerturbFan(torch.autograd.Function):
             for kind in kinds:
                 y = torch.empty_like(f)
                 if kind == "noise":
-                    offs = [_RngState.reserve(chw)[1] for _ in range(groups)]
+                    offs = [rng().reserve(chw)[1] for _ in range(groups)]
                     for g, off in enumerate(offs):
                         _lib.check(L.uaps_feat_noise(f.data_ptr() + 4 * g * Bg * chw, y.data_ptr() + 4 * g * Bg * chw, Bg, Cc, H, W, seed,
                                                      off, float(noise_range), None, st), "uaps_feat_noise")
                     offsets.append(offs); keeps.append(None)
                 elif kind == "dropout":
-                    off = _RngState.reserve(f.numel())[1]
+                    off = rng().reserve(f.numel())[1]
                     _lib.check(L.uaps_feat_bernoulli(f.data_ptr(), y.data_ptr(), f.numel(), seed, off, float(drop_p), None, st),
                                "uaps_feat_bernoulli")
                     offsets.append([off] * groups); keeps.append(None)
@@ -426,7 +462,7 @@ class _PerturbFan(torch.autograd.Function):
         live = [(g.contiguous(), modes[i], offsets[i], ctx.keeps[i]) for i, g in enumerate(grads) if g is not None]
         if not live:
             return None, None, None, None, None, None
-        _conv.early_flush()                 # (a training step's scope: the decoders' weight-gradient reductions start beside the encoder's backward)
+        _conv.early_flush(ctx.step)         # (a training step's scope: the decoders' weight-gradient reductions start beside the encoder's backward)
         if live[0][1] == 4:                 # the output buffer takes its shape from the first entry: keep a full-size one first
             live.append(live.pop(0))
         dev = live[0][0].device

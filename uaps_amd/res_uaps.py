@@ -43,9 +43,7 @@ class _AddRelu(torch.autograd.Function):
         a, b = a.contiguous(), b.contiguous()
         out = torch.empty_like(a)
         with _lib.device_guard(a.device):
-            if am is not None:
-                _lib.hints((), am)
-            rc = _lib.lib().uaps_add_relu(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
+            rc = _lib.lib().uaps_add_relu_h(_lib.mk_hints((), am) if am is not None else None, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _lib.current_stream(a.device))
         _lib.check(rc, "uaps_add_relu")
         ctx.save_for_backward(out)
         return tuple(out.view_as(out) for _ in range(n))

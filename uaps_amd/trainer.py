@@ -14,12 +14,12 @@ from typing import Callable, Dict, Optional
 import numpy as np
 import torch
 
-from . import _lib, conv, lazybn
+from . import _lib, config, conv, lazybn
 from . import dist as udist
 from . import losses, metrics, optim, perturb
 from .ramps import get_current_consistency_weight
 
-_EARLY_ADAM = os.environ.get("UAPS_EARLY_ADAM", "1") != "0"      # the decoders' Adam step beside the encoder's backward (world size 1)
+_EARLY_ADAM = config.flag("UAPS_EARLY_ADAM", True)      # the decoders' Adam step beside the encoder's backward (world size 1)
 
 
 class UAPSTrainer:
@@ -122,7 +122,13 @@ class UAPSTrainer:
             self._late_params = tuple(fn()) if callable(fn) else ()
         if not self._late_params:
             return None
-        self.optimizer._early_done.clear()       # (a step that raised between its early and its final Adam call leaves nothing behind)
+        if self.optimizer._early_done:
+            # the previous step raised between its early and its final Adam call: the decoders' parameters (and their step counts)
+            # are one update ahead of the encoder's -- nothing here can undo that, so say it instead of training on
+            self.optimizer._early_done.clear()
+            raise RuntimeError("uaps_amd: the previous training step failed after the decoders' parameters had been updated (early Adam "
+                               "step) and before the encoder's were: the model is half a step out of sync.  Reload the last checkpoint; "
+                               "UAPS_EARLY_ADAM=0 keeps the optimizer step in one piece.")
         return lambda: self.optimizer.step_early(self._late_params)
 
     def _unit_gradient(self, loss: torch.Tensor) -> torch.Tensor:
@@ -140,7 +146,9 @@ class UAPSTrainer:
         # forward + backward of a step this trainer drives itself: the two-halves BatchNorm backward may run, and the weight-gradient
         # reductions run batched -- behind the backward, or per bucket in front of its all-reduce (dist.GradBuckets._launch)
         pair = self.pair_forward and x_l.shape == x_u.shape       # (two forwards of one model: autograd sums the two gradients of a weight)
-        with lazybn.scope(), conv.deferred_reduces(pair, on_early=self._early_adam()):
+        with lazybn.scope(), conv.deferred_reduces(pair, on_early=self._early_adam(), model=self.model) as step:
+            if self.buckets is not None:
+                self.buckets.step = step          # the bucket hooks reduce their bucket's deferred weight gradients in front of the all-reduce
             if pair:
                 both = self.model.forward_pair(x_l, x_u)                              # UAPS_train.py:177 + :185 in one pass
                 if w is None:
@@ -334,7 +342,9 @@ class BaselineTrainer(UAPSTrainer):
     def train_step(self, x_l: torch.Tensor, y_l: torch.Tensor, x_u=None, w=None) -> Dict[str, torch.Tensor]:
         if not self.model.training:
             self.model.train()
-        with lazybn.scope(), conv.deferred_reduces():
+        with lazybn.scope(), conv.deferred_reduces(model=self.model) as step:
+            if self.buckets is not None:
+                self.buckets.step = step
             out = self.model(x_l)                                                 # baseline_train.py:158
             main = out[0] if isinstance(out, (tuple, list)) else out
             s = losses.uaps_sup_loss((main,), y_l)                                # :161-164, 0.5 * (dice + CE)

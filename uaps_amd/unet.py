@@ -23,27 +23,27 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import bounds, conv, fused, perturb
+from . import bounds, config, conv, fused, perturb, stepctx
 
 FEATURE_CHANNELS = (16, 32, 64, 128, 256)          # UAPS_unet.py:213
 ENCODER_DROPOUT = (0.05, 0.1, 0.2, 0.3, 0.5)       # UAPS_unet.py:214
 LEAKY_SLOPE = 0.01                                  # nn.LeakyReLU() default
-_EPILOGUE_STATS = os.environ.get("UAPS_EPILOGUE_STATS", "1") != "0"   # A/B switches for tools/ab_bench.sh
-_VIRTUAL_CAT = os.environ.get("UAPS_VIRTUAL_CAT", "1") != "0"
-_FUSED_FAN = os.environ.get("UAPS_FUSED_FAN", "1") != "0"
-_DECODER_CHAINS = max(2, int(os.environ.get("UAPS_DECODER_CHAINS", "8")))      # diagnosis: decoders are dealt round-robin onto this many streams (main included)
-_FAN_BESIDE = os.environ.get("UAPS_FAN_BESIDE", "1") != "0"        # the perturbed feature copies are written on a side stream beside the encoder's next levels
-_PACK_BESIDE = os.environ.get("UAPS_PACK_BESIDE", "1") != "0"      # the decoders' weights are packed on a side stream beside the encoder's forward
-_FUSED_POOL = os.environ.get("UAPS_FUSED_POOL", "1") != "0"
-_FUSED_BN_CONV = os.environ.get("UAPS_FUSED_BN_CONV", "1") != "0"
+_EPILOGUE_STATS = config.flag("UAPS_EPILOGUE_STATS", True)   # A/B switches for tools/ab_bench.sh
+_VIRTUAL_CAT = config.flag("UAPS_VIRTUAL_CAT", True)
+_FUSED_FAN = config.flag("UAPS_FUSED_FAN", True)
+_DECODER_CHAINS = max(2, config.integer("UAPS_DECODER_CHAINS", 8))      # diagnosis: decoders are dealt round-robin onto this many streams (main included)
+_FAN_BESIDE = config.flag("UAPS_FAN_BESIDE", True)        # the perturbed feature copies are written on a side stream beside the encoder's next levels
+_PACK_BESIDE = config.flag("UAPS_PACK_BESIDE", True)      # the decoders' weights are packed on a side stream beside the encoder's forward
+_FUSED_POOL = config.flag("UAPS_FUSED_POOL", True)
+_FUSED_BN_CONV = config.flag("UAPS_FUSED_BN_CONV", True)
 # One HIP stream per auxiliary decoder (see UNet_UAPS.forward): +5 % images/s on the bench step, opt-in because kernels of
 # different decoders then overlap and per-launch timings (bench.py's roofline, rocprof averages) stop describing one kernel.
-_DECODER_STREAMS = os.environ.get("UAPS_DECODER_STREAMS", "0") != "0"
+_DECODER_STREAMS = config.flag("UAPS_DECODER_STREAMS", False)
 _CAPTURE_KEEP = weakref.WeakKeyDictionary()     # model -> tensors that cross streams inside its captured step (UNet_UAPS.forward)
 # BatchNorm partial sums in the conv epilogues are taken about running_mean - conv bias (no variance cancellation for channels
 # with |mean| >> std).  Off: plain sums, as in round 1 -- then forward_pair and two successive forwards agree bit for bit (with
 # the shift the second forward already sees the running mean the first one updated: another rounding of the same statistics)
-_STAT_SHIFT = os.environ.get("UAPS_STAT_SHIFT", "1") != "0"
+_STAT_SHIFT = config.flag("UAPS_STAT_SHIFT", True)
 
 
 class ConvBlock(nn.Module):
@@ -316,7 +316,7 @@ class UNet_UAPS(nn.Module):
                     self._fan_stream = torch.cuda.Stream(device=x.device)
                 fan_side = self._fan_stream
             fans, f = [], enc.in_conv(x)
-            perturb._fan_side = fan_side
+            stepctx.fwd().fan_side = fan_side
             try:
                 for blk in (enc.down1, enc.down2, enc.down3, enc.down4, None):
                     # (the fan-in kernel sums at most 8 gradients: clean + n_aux perturbed + the pooled one)
@@ -326,7 +326,7 @@ class UNet_UAPS(nn.Module):
                     if blk is not None:
                         f = blk.maxpool_conv[1](fan[-1]) if pool else blk(f)
             finally:
-                perturb._fan_side = None
+                stepctx.fwd().fan_side = None
             if fan_side is not None:
                 torch.cuda.current_stream(x.device).wait_stream(fan_side)
             per_dec = [[fan[d] for fan in fans] for d in range(1 + self.n_aux)]
