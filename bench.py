@@ -323,6 +323,26 @@ class PowerLog:
         return out
 
 
+def plan_ranks(usable_cpus, world, local_rank, graph_multi_env=""):
+    """What a rank of an N-rank run on ONE host does about the host's cores (pure function: tests/test_host_cpu.py drives it with a
+    mocked 16-CPU quota and 8 ranks).  Returns (affinity, cores_per_rank, graph_multi):
+      affinity        the slice [r n, (r + 1) n) of the usable cores this rank pins itself to when n = cores / ranks >= 4 (launch thread +
+                      autograd thread + RCCL's threads), else None: with fewer the scheduler is left alone;
+      cores_per_rank  n as above (the pinned slice's size, or usable cores // ranks);
+      graph_multi     step with the two-graph form of uaps_amd/graph.py instead of eager launches: forced by UAPS_GRAPH_MULTI=1 / =0, else
+                      chosen when a rank has fewer than 2 cores (the eager step needs the host: 14.0 ms with two cores per rank, 18.3 ms
+                      with one -- DESIGN.md section 6)."""
+    cpus = sorted(usable_cpus)
+    affinity = None
+    if world > 1:
+        per = len(cpus) // world
+        if per >= 4:
+            affinity = cpus[local_rank * per:(local_rank + 1) * per]
+    cores_per_rank = len(affinity) if affinity is not None else len(cpus) // max(world, 1)
+    graph_multi = graph_multi_env == "1" or (graph_multi_env != "0" and world > 1 and cores_per_rank < 2)
+    return affinity, cores_per_rank, graph_multi
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N ...` without torch.distributed.run: start N fresh copies of this command, one rank per GPU
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as the launcher would), wait for them and return the job's exit code.
@@ -441,10 +461,8 @@ def main():
         dist.all_reduce(one)                                # the process group itself counts the ranks (not WORLD_SIZE)
         ranks_seen = int(one.item())
         if world > 1 and hasattr(os, "sched_setaffinity"):  # every rank its own slice of the usable cores: 8 launching processes + RCCL threads share the host
-            cpus = sorted(os.sched_getaffinity(0))
-            per = len(cpus) // world
-            if per >= 4:                                    # fewer than 4 cores per rank (launch + autograd + RCCL threads): leave the scheduler alone
-                affinity = cpus[local_rank * per:(local_rank + 1) * per]
+            affinity = plan_ranks(os.sched_getaffinity(0), world, local_rank)[0]
+            if affinity is not None:
                 try:
                     os.sched_setaffinity(0, affinity)
                 except OSError:
@@ -470,9 +488,11 @@ def main():
     # two-graph form has never run over RCCL with more than one rank -- 7 % is not worth the first such run being the scaling run.
     # The abort seen once behind it happened in a process that had created and destroyed other process groups with captures in
     # between; this script creates exactly one group per process, before any capture.
-    cores_per_rank = (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)) // max(world, 1) if affinity is None else len(affinity)
-    gm = os.environ.get("UAPS_GRAPH_MULTI", "")
-    graph_multi = gm == "1" or (gm != "0" and world > 1 and cores_per_rank < 2)
+    usable = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else range(os.cpu_count() or 1)
+    if affinity is not None:
+        cores_per_rank, graph_multi = len(affinity), os.environ.get("UAPS_GRAPH_MULTI", "") == "1"
+    else:
+        _, cores_per_rank, graph_multi = plan_ranks(usable, world, local_rank, os.environ.get("UAPS_GRAPH_MULTI", ""))
     use_graph = not args.no_graph and args.net == "unet_uaps" and (world == 1 or graph_multi)
     trainer = uaps_amd.UAPSTrainer(model, seed=1337, use_graph=use_graph)
     data = uaps_amd.data.SyntheticBatches(b, args.in_chns, C, H, W, n_batches=2, seed=1337 + rank, device=dev)
@@ -658,6 +678,26 @@ def main():
                             "fp32 MFMA kernels, 2500 / 3 = 833.3 for the fp16-split kernels (conv_h*: three fp16 partial products per "
                             "fp32 multiply, fp32 accumulation), 2500 / 6 = 416.7 for the bf16-split kernels (conv_s*, six partial "
                             "products; operands without a magnitude bound); DESIGN.md section 5"}
+            # What the chip has been SEEN to sustain with this arithmetic (tools/split_gemm_ceiling.hip, committed measurement): the
+            # same fp16-split contraction -- fp32 activations split in staging, pre-split weights, three products, fp32 accumulate --
+            # as a nine-tap GEMM without the convolution's geometry (no halo, no tap shifts), on large per-wave register blocks, for
+            # the M x N x K of the four layers this kernel family spends its time on; time-weighted over those layers
+            try:
+                with open(os.path.join(ROOT, "profiles", "r06_split_gemm_ceiling.json")) as f:
+                    ceil = json.load(f)
+                if peak == MFMA_BF16_PEAK_TF / 3.0 and ceil.get("layers"):
+                    gf = sum(l["gflop"] for l in ceil["layers"])
+                    tw = gf / sum(l["gflop"] / l["best_tflops_reread"] for l in ceil["layers"])
+                    roof["practical_peak"] = {"tflops": round(tw, 1), "frac": round(ach / tw, 4),
+                                              "per_layer_tflops": {l["layer"]: l["best_tflops_reread"] for l in ceil["layers"]},
+                                              "source": "profiles/r06_split_gemm_ceiling.json",
+                                              "note": "same-arithmetic tap-reuse GEMM (fp32 activations split into two fp16 pieces in staging, three "
+                                                      "products on v_mfma_f32_16x16x32_f16, fp32 accumulation) at B = 32 for 64->64 and 128->64 @64^2, "
+                                                      "128->128 and 256->128 @32^2: best form per layer with the A fragments re-read per tap (what a "
+                                                      "3x3 kernel must do), time-weighted; measured on one MI355X of this pool in round 6, not on "
+                                                      "this run's box (DESIGN.md section 3.2)"}
+            except (OSError, ValueError, KeyError, ZeroDivisionError):
+                pass
         elif ev:
             dom = max(ev, key=lambda k: kern[k]["avg_us"])
             roof = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -717,7 +757,10 @@ def main():
                               "exact": "fp32 matrix instruction (v_mfma_f32_16x16x4_f32) everywhere"}[conv.get_mode()],
                "config": {"workload": f"UAPS K={args.aux} decoders, NEU-Seg-shaped {H}x{W} {C}-class, batch {b}+{b} per GPU (BASELINE.json configs[1])",
                           "heads": D, "per_gpu_batch": f"{b} labelled + {b} unlabelled", "parallelism": f"dp{world}", "final_loss": round(last_loss, 5),
-                          "launch_mode": mode},
+                          "launch_mode": mode,
+                          # every UAPS_* switch whose value is not the package default (uaps_amd/config.py) -- {} = the shipped configuration;
+                          # UAPS_DECODER_STREAMS is set by this script itself for the headline (--single-stream turns it off)
+                          "switches": uaps_amd.config.non_default()},
                "roofline": roof, "kernels": kern}
         # clock and socket power across the timed region and the analysis pass (tools/power_sampler.py)
         power = None

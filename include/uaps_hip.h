@@ -66,6 +66,8 @@ const char* uaps_error_string(int code);
 #define UAPS_U_PS(D, C) (4 * (D))                           /* ps_loss                                     :277 */
 #define UAPS_U_LUN(D, C) (4 * (D) + 1)                      /* l_uncert                                    :243 */
 #define UAPS_U_LOSS(D, C) (4 * (D) + 2)                     /* cw1*ps_loss + cw2*l_uncert                  :282 */
+#define UAPS_U_TOTAL(D, C) (4 * (D) + 3)                    /* uaps_pairloss_fwd / _finalize_sums only (round 6): supervised_loss + the
+                                                             * slot above = the step's loss (:282), so that the host needs no add launch */
 #define UAPS_U_A1(D, C) (4 * (D) + 4)                       /* a1[D*C] = -(2/C)/(card+eps)   (for backward) */
 #define UAPS_U_A2(D, C) (4 * (D) + 4 + (D) * (C))           /* a2[D*C] = (2/C) I/(card+eps)^2               */
 #define UAPS_U_I(D, C) (4 * (D) + 4 + 2 * (D) * (C))        /* I[D*C]    sum p_kc [y=c]    pytorch_losses.py:85 */

@@ -16,20 +16,27 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _run(seed: int, steps: int, barrier=None, out=None, key=None):
+def _setup(seed: int, steps: int):
+    """Model and batches of one trainer, built on the CALLING thread: parameter initialisation draws from torch's process-wide CPU
+    generator, which two threads must not share."""
     import uaps_amd
-    from uaps_amd import conv, lazybn, perturb, stepctx
     torch.manual_seed(seed)
+    model = uaps_amd.net_factory("unet_uaps", 3, 4, n_aux=2)          # FeatureNoise + Dropout decoders (FeatureDropout's threshold is numpy's global RNG)
+    g = torch.Generator().manual_seed(1000 + seed)
+    batches = [(torch.randn(2, 3, 32, 256, generator=g).to(DEV), torch.randint(0, 4, (2, 32, 256), generator=g).to(DEV),
+                torch.randn(2, 3, 32, 256, generator=g).to(DEV)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    return model, batches
+
+
+def _run(seed: int, model, batches, barrier=None, out=None, key=None):
+    import uaps_amd
+    from uaps_amd import lazybn, perturb, stepctx
     stream = torch.cuda.Stream(device=DEV)
     res = None
     try:
         with torch.cuda.stream(stream), perturb.local_rng(seed):
-            model = uaps_amd.net_factory("unet_uaps", 3, 4, n_aux=2)          # FeatureNoise + Dropout decoders (FeatureDropout's threshold is numpy's global RNG)
             tr = uaps_amd.UAPSTrainer(model, seed=seed, track_metrics=False)
-            g = torch.Generator().manual_seed(1000 + seed)
-            batches = [(torch.randn(2, 3, 32, 256, generator=g).to(DEV), torch.randint(0, 4, (2, 32, 256), generator=g).to(DEV),
-                        torch.randn(2, 3, 32, 256, generator=g).to(DEV)) for _ in range(steps)]
-            stream.synchronize()
             if barrier is not None:
                 barrier.wait()
             n0 = lazybn.prepared_total()
@@ -54,12 +61,13 @@ def test_two_trainers_in_two_threads_equal_their_single_threaded_runs():
         pytest.skip("the two-halves BatchNorm backward and the row kernels it rides on exist in the default arithmetic")
     assert conv._DEFER
     steps = 4
-    solo = {s: _run(s, steps) for s in (3, 4)}
+    solo = {s: _run(s, *_setup(s, steps)) for s in (3, 4)}
     for s in solo.values():
         assert not isinstance(s, BaseException), s
         assert s["lazy"] > 0                         # 256-wide maps: the lazy BatchNorm backward did run
     out, bar = {}, threading.Barrier(2)
-    ts = [threading.Thread(target=_run, args=(s, steps, bar, out, s)) for s in (3, 4)]
+    fresh = {s: _setup(s, steps) for s in (3, 4)}                  # the same initial parameters and batches again
+    ts = [threading.Thread(target=_run, args=(s, *fresh[s], bar, out, s)) for s in (3, 4)]
     for t in ts:
         t.start()
     for t in ts:

@@ -230,7 +230,7 @@ def test_bench_four_ranks_at_the_metric_batch(tmp_path):
     assert all(b["allreduce_ms"] > 0 for b in comm["buckets"]) and np.isfinite(comm["exposed_ms"])
 
 
-def _graph_worker(rank, world, port, out_dir, use_graph, steps):
+def _graph_worker(rank, world, port, out_dir, use_graph, steps, defer=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -238,6 +238,7 @@ def _graph_worker(rank, world, port, out_dir, use_graph, steps):
     from uaps_amd import conv, unet
     conv.set_mode(os.environ.get("UAPS_TEST_MODE", MODE))
     unet._DECODER_STREAMS = os.environ.get("UAPS_TEST_STREAMS", "1") != "0"
+    conv._DEFER = bool(defer)                    # the batched weight-gradient reductions (conv.deferred_reduces) on / off
     model = _make_model(seed=0)
     uaps_amd.dist.broadcast_model(model)
     kw = {"use_graph": True} if use_graph else {"step_state": True}
@@ -258,7 +259,7 @@ def _graph_worker(rank, world, port, out_dir, use_graph, steps):
                 "params": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
                 "adam": {i: {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
                          for i, st in enumerate(tr.optimizer.state.values())}},
-               os.path.join(out_dir, f"rank{rank}_{int(use_graph)}.pt"))
+               os.path.join(out_dir, f"rank{rank}_{int(use_graph)}_{int(bool(defer))}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -267,22 +268,26 @@ def test_two_ranks_split_graph_equals_eager(tmp_path):
     """Data parallel with the captured step: two graphs per step (forward + loss + backward | Adam + metrics) replayed around the
     eager all-reduce of the flat buckets.  Eight steps (two eager warm-ups, the capture, five replays) leave parameters,
     BatchNorm buffers, Adam state and losses bit for bit as the eager state-mode run of the same ranks leaves them, and the
-    two ranks agree."""
+    two ranks agree -- with the batched (deferred) weight-gradient reductions, which the captured backward runs inside its graph and
+    the eager one per bucket on the exchange's side stream, and (the two-graph form once more) without them."""
     got = {}
-    for use_graph in (False, True):
+    for use_graph, defer in ((False, True), (True, True), (True, False)):
         port = _free_port()
-        mp.spawn(_graph_worker, args=(2, port, str(tmp_path), use_graph, 8), nprocs=2, join=True)
-        got[use_graph] = [torch.load(os.path.join(tmp_path, f"rank{r}_{int(use_graph)}.pt"), weights_only=False) for r in range(2)]
-    assert all(g["captured"] for g in got[True]) and not any(g["captured"] for g in got[False])
+        mp.spawn(_graph_worker, args=(2, port, str(tmp_path), use_graph, 8, defer), nprocs=2, join=True)
+        got[(use_graph, defer)] = [torch.load(os.path.join(tmp_path, f"rank{r}_{int(use_graph)}_{int(defer)}.pt"), weights_only=False) for r in range(2)]
+    assert all(g["captured"] for k in ((True, True), (True, False)) for g in got[k]) and not any(g["captured"] for g in got[(False, True)])
     for r in range(2):
-        e, g = got[False][r], got[True][r]
-        assert e["losses"] == g["losses"], (r, e["losses"], g["losses"])
-        for k, v in e["params"].items():
-            assert torch.equal(v, g["params"][k]), (r, k)
-        for i, st in e["adam"].items():
-            for k, v in st.items():
-                if torch.is_tensor(v):
-                    assert torch.equal(v, g["adam"][i][k]), (r, i, k)
+        e = got[(False, True)][r]
+        for key in ((True, True), (True, False)):
+            g = got[key][r]
+            assert e["losses"] == g["losses"], (r, key, e["losses"], g["losses"])
+            for k, v in e["params"].items():
+                assert torch.equal(v, g["params"][k]), (r, key, k)
+            for i, st in e["adam"].items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        assert torch.equal(v, g["adam"][i][k]), (r, key, i, k)
+    got = {False: got[(False, True)], True: got[(True, True)]}
     for k, v in got[True][0]["params"].items():
         if "running_" in k or "num_batches" in k:
             continue

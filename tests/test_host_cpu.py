@@ -5,6 +5,7 @@ without a GPU instead of falling back."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -253,3 +254,28 @@ def test_a_model_behind_a_foreign_gradient_reducer_is_not_deferred():
         assert step is None
     with conv.deferred_reduces(model=m) as step:
         assert step is not None
+
+
+def test_bench_rank_plan_under_a_16_cpu_quota_and_8_ranks():
+    """bench.py's choice of CPU affinity and launch mode per rank: the driver's GPU boxes give a container 16
+    CPUs; eight ranks then have two cores each -- no pinning (fewer than 4 per rank), eager launches (two cores are the floor the
+    eager step was measured with); with 8 CPUs the two-graph form is chosen by itself; UAPS_GRAPH_MULTI forces either."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cpus16 = list(range(100, 116))                                  # a cgroup's cores need not start at 0
+    for r in range(8):
+        aff, per, gm = bench.plan_ranks(cpus16, 8, r)
+        assert aff is None and per == 2 and gm is False
+    assert bench.plan_ranks(cpus16, 8, 0, "1")[2] is True and bench.plan_ranks(list(range(8)), 8, 0, "0")[2] is False
+    for r in range(8):
+        aff, per, gm = bench.plan_ranks(list(range(8)), 8, r)      # one core per rank: launch-bound eagerly -> the captured form
+        assert aff is None and per == 1 and gm is True
+    seen = []
+    for r in range(4):                                              # 16 CPUs, 4 ranks: disjoint slices of 4, pinned
+        aff, per, gm = bench.plan_ranks(cpus16, 4, r)
+        assert per == 4 and len(aff) == 4 and gm is False
+        seen += aff
+    assert sorted(seen) == cpus16
+    assert bench.plan_ranks(cpus16, 1, 0) == (None, 16, False)       # one rank: nothing to share
+    aff, per, gm = bench.plan_ranks(range(256), 8, 7)               # a whole 2 x 64-core host
+    assert aff == list(range(224, 256)) and per == 32 and gm is False

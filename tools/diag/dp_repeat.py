@@ -15,7 +15,7 @@ def run(tmp, use_graph, tag):
     mp.spawn(T._graph_worker, args=(2, port, tmp, use_graph, STEPS), nprocs=2, join=True)
     out = []
     for r in range(2):
-        src = os.path.join(tmp, f"rank{r}_{int(use_graph)}.pt")
+        src = os.path.join(tmp, f"rank{r}_{int(use_graph)}_1.pt")
         out.append(torch.load(src, weights_only=False))
         os.remove(src)
     return out

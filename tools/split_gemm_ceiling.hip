@@ -228,15 +228,14 @@ static double run(const Layer& L, const char* form, bool check, FILE* js, bool f
     // ~0.5 s of back-to-back launches first (the clock settles under the load), then 50 timed ones
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int rounds = 0; rounds < 60; ++rounds) {
-        for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, dA, dB, dC, M, N, Cin, sa, os);
-        CK(hipEventRecord(e0));
+    CK(hipEventRecord(e0));
+    for (int rounds = 0; rounds < 200; ++rounds) {
+        for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, dA, dB, dC, M, N, Cin, sa, os);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float w;
         CK(hipEventElapsedTime(&w, e0, e1));
-        (void)w;
-        if ((rounds + 1) * 200 * 30e-6 > 0.5) break;      // >= 0.5 s at >= 30 us per launch
+        if (w > 500.f) break;      // >= 0.5 s under this load
     }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
@@ -292,5 +291,18 @@ int main(int argc, char** argv) {
         if (js) fprintf(js, "], \"best_tflops\": %.1f, \"best_tflops_reread\": %.1f}", best, best_reread);
     }
     if (js) { fprintf(js, "]}\n"); fclose(js); }
+    // ---- the same kernel as a plain GEMM (R = 1): the ResNet-50 configuration's 1x1 bottleneck projections (utilities/resnet.py:
+    // 55-95) at the configs[4] per-GPU batch, 8 + 8 images of 640 x 640 -> 80 x 80 maps.  Every staged activation element now serves
+    // ONE tap: the split arithmetic of the staging is no longer amortised over nine.  Shipped conv_g1h256_kernel: 692-751 us on the
+    // first two (profiles/r05_g1_wide_ab.txt, r05_g1_ablation.txt).
+    const Layer pw[] = {{"1x1 2048 -> 512 @80^2, B = 16", 16, 80, 80, 2048, 512}, {"1x1 512 -> 2048 @80^2, B = 16", 16, 80, 80, 512, 2048},
+                        {"1x1 1024 -> 512 @80^2, B = 16", 16, 80, 80, 1024, 512}};
+    for (const Layer& L : pw) {
+        printf("%s: M = %d, N = %d, K = %d, %.1f GFLOP\n", L.name, L.B * L.H * L.W, L.Cout, L.Cin, 2.0 * L.B * L.H * L.W * L.Cout * L.Cin / 1e9);
+        run<8, 4, 2, 2, 1, true, 1>(L, "128x64 per wave, 4 waves (1 / SIMD), 256 x 128 tile", false, nullptr, true);
+        run<8, 4, 4, 1, 1, true, 1>(L, "128x64 per wave, 4 waves (1 / SIMD), 512 x 64 tile", false, nullptr, true);
+        run<4, 4, 2, 2, 1, true, 2>(L, "64x64 per wave, 4 waves, 2 wg / CU, 128 x 128 tile", false, nullptr, true);
+        run<4, 4, 4, 2, 1, true, 1>(L, "64x64 per wave, 8 waves (2 / SIMD), 256 x 128 tile", false, nullptr, true);
+    }
     return 0;
 }

@@ -278,9 +278,7 @@ def early_flush(step: Optional[stepctx.StepContext]) -> int:
     dev = step.deferred[0].dev
     if any(it.dev != dev for it in step.deferred):
         return 0
-    side = _reduce_streams.get(dev.index)
-    if side is None:
-        side = _reduce_streams[dev.index] = torch.cuda.Stream(device=dev)
+    side = reduce_stream(dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     for st in {it.stream for it in step.deferred}:   # ... and for every stream partials were launched on (the caller's wait covers only
         side.wait_stream(st)                         # the producers of ITS inputs: true for all of them in UNet_UAPS, not in general)
@@ -308,11 +306,21 @@ def _verify(items, early: bool = False) -> None:
                                    "several backward passes); set UAPS_DEFER_WRW_REDUCE=0 for this training loop")
 
 
-def flush_params(step: Optional[stepctx.StepContext], param_ids) -> int:
+def reduce_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """The side stream of `dev` that reductions taken off the backward's own stream run on (early_flush; dist.GradBuckets._launch)."""
+    side = _reduce_streams.get(dev.index)
+    if side is None:
+        side = _reduce_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return side
+
+
+def flush_params(step: Optional[stepctx.StepContext], param_ids, keep_for=None) -> int:
     """The pending reductions of the convolutions whose weight is one of `param_ids` (ids of parameters), on the current stream:
     dist.GradBuckets calls this from the gradient hook that completes a bucket, in front of the bucket's all-reduce -- the
     overlapped data-parallel exchange reads .grad inside the backward, so its reductions cannot wait for the end of the scope;
-    one launch per bucket instead of one per convolution.  The number of gradients reduced."""
+    one launch per bucket instead of one per convolution.  The number of gradients reduced.
+    keep_for: the (side) stream this call runs on when that is not the stream the partials' buffers were allocated on -- they are
+    recorded on it, so that the allocator does not hand them out again while the reduction is still queued there."""
     if step is None or not step.deferred:
         return 0
     mine, rest = [], []
@@ -327,6 +335,9 @@ def flush_params(step: Optional[stepctx.StepContext], param_ids) -> int:
         if st != cur:
             cur.wait_stream(st)
     _launch_reduces(mine, dev)
+    if keep_for is not None:
+        for it in mine:
+            it.ws.record_stream(keep_for)
     _verify(mine)
     step.deferred[:] = rest
     return len(mine)

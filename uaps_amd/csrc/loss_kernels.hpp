@@ -664,6 +664,9 @@ __device__ __forceinline__ void finalize_pair_from_tot(const double* tot_s, cons
     __syncthreads();
     finalize_scalars<false>(ts, tot_s, dice_s, D, C, N, ce_coef, dice_coef, sscal);
     finalize_scalars<true>(tu, tot_u, dice_u, D, C, N, cw1, cw2, uscal);
+    // the step's loss (UAPS_train.py:282): supervised + consistency terms, one fp32 add -- what the host used to launch an add kernel for
+    __syncthreads();
+    if (threadIdx.x == 0) uscal[UAPS_U_TOTAL(D, C)] = sscal[UAPS_S_SUP(D, C)] + uscal[UAPS_U_LOSS(D, C)];
 }
 
 __host__ __device__ constexpr int unsup_nsums(int D, int C) { return D + 2 * D * C + C + 2 * D; }

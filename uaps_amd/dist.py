@@ -13,11 +13,14 @@ Works unchanged on the gloo backend with CPU tensors (that is how tests/test_ddp
 """
 from __future__ import annotations
 
+import contextlib
 from collections import OrderedDict
 from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
+
+from . import config
 
 
 def is_dist() -> bool:
@@ -86,6 +89,9 @@ class GradBuckets:
         self._hooks = []
         self.step = None                       # the trainer's open step scope (conv.deferred_reduces), set by the trainer for each step:
                                                # the hook that completes a bucket reduces that bucket's deferred weight gradients first
+        # the per-bucket reductions + all-reduce on a side stream beside the rest of the backward (UAPS_SIDE_EXCHANGE=0: in the
+        # backward's own stream, as in round 5)
+        self.side_exchange = config.flag("UAPS_SIDE_EXCHANGE", True)
         self.defer = False
         self.muted = False                     # hooks do nothing (a caller that steps without any exchange: bench.py's no-exchange leg)
         if self.world > 1 and overlap:
@@ -117,17 +123,26 @@ class GradBuckets:
 
     def _launch(self, bi: int):
         from . import conv
-        conv.flush_params(self.step, self._ids[bi])      # inside a trainer's deferred_reduces scope: this bucket's weight gradients, one launch
         flat = self._flat[bi]
-        for k, p in enumerate(self.buckets[bi]):
-            v = self._view(bi, k)
-            if p.grad is None:
-                raise RuntimeError(f"bucket {self.names[bi]}: a parameter got no gradient this step")
-            if p.grad.data_ptr() != v.data_ptr():                    # produced outside the flat buffer: copy in, re-point
-                v.copy_(p.grad)
-                p.grad = v
-        h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._handles.append((bi, h))
+        # Round 6: a bucket whose gradients are complete while the backward still runs (the decoders' buckets: the encoder's backward
+        # follows) does its reductions and its all-reduce on a SIDE stream, beside the rest of the backward -- what the early flush
+        # does at N = 1 (conv.early_flush) -- instead of in the backward's own stream, where the 200-us batched reduction of the
+        # decoders' 52 weight gradients would sit in front of the encoder's kernels.  finish() joins the collectives as before.
+        side = None
+        if self.side_exchange and self.step is not None and self.overlap and not self.defer and flat.is_cuda:
+            side = conv.reduce_stream(flat.device)
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            conv.flush_params(self.step, self._ids[bi], keep_for=side)   # this bucket's deferred weight gradients, one launch
+            for k, p in enumerate(self.buckets[bi]):
+                v = self._view(bi, k)
+                if p.grad is None:
+                    raise RuntimeError(f"bucket {self.names[bi]}: a parameter got no gradient this step")
+                if p.grad.data_ptr() != v.data_ptr():                    # produced outside the flat buffer: copy in, re-point
+                    v.copy_(p.grad)
+                    p.grad = v
+            h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append((bi, h, side))
 
     def finish(self):
         """Call after backward(): waits for the collectives and (average=True) divides by the world size."""
@@ -141,8 +156,10 @@ class GradBuckets:
                 if left != 0:
                     raise RuntimeError(f"bucket {self.names[bi]}: {left} parameters got no gradient this step")
         inv = 1.0 / self.world
-        for bi, h in self._handles:
+        for bi, h, side in self._handles:
             h.wait()
+            if side is not None:                           # (a gloo collective completes on the host: the side stream's reductions and
+                torch.cuda.current_stream(self._flat[bi].device).wait_stream(side)      # copies in front of it are joined explicitly)
             if self.average:
                 self._flat[bi].mul_(inv)
         self.reset()

@@ -236,7 +236,9 @@ class StepGraph:
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         if not self.split:
-            with _lib.quiet_gc(), torch.cuda.graph(g):
+            # thread-local error mode on every capture (round 6): runtime calls of OTHER threads (a DataLoader's pin thread, RCCL's
+            # watchdog) do not invalidate it; quiet_gc keeps this thread's own finalisers out of it
+            with _lib.quiet_gc(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out, cm = self._body(self.static["x_l"], self.static["y_l"], self.static["x_u"])
         else:
             # thread_local: the process group's watchdog thread may query its events while this thread captures
@@ -256,7 +258,13 @@ class StepGraph:
             self.static["both"] = both
         self.graph = g
         bounds.reset_pool()                          # eager code must not be handed scalars the replays re-zero
-        self.static["out"], self.static["cm"] = out, cm
+        # what the replays update and step() hands out: the output tensors WITHOUT their autograd graph.  Keeping `out` itself kept every
+        # node of the captured backward alive -- among them the parameters' AccumulateGrad nodes, created on the capture's streams, which
+        # later eager steps on other streams then met again (PyTorch's "AccumulateGrad node's stream does not match" warning in
+        # bench.py's analysis pass); the activations it held belong to the graph's private pool either way
+        self.static["out"] = type(out)(*[(t.detach() if torch.is_tensor(t) else t) for t in out]) if isinstance(out, tuple) else out
+        self.static["cm"] = cm
+        out = self.static["out"]
         # the graph writes the packed weights through raw pointers: hold the buffers, whatever the cache does later
         self.static["packed"] = [(e[3], e[4]) for e in conv._packed.values()]
         # the capture executed nothing (and its host-side Adam counter bump belongs to no step): undo that, then run the step

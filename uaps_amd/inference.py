@@ -60,13 +60,31 @@ class CapturedMainHead:
         bounds.reset_pool()                                  # the zero fill of every max|.| scalar the kernels raise belongs to the graph
         self.graph = torch.cuda.CUDAGraph()
         from . import _lib
-        with _lib.quiet_gc(), torch.cuda.graph(self.graph), torch.no_grad():      # (no finaliser runs inside the capture)
+        # thread-local error mode: another thread's runtime calls (a DataLoader's pin thread, a watchdog) do not invalidate the capture;
+        # quiet_gc: no finaliser of THIS thread runs inside it
+        with _lib.quiet_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"), torch.no_grad():
             self.out = predict_main(model, self.x)
         bounds.reset_pool()                                  # eager code must not be handed scalars the replays re-zero
+        # the graph reads the packed weights and the BatchNorm buffers through raw addresses: hold the packed buffers (the cache may
+        # drop them), and remember what the parameters looked like -- a replay after they changed would silently use stale weights
+        from . import conv
+        self._held = [(e[3], e[4]) for e in conv._packed.values()]
+        self._stamp = self._weights_stamp()
+
+    def _weights_stamp(self):
+        from . import conv
+        return (conv._generation, tuple(p._version for p in self.model.parameters()), tuple(b._version for b in self.model.buffers()))
+
+    def stale(self) -> bool:
+        """Have the model's parameters or buffers changed since the capture (an optimizer step, a checkpoint load, an in-place edit)?"""
+        return self._weights_stamp() != self._stamp
 
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
         if images.shape != self.x.shape or images.device != self.x.device or images.dtype != self.x.dtype:
             raise ValueError(f"CapturedMainHead: captured for {tuple(self.x.shape)} {self.x.dtype} on {self.x.device}")
+        if self.stale():
+            raise RuntimeError("CapturedMainHead: the model's parameters or buffers changed since the capture (optimizer step, checkpoint "
+                               "load, in-place edit): the graph holds the OLD packed weights -- build a new CapturedMainHead")
         self.x.copy_(images, non_blocking=True)
         self.graph.replay()
         return self.out

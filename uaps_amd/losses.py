@@ -23,7 +23,7 @@ MAX_HEADS, MAX_CLASSES = 8, 8
 # ---- offsets into the `scalars` outputs (include/uaps_hip.h) ----------------------------------
 def _u_off(D, C):
     b = 4 * D + 4
-    return {"ce": 0, "dice": D, "s": 2 * D, "E": 3 * D, "ps_loss": 4 * D, "l_uncert": 4 * D + 1, "loss": 4 * D + 2,
+    return {"ce": 0, "dice": D, "s": 2 * D, "E": 3 * D, "ps_loss": 4 * D, "l_uncert": 4 * D + 1, "loss": 4 * D + 2, "total": 4 * D + 3,
             "a1": b, "a2": b + D * C, "I": b + 2 * D * C, "card": b + 3 * D * C, "cnt": b + 4 * D * C,
             "n": b + 4 * D * C + C}
 
@@ -315,10 +315,12 @@ class _PairLoss(torch.autograd.Function):
                 rc = L.uaps_pairloss_finalize_sums(sums.data_ptr(), D, Cc, n_loss, float(cw1), float(cw2), float(eps), sscal.data_ptr(),
                                                    uscal.data_ptr(), st)
                 _lib.check(rc, "uaps_pairloss_finalize_sums")
-        sup, unsup = sscal[so["sup"]].clone(), uscal[uo["loss"]].clone()
+        # the three scalars are aliases of slots the finalize kernel wrote (detach(): plain storage-sharing tensors, not autograd views) --
+        # round 5 cloned two of them and added them with an ATen launch: three dependent launches between the loss forward and its backward
+        sup, unsup, total = sscal[so["sup"]].detach(), uscal[uo["loss"]].detach(), uscal[uo["total"]].detach()
         ctx.save_for_backward(y, pseudo, sscal, uscal, *zs)
         ctx.meta = (D, B, Cc, H, W, float(cw1), float(cw2), n_loss, bool(halves))
-        outs = (sup + unsup, sup, unsup, pseudo, sscal, uscal) + ((var,) if want_var else ())
+        outs = (total, sup, unsup, pseudo, sscal, uscal) + ((var,) if want_var else ())
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 

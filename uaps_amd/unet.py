@@ -363,13 +363,13 @@ class UNet_UAPS(nn.Module):
                 side.wait_event(ready)
                 for t in per_dec[d]:
                     if capturing:
-                        keep.append(t)
-                    else:
-                        t.record_stream(side)
+                        keep.append(t.detach())      # the STORAGE is what must stay; a tensor with its grad_fn would keep the captured step's
+                    else:                            # whole autograd graph alive (and with it the parameters' AccumulateGrad nodes, created on
+                        t.record_stream(side)        # the capture's streams: PyTorch warns when a later eager step meets them on another stream)
                 with torch.cuda.stream(side):
                     outs[d] = decoders[d](per_dec[d])
                 if capturing:
-                    keep.append(outs[d])
+                    keep.append(outs[d].detach())
                 else:
                     outs[d].record_stream(main)          # consumed by the loss on the main stream
             if capturing:
