@@ -366,6 +366,8 @@ int uaps_conv_set_mode(int mode);      /* 0 / 1 / 2 as above (default 2); proces
 #define UAPS_TUNE_NO_ROW_WRW 256u     /* no full-width-row weight-gradient kernels (csrc/conv_split_wrw_row.hpp) */
 #define UAPS_TUNE_DEEP_ROWS 512u      /* diagnostic: the full-width-row kernels with two row sets in flight (round 5: measured slower) */
 #define UAPS_TUNE_G1_NARROW 1024u    /* 1x1 GEMM kernels: 128 output channels per workgroup also where 256 divide the layer's width */
+#define UAPS_TUNE_NO_G 2048u         /* no whole-layer-width tile kernels (csrc/conv_split_g.hpp, round 6): the 8 x 32-tile kernels instead */
+#define UAPS_TUNE_G_DEEP 4096u       /* diagnostic: those kernels with all nine taps' weight fragments in registers, loaded around the fetch */
 int uaps_conv_set_tuning(unsigned flags);
 unsigned uaps_conv_get_tuning(void);
 
@@ -516,6 +518,13 @@ int uaps_conv_bwd_weight_reduce_batch(const uaps_wrw_reduce_item* items, int n, 
  * bounded); anything else returns UAPS_ENOFORM with nothing launched: call uaps_up_cat_fwd and the plain entry point.  The input
  * gradient (uaps_conv_bwd_data_cat) still yields the gradient of the up-sampled tensor; uaps_up_cat_bwd folds it to [B,C2,H/2,W/2]. */
 #define UAPS_CONV_X2_UP2 (1 << 10)
+/* cfg bit UAPS_CONV_BOUNDED on uaps_conv_fwd_stats_parts and the forward entry points (round 6): the caller PROMISES that the call's
+ * hints carry a magnitude bound for every tensor operand (mode 2).  It lets the planner pick kernels that exist in the fp16-split
+ * arithmetic only and write their BatchNorm partial sums in a layout of their own (csrc/conv_split_g.hpp: one part per 4-row band on
+ * 32-wide maps): uaps_conv_fwd_stats_parts reports that layout for the same dimensions + bit, and a call that sets the bit without
+ * the bounds is UAPS_EINVAL, and so is uaps_conv_fwd_bn with the bit on such a shape (the staging-time BatchNorm form keeps the tile
+ * kernels and their layout).  Without the bit nothing changes (calls without statistics choose the kernel from the hints alone). */
+#define UAPS_CONV_BOUNDED (1 << 11)
 int uaps_conv_fwd_cat(const float* x1, int C1, const float* x2, int C2, const float* wf, const float* bias, float* y,
                       void* stats_or_null, int B, int Cout, int H, int W, int ks, int cfg, uaps_stream_t stream);
 int uaps_conv_bwd_data_cat(const float* dy, const float* wb, float* dx1, int C1, float* dx2, int C2, int B, int Cout,

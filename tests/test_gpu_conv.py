@@ -587,3 +587,62 @@ def test_batched_weight_gradient_reduction_equals_the_single_reductions():
         if db1 is not None:
             np.testing.assert_array_equal(it[2].cpu().numpy(), db1.cpu().numpy())
     assert L.uaps_conv_bwd_weight_reduce_batch(None, 0, st) == 0 and L.uaps_conv_bwd_weight_reduce_batch(None, 2, st) != 0
+
+
+@pytest.mark.parametrize("B,H", [(2, 32), (3, 8)])
+def test_whole_width_tile_form_equals_the_tile_kernels(B, H):
+    """csrc/conv_split_g.hpp (round 6): 128-output-channel 3x3 layers on 32-wide maps as one workgroup per 4-row band and 128 channels
+    (input staged once per layer, 32-channel chunks, weight fragments straight from L2, BatchNorm partials per 4-row band behind
+    UAPS_CONV_BOUNDED) against the 8 x 32-tile kernels (UAPS_TUNE_NO_G): a two-source convolution with statistics -> BatchNorm ->
+    LeakyReLU -> convolution with the normalisation in its staging -> BatchNorm, forward values and every gradient (the input
+    gradients run 128 -> 128 and 128 -> 256 with two output tensors on the new form too).  Both are fp32-accurate; they differ by
+    summation order only."""
+    import torch.nn as nn
+    from uaps_amd import _lib, bounds, conv, fused
+    if conv.get_mode() != "h16":
+        pytest.skip("the whole-width tile form exists in the fp16-split arithmetic only")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B * 10 + H)
+    W = 32
+    skip0 = torch.randn(B, 128, H, W, device=dev)
+    up0 = torch.randn(B, 128, H, W, device=dev) * 1.5
+    w1 = torch.randn(128, 256, 3, 3, device=dev) / 30
+    w2 = torch.randn(128, 128, 3, 3, device=dev) / 20
+    bn1, bn2 = nn.BatchNorm2d(128).to(dev), nn.BatchNorm2d(128).to(dev)
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+    g = torch.randn(B, 128, H, W, device=dev)
+    L = _lib.lib()
+
+    def run(no_g):
+        L.uaps_conv_set_tuning(2048 if no_g else 0)
+        conv._parts_cache.clear(); conv._variant_cache.clear()
+        try:
+            for bn in (bn1, bn2):
+                bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.num_batches_tracked.zero_()
+            bounds.refresh([bn1, bn2])
+            a = bounds.put(skip0.clone().requires_grad_(True), bounds.from_value(skip0.abs().max()))
+            b = bounds.put(up0.clone().requires_grad_(True), bounds.from_value(up0.abs().max()))
+            p1, p2 = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+            y, st = conv.conv2d_cat(a, b, p1, None, with_stats=True)
+            parts = int(st.shape[2])
+            z, zst = fused.bn_act_conv(y, st, None, bn1, 0.01, p2, None, want_stats=True)
+            out = fused.bn_act(z, None, bn2, 0.01, 0.0, True, stats=zst)
+            (out * g).sum().backward()
+            torch.cuda.synchronize()
+            return parts, [t.detach().clone() for t in (y, z, out, a.grad, b.grad, p1.grad, p2.grad, bn1.weight.grad, bn1.bias.grad,
+                                                          bn1.running_mean, bn1.running_var, bn2.running_var)]
+        finally:
+            L.uaps_conv_set_tuning(0)
+            conv._parts_cache.clear(); conv._variant_cache.clear()
+            for bn in (bn1, bn2):
+                bn.weight.grad = bn.bias.grad = None
+
+    parts_g, new = run(False)
+    parts_t, old = run(True)
+    assert parts_g == H // 4 and parts_t == (H + 7) // 8            # one part per 4-row band against one per 8 x 32 tile
+    names = "y z out dskip dup dw1 dw2 dgamma dbeta rmean rvar rvar2".split()
+    for n, u, v in zip(names, new, old):
+        scale = float(v.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 3e-5 * scale, (n, float((u - v).abs().max()) / scale)

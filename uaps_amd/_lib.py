@@ -182,7 +182,7 @@ def lib() -> C.CDLL:
 _TUNE_ENV = (("UAPS_DIAG_NO_SPLIT_FWD", 1, None), ("UAPS_DIAG_NO_SPLIT_WRW", 2, None), ("UAPS_DIAG_NO_SMALL", 4, None),
              ("UAPS_DIAG_NO_HP16", 8, None), ("UAPS_SWRW_COLMAJOR", 16, "0"), ("UAPS_WRW_TALL", 32, "0"), ("UAPS_FWD_TALL", 64, "0"),
              ("UAPS_DIAG_NO_ROW16", 128, None), ("UAPS_DIAG_NO_ROW_WRW", 256, None), ("UAPS_DIAG_DEEP_ROWS", 512, None),
-             ("UAPS_DIAG_G1_NARROW", 1024, None))
+             ("UAPS_DIAG_G1_NARROW", 1024, None), ("UAPS_DIAG_NO_G", 2048, None), ("UAPS_DIAG_G_DEEP", 4096, None))
 
 
 def _configure_from_environment(l) -> None:

@@ -95,6 +95,13 @@ class _timed:
                 if (kind == "bwd_data" and ks == 3 and kin == 16 and Cin == 32 and W % 256 == 0 and H % 16 == 0 and self.name.startswith("conv_s32")
                         and not (_lib.lib().uaps_conv_get_tuning() & (128 | 8))):
                     self.name = "conv_hr16wx2_kernel" if W > 256 else "conv_hr16x2_kernel"       # 16 -> 16 + 16 channels: two output tiles of the full-width-row kernel
+                kout = Cin if kind == "bwd_data" else Cout
+                if (kind in ("fwd", "fwd_bn", "bwd_data") and ks == 3 and W == 32 and H % 4 == 0 and kin % 32 == 0 and kout % 128 == 0
+                        and not (cfg & 0x7fffffff & ~BOUNDED) and (not stats or (cfg & BOUNDED))
+                        and (self.name.startswith("conv_s32") or self.name.startswith("conv_sfwd"))
+                        and not (_lib.lib().uaps_conv_get_tuning() & 2048)):
+                    # 128-output-channel layers on 32-wide maps: the whole-layer-width tile form (csrc/conv_split_g.hpp; csrc/conv_fwd.hip: g128)
+                    self.name = "conv_hg128_bn_kernel" if "_bn_" in self.name else "conv_hg128_kernel"
                 self.name = (self.name.replace("conv_s32", "conv_h32").replace("conv_sfwd", "conv_hfwd").replace("conv_swrw", "conv_hwrw")
                              .replace("conv_g1s", "conv_g1h").replace("conv_gw1s", "conv_gw1h"))
                 if self.name == "conv_g1h_kernel<128>" and (Cin if kind == "bwd_data" else Cout) % 256 == 0 and not (_lib.lib().uaps_conv_get_tuning() & 1024):
@@ -548,6 +555,14 @@ def _h16(*bs) -> bool:
 
 
 _EXACT = 1 << 28          # cfg bit 28: the exact fp32 kernels (include/uaps_hip.h)
+BOUNDED = 1 << 11         # UAPS_CONV_BOUNDED: every tensor operand of this forward call carries a bound (the planner may then pick a kernel
+                          # of the fp16-split arithmetic whose BatchNorm-partials layout differs: csrc/conv_split_g.hpp)
+
+
+def stats_cfg(cfg: int, *bs) -> int:
+    """cfg of a forward call WITH BatchNorm partial sums: + UAPS_CONV_BOUNDED when all operand bounds `bs` are present in mode 'h16'.
+    The same value goes to stats_parts_per_image and to the launch (they must agree on the partial-sum layout)."""
+    return cfg | BOUNDED if _h16(*bs) else cfg
 
 
 def plan_cfg(ks: int, cfg: int, plain: bool, *tensors) -> int:
@@ -613,6 +628,7 @@ def conv_fwd_raw(x: torch.Tensor, wf: torch.Tensor, bias: Optional[torch.Tensor]
     bp = bias.data_ptr() if bias is not None else None
     cfg = plan_cfg(ks, cfg, True, x, y)
     if want_stats:
+        cfg = stats_cfg(cfg, xb)
         ppi = stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg)
         stats = torch.empty((Cout, B, ppi, 2), dtype=torch.float32, device=x.device)
     am = _claim_amax(x.device)
@@ -823,12 +839,13 @@ class _Conv2dCat(torch.autograd.Function):
         cfg = plan_cfg(ks, 0, False)
         y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
         stats = None
-        if want_stats:
-            stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg), 2), dtype=torch.float32, device=dev)
         b1, b2 = bounds.get(x1), bounds.get(x2)
         ctx.xb = (b1, b2)
-        ucfg = cfg | (X2_UP2 if up2 else 0)
-        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, cfg, _h16(b1, b2), name="conv_hr16_up_kernel" if up2 else None):
+        fcfg = stats_cfg(cfg, b1, b2) if want_stats else cfg       # (the forward launch and its statistics layout only: ctx.meta keeps cfg)
+        if want_stats:
+            stats = torch.empty((Cout, B, stats_parts_per_image(B, Cin, Cout, H, W, ks, fcfg), 2), dtype=torch.float32, device=dev)
+        ucfg = fcfg | (X2_UP2 if up2 else 0)
+        with _lib.device_guard(dev), _timed("fwd", B, Cin, Cout, H, W, ks, fcfg, _h16(b1, b2), want_stats, name="conv_hr16_up_kernel" if up2 else None):
             hh = None
             if (b1 is not None and b2 is not None) or (want_stats and stat_shift is not None):
                 hh = _lib.mk_hints((b1, b2) if (b1 is not None and b2 is not None) else (), None, stat_shift if want_stats else None)

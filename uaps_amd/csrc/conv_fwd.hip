@@ -9,6 +9,7 @@
 #include "conv_split_row16.hpp"
 #include "conv_small.hpp"
 #include "conv_gemm1x1.hpp"
+#include "conv_split_g.hpp"
 #include "hints.hpp"
 using namespace uaps;
 
@@ -244,12 +245,15 @@ int launch_s32t(ConvFwdArgs a, hipStream_t s) {
 // small: 1 = the exact-N VALU kernel for <= 4 output channels (conv_small.hpp)
 // g1: the GEMM-tiled 1x1 kernels of conv_gemm1x1.hpp (128 consecutive pixels x 128 / 64 output channels per workgroup)
 // s32t: 16-row tiles for the 32-channel blocks (the statistics parts stay per 8 rows)
-struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; bool g1, s32t; };
+struct FwdPlan { int ck, bn, th, tw; bool vec; int CinP, CoutP, extra_lds, dil; bool split, s32; int sck, sbn; int small; bool g1, s32t;
+                 bool bounded, g128; };
 
 int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int W, int ks, int cfg, FwdPlan* p) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return UAPS_EINVAL;
     if (ks != 1 && ks != 3) return UAPS_ERANGE;
     if ((double)Cin * H * W * 4.0 >= 2147483648.0 || (double)Cout * H * W * 4.0 >= 2147483648.0) return UAPS_ERANGE;
+    p->bounded = (cfg & UAPS_CONV_BOUNDED) != 0;      // the caller's promise of operand bounds (include/uaps_hip.h); not a planner setting
+    cfg &= ~UAPS_CONV_BOUNDED;
     p->CinP = kdim_pad(Cin, ks); p->CoutP = ndim_pad(Cout);
     p->ck = (ks == 3 && Cin <= 4 && ((cfg >> 24) & 0xf) <= 1) ? 4 : 8;
     // 16-byte loads/stores need rows that start 16-byte aligned
@@ -311,7 +315,32 @@ int plan_fwd(const void* x, const void* y, int B, int Cin, int Cout, int H, int 
         if ((bn_req != 16 && bn_req != 32) || p->CoutP % bn_req) return UAPS_EINVAL;
         p->sbn = bn_req;
     }
+    // round 6 (csrc/conv_split_g.hpp): 128-output-channel layers on 32-wide maps as ONE workgroup per 4-row band and 128 channels --
+    // every input element staged once per layer, 32-channel chunks, weight fragments straight from L2; fp16-split arithmetic only
+    // (exactly 128 output channels: with 256 -- the input gradient of up1's first convolution -- the form needs two rounds of one
+    // workgroup per CU and stages the input twice: 100 us against 63.5 us of conv_h32_kernel<64>, profiles/r06_hg128_ab.txt)
+    p->g128 = p->split && conv_mode() == 2 && ks == 3 && p->dil == 1 && W == 32 && H % 4 == 0 && Cin % 32 == 0 && Cout == 128 && p->vec &&
+              !(cfg & 0x7fffffff) && !(g_conv_tuning & UAPS_TUNE_NO_G);
     return UAPS_OK;
+}
+
+int launch_hg128(ConvFwdArgs a, hipStream_t s) {
+    a.tiles_x = 1;
+    a.tiles_y = a.H / 4;
+    a.nblk = a.Cout / 128;
+    const long grid = ((long)a.B * a.tiles_y * a.nblk + 7) / 8 * 8;
+    if (grid <= 0 || grid > 0x7fffffffL) return UAPS_EINVAL;
+    static bool attr = false;
+    if (!attr) {                                      // (idempotent; > 48 KB of dynamic LDS needs the attribute once per kernel)
+        (void)hipFuncSetAttribute((const void*)conv_hg128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHg128Lds);
+        (void)hipFuncSetAttribute((const void*)conv_hg128_bn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHg128Lds);
+        (void)hipFuncSetAttribute((const void*)conv_hg128_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHg128Lds);
+        attr = true;
+    }
+    if (a.xf) UAPS_LAUNCH_MAIN(conv_hg128_bn_kernel, dim3((unsigned)grid), dim3(kHg128Threads), kHg128Lds, s, a);
+    else if (g_conv_tuning & UAPS_TUNE_G_DEEP) UAPS_LAUNCH_MAIN(conv_hg128_deep_kernel, dim3((unsigned)grid), dim3(kHg128Threads), kHg128Lds, s, a);
+    else UAPS_LAUNCH_MAIN(conv_hg128_kernel, dim3((unsigned)grid), dim3(kHg128Threads), kHg128Lds, s, a);
+    return (int)hipGetLastError();
 }
 
 template <int BN>
@@ -413,6 +442,15 @@ int conv_fwd_any(const uaps_call_hints& hints, const float* x, const float* wp, 
             if (x2 && Csplit < Cin) { a.in2_bound = hints.bound[1]; a.in2_mul = hints.mul[1]; }
             a.err = uaps::error_word();
         }
+        // the whole-layer-width tile form (conv_split_g.hpp): with statistics only when the caller promised the bounds up front
+        // (UAPS_CONV_BOUNDED: the partial-sum layout of this form is what uaps_conv_fwd_stats_parts reported for the same bit)
+        // (not with the staging-time BatchNorm: its transform sits exposed in a one-wave-per-SIMD kernel -- 46.7 against 41.1 us of
+        // conv_hfwd_bn_kernel -- so such calls keep the tile kernels AND their partial-sum layout: see uaps_conv_fwd_stats_parts)
+        if (p.g128 && xf && stats && p.bounded) return UAPS_EINVAL;      // (the bit changes the statistics layout; this form has none)
+        if (p.g128 && !xf && stats && p.bounded && !a.wscale) return UAPS_EINVAL;
+        if (p.g128 && !xf && a.wscale && (!stats || p.bounded) && (Csplit == Cin || Csplit % 32 == 0) && (Osplit == Cout || Osplit % 128 == 0) &&
+            !hints.out_amax && !bsum && !up2)
+            return launch_hg128(a, s);
         if (p.g1) {
             // no two-tensor / BatchNorm-in-staging form of the GEMM-tiled kernels: the 3x3-style tiling (never with statistics, see above)
             if (!x2 && !y2 && !xf) {
@@ -569,6 +607,7 @@ extern "C" int uaps_conv_fwd_stats_parts(int B, int Cin, int Cout, int H, int W,
     if (rc) return rc;
     if (!parts_per_image) return UAPS_EINVAL;
     *parts_per_image = p.g1 ? (H * W + 127) / 128 : ((H + p.th - 1) / p.th) * ((W + p.tw - 1) / p.tw);
+    if (p.g128 && p.bounded) *parts_per_image = H / 4;      // conv_split_g.hpp: one part per 4-row band
     return UAPS_OK;
 }
 

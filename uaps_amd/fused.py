@@ -269,9 +269,10 @@ class _BnActConv(torch.autograd.Function):
         wf, wb = _conv.pack_weights(weight, need_bwd=True)
         z = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
         cfg = _conv.plan_cfg(ks, 0, False)          # a 1x1 here: never the GEMM-tiled plan (conv.plan_cfg)
+        fcfg = cfg      # (no UAPS_CONV_BOUNDED here: the staging-time BatchNorm form keeps the tile kernels and their partial-sum layout)
         zstats = None
         if want_stats:
-            zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks, cfg), 2), dtype=torch.float32, device=dev)
+            zstats = torch.empty((Cout, B, _conv.stats_parts_per_image(B, Cin, Cout, H, W, ks, fcfg), 2), dtype=torch.float32, device=dev)
         with _lib.device_guard(dev):
             st = _lib.current_stream(dev)
             rc = L.uaps_bn_finalize_train_h(_lib.mk_hints((), None, (running_mean, conv_bias)) if getattr(stats_partials, "_uaps_shifted", False) else None,
@@ -284,20 +285,20 @@ class _BnActConv(torch.autograd.Function):
             _lib.check(rc, "uaps_bn_finalize_train")
             am = _conv._claim_amax(dev)               # conv.request_out_amax(): track max|z| (the 1x1 projection in front of an up-sampling)
             for attempt in range(2):
-                with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, cfg, _conv._h16(xb)) as tm:
+                with _conv._timed("fwd_bn", B, Cin, Cout, H, W, ks, fcfg, _conv._h16(xb), want_stats) as tm:
                     hh = None
                     if xb is not None or (want_stats and stat_shift is not None) or am is not None:
                         hh = _lib.mk_hints((xb,) if xb is not None else (), am, stat_shift if want_stats else None)
                     rc = L.uaps_conv_fwd_bn_h(hh, y.data_ptr(), xf.data_ptr(), float(slope), groups, wf.data_ptr(),
                                             bias.data_ptr() if bias is not None else None, z.data_ptr(),
-                                            zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, cfg, st)
+                                            zstats.data_ptr() if want_stats else None, B, Cin, Cout, H, W, ks, fcfg, st)
                     if rc == _conv.ENOFORM:
                         tm.on = False
                 if rc != _conv.ENOFORM or am is None:
                     break
                 am = None                             # this layer's kernel cannot track it: run without (the caller falls back)
             _lib.check(rc, "uaps_conv_fwd_bn")
-            _conv._last_out_amax = am
+            _conv._set_out_amax(am)
         ctx.save_for_backward(y, gamma, beta, stats, xf, wb)
         ctx.meta = (float(slope), groups, conv_bias is not None, bias is not None, Cout, ks, cfg)
         ctx.keys = (id(gamma), id(beta), id(conv_bias) if conv_bias is not None else None, id(weight), id(bias) if bias is not None else None)
