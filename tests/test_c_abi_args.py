@@ -137,7 +137,7 @@ def test_process_wide_switches_and_the_round3_plans(L):
     import re, os
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "uaps_hip.h")).read()
     tune = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(UAPS_TUNE_\w+)\s+\(?(\d+)u?\)?", hdr)}
-    assert tune["UAPS_TUNE_NO_SPLIT_FWD"] == 1 and tune["UAPS_TUNE_NO_SPLIT_WRW"] == 2 and tune["UAPS_TUNE_DEEP_ROWS"] == 512 and tune["UAPS_TUNE_G1_NARROW"] == 1024 and len(tune) == 11
+    assert tune["UAPS_TUNE_NO_SPLIT_FWD"] == 1 and tune["UAPS_TUNE_NO_SPLIT_WRW"] == 2 and tune["UAPS_TUNE_DEEP_ROWS"] == 512 and tune["UAPS_TUNE_G1_NARROW"] == 1024 and tune["UAPS_TUNE_NO_G"] == 2048 and tune["UAPS_TUNE_G_DEEP"] == 4096 and len(tune) == 13
     L.uaps_conv_get_tuning.restype = C.c_uint
     buf, parts, n = C.create_string_buffer(96), C.c_int(), C.c_size_t()
     prev_mode, prev_tune = L.uaps_conv_get_mode(), L.uaps_conv_get_tuning()

@@ -50,7 +50,9 @@ __device__ __forceinline__ void conv_hg_body(const ConvFwdArgs& a) {
     const uint32_t HW4 = (uint32_t)HW * 4u;
 
     const f32x2 sc = h16_scale(__builtin_fmaxf(bound_of(a.in_bound, a.in_mul), bound_of(a.in2_bound, a.in2_mul)));
-    const float in_scale = sc.x, out_scale_a = sc.y, out_scale_w = a.wscale[1];
+    // ONE output scale (the product of two powers of two whose exponents h16_scale clamps so that it stays normal): two separate packed
+    // multiplies made hipcc pair the scalars and select the second by op_sel on the low half (tools/isa_lint.py keeps that form out)
+    const float in_scale = sc.x, out_scale = sc.y * a.wscale[1];
 
     // the image edge: one zero unit either side of every row of every plane, written once (staging never touches them)
     for (int e = tid; e < 2 * 2 * 4 * IH * 2; e += NTHR) {
@@ -270,7 +272,7 @@ __device__ __forceinline__ void conv_hg_body(const ConvFwdArgs& a) {
             const int g = wm * MT + i;
             const int gy = y0 + g / MPR, gx = (g % MPR) * 16 + (lane >> 4) * 4;
             f32x4 v = acc[i][j];
-            v *= out_scale_a; v *= out_scale_w;       // exact: powers of two
+            v *= out_scale;                           // exact: a power of two
             v += bv;
             note_nonfinite(chk, v);
             *reinterpret_cast<f32x4*>(out_c + (size_t)gy * a.W + gx) = v;
