@@ -92,14 +92,19 @@ def enabled() -> bool:
 
 # ---- BatchNorm parameter bounds, refreshed once per optimizer step -------------------------------------------------------------
 
+def _param_stamp(bn) -> tuple:
+    from . import conv
+    return (conv.stamp(bn.weight), bn.weight._version, bn.bias._version)
+
+
 def refresh(bns: List[torch.nn.BatchNorm2d]) -> None:
     """max_c(|gamma_c| + |beta_c|) of every layer in `bns` by one launch; each layer keeps a view of its scalar."""
     from . import conv
     if not bns or not enabled():
         return
-    gen = conv._generation
-    if getattr(bns[0], "_uaps_G_gen", None) == gen and getattr(bns[0], "_uaps_G", None) is not None \
-            and bns[0]._uaps_G.device == bns[0].weight.device:
+    # current = every layer's scalar was computed for its parameters as they are: the owning optimizer's step counter (conv.stamp:
+    # this package's Adam writes through raw pointers) and the tensors' version counters (load_state_dict, in-place edits)
+    if all(getattr(m, "_uaps_G_gen", None) == _param_stamp(m) for m in bns) and bns[0]._uaps_G.device == bns[0].weight.device:
         return
     dev = bns[0].weight.device
     n = len(bns)
@@ -110,13 +115,13 @@ def refresh(bns: List[torch.nn.BatchNorm2d]) -> None:
                                              (C.c_int * n)(*[m.num_features for m in bns]), n, out.data_ptr(), _lib.current_stream(dev))
     _lib.check(rc, "uaps_bn_param_bounds")
     for i, m in enumerate(bns):
-        m._uaps_G, m._uaps_G_gen = out[i * FLOATS:(i + 1) * FLOATS], gen
+        m._uaps_G, m._uaps_G_gen = out[i * FLOATS:(i + 1) * FLOATS], _param_stamp(m)
 
 
 def bn_output_bound(bn: torch.nn.BatchNorm2d, n_per_channel: int, factor: float = 1.0) -> Optional[Bound]:
     """Bound of leaky_relu(batch_norm_train(.)) (x factor) of this layer, if its scalar is current."""
     from . import conv
     g = getattr(bn, "_uaps_G", None)
-    if g is None or getattr(bn, "_uaps_G_gen", None) != conv._generation:
+    if g is None or getattr(bn, "_uaps_G_gen", None) != _param_stamp(bn):
         return None
     return (g, math.sqrt(max(1, n_per_channel)) * float(factor))

@@ -22,20 +22,47 @@ from . import _graddest, lazybn, _lib, bounds, config, stepctx
 _ws: Dict[Tuple[int, int], torch.Tensor] = {}
 # packed weights per parameter: id(weight) -> (weakref, version, generation, wf, wb)
 _packed: Dict[int, tuple] = {}
-# Bumped after every torch.optim optimizer step (global post-step hook): fused / foreach optimizers
-# update parameters without touching Tensor._version, so the version counter alone is not enough.
-_generation = 0
+# Fused / foreach optimizers (and this package's Adam kernel) update parameters without touching Tensor._version, so the version
+# counter alone does not say when a packed copy or a BatchNorm parameter bound is stale.  What does: a counter of the OPTIMIZER that
+# owns the parameter, bumped after each of its steps (global post-step hook) -- per optimizer, not per process (round 6): with one
+# process-wide counter another trainer's step, from another thread, invalidated this model's bounds in the MIDDLE of its forward
+# (bounds.bn_output_bound then returned None and that convolution silently ran the three-piece bf16 form: still fp32-accurate, but
+# not the bits of the single-threaded run -- seen once as a failure of tests/test_gpu_threads.py inside the full suite).
+_generation = 0            # bumped by invalidate_packed_weights(): manual invalidation of everything
+_shared_cell = [0]         # the counter of parameters that more than one optimizer owns: every optimizer's step bumps it
+
+
+def optimizer_stepped(optimizer, *_args, **_kwargs) -> None:
+    """Post-step hook of every torch.optim optimizer (also called by graph.StepGraph behind a replayed step): the optimizer's
+    parameters have changed.  Each parameter learns its optimizer's counter cell once."""
+    cell = getattr(optimizer, "_uaps_cell", None)
+    if cell is None:
+        cell = optimizer._uaps_cell = [0]
+    cell[0] += 1
+    _shared_cell[0] += 1
+    n = sum(len(g["params"]) for g in optimizer.param_groups)
+    if getattr(optimizer, "_uaps_cell_n", -1) != n:          # first step, or add_param_group since
+        for g in optimizer.param_groups:
+            for p in g["params"]:
+                other = getattr(p, "_uaps_cell", None)
+                p._uaps_cell = cell if (other is None or other is cell) else _shared_cell
+        optimizer._uaps_cell_n = n
+
+
+def stamp(t: torch.Tensor) -> tuple:
+    """What a cached derivative of parameter `t` (packed weights, a BatchNorm bound) is valid for."""
+    c = getattr(t, "_uaps_cell", None)
+    return (_generation, c[0] if c is not None else -1)
 
 
 def invalidate_packed_weights(*_args, **_kwargs) -> None:
-    """Forget every packed weight buffer.  Runs automatically after each `optimizer.step()` of any
-    torch.optim optimizer; call it yourself after writing to parameters through `.data` or other
-    paths that bypass both the optimizer and the tensor version counter."""
+    """Forget every packed weight buffer and BatchNorm parameter bound.  Call it after writing to parameters through `.data` or other
+    paths that bypass both the optimizers and the tensor version counter (optimizer steps are seen by themselves)."""
     global _generation
     _generation += 1
 
 
-register_optimizer_step_post_hook(invalidate_packed_weights)
+register_optimizer_step_post_hook(optimizer_stepped)
 
 
 # bench.py sets KERNEL_EVENTS to a dict {kernel instantiation name: [(start_event, end_event, flops), ...]}
@@ -438,7 +465,7 @@ def _remember(weight: torch.Tensor, wf, wb) -> None:
         ent = _packed.get(key)
         if ent is not None and ent[0] is r:          # not an entry of a newer tensor that got the same id
             del _packed[key]
-    _packed[key] = (weakref.ref(weight, _gone), weight._version, _generation, wf, wb)
+    _packed[key] = (weakref.ref(weight, _gone), weight._version, stamp(weight), wf, wb)
 
 
 def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
@@ -448,7 +475,7 @@ def pack_weights(weight: torch.Tensor, need_bwd: bool = True):
     ent = _packed.get(key)
     if ent is not None:
         ref, ver, gen, wf, wb = ent
-        if (ref() is weight and ver == weight._version and gen == _generation and wf.device == weight.device
+        if (ref() is weight and ver == weight._version and gen == stamp(weight) and wf.device == weight.device
                 and (wb is not None or not need_bwd)):
             return wf, wb
     Cout, Cin, ks, ks2 = weight.shape
@@ -514,7 +541,7 @@ def pack_all(weights, dry: bool = False) -> int:
     todo = []
     for wt in weights:
         ent = _packed.get(id(wt))
-        if ent is not None and ent[0]() is wt and ent[1] == wt._version and ent[2] == _generation and ent[3].device == wt.device \
+        if ent is not None and ent[0]() is wt and ent[1] == wt._version and ent[2] == stamp(wt) and ent[3].device == wt.device \
                 and ent[4] is not None:
             continue
         todo.append(wt)
@@ -961,7 +988,7 @@ _spacked: Dict[int, tuple] = {}
 def _pack_strided(weight: torch.Tensor):
     key = id(weight)
     ent = _spacked.get(key)
-    if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2] == _generation and ent[3].device == weight.device:
+    if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2] == stamp(weight) and ent[3].device == weight.device:
         return ent[3], ent[4]
     Cout, Cin, ks, ks2 = weight.shape
     nf, nb = C.c_size_t(), C.c_size_t()
@@ -974,7 +1001,7 @@ def _pack_strided(weight: torch.Tensor):
     with _lib.device_guard(dev):
         rc = L.uaps_convs_pack_weights(w.data_ptr(), Cout, Cin, ks, wf.data_ptr(), wb.data_ptr(), _lib.current_stream(dev))
     _lib.check(rc, "uaps_convs_pack_weights")
-    _spacked[key] = (weakref.ref(weight), weight._version, _generation, wf, wb)
+    _spacked[key] = (weakref.ref(weight), weight._version, stamp(weight), wf, wb)
     return wf, wb
 
 

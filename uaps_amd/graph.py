@@ -160,7 +160,7 @@ class StepGraph:
         opt = self.tr.optimizer
         steps = [opt.state[p]["step"] for g in opt.param_groups for p in g["params"] if p in opt.state]
         torch._foreach_add_(steps, 1)
-        conv.invalidate_packed_weights()
+        conv.optimizer_stepped(opt)
 
     def step(self, x_l, y_l, x_u) -> Dict[str, torch.Tensor]:
         tr = self.tr

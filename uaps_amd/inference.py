@@ -73,7 +73,8 @@ class CapturedMainHead:
 
     def _weights_stamp(self):
         from . import conv
-        return (conv._generation, tuple(p._version for p in self.model.parameters()), tuple(b._version for b in self.model.buffers()))
+        return (tuple(conv.stamp(p) for p in self.model.parameters()), tuple(p._version for p in self.model.parameters()),
+                tuple(b._version for b in self.model.buffers()))
 
     def stale(self) -> bool:
         """Have the model's parameters or buffers changed since the capture (an optimizer step, a checkpoint load, an in-place edit)?"""
