@@ -279,3 +279,30 @@ def test_bench_rank_plan_under_a_16_cpu_quota_and_8_ranks():
     assert bench.plan_ranks(cpus16, 1, 0) == (None, 16, False)       # one rank: nothing to share
     aff, per, gm = bench.plan_ranks(range(256), 8, 7)               # a whole 2 x 64-core host
     assert aff == list(range(224, 256)) and per == 32 and gm is False
+
+
+def test_staleness_stamps_belong_to_the_owning_optimizer():
+    """conv.stamp(parameter): what a packed copy / BatchNorm bound is valid for.  One optimizer's step must not invalidate another
+    model's cached derivatives (round 6: a process-wide counter did, from another thread, in the middle of a forward), a manual
+    invalidate_packed_weights() invalidates everything, and a parameter two optimizers share follows both."""
+    import torch.nn as nn
+    from uaps_amd import conv
+    a, b = nn.Conv2d(3, 4, 3), nn.Conv2d(3, 4, 3)
+    oa, ob = torch.optim.SGD(a.parameters(), lr=0.1), torch.optim.Adam(b.parameters(), lr=0.1)
+    for m in (a, b):
+        m(torch.randn(1, 3, 8, 8)).sum().backward()
+    sa0, sb0 = conv.stamp(a.weight), conv.stamp(b.weight)
+    oa.step()
+    assert conv.stamp(a.weight) != sa0 and conv.stamp(a.bias) == conv.stamp(a.weight)
+    assert conv.stamp(b.weight) == sb0                                   # b's caches stay valid while a trains
+    sa1 = conv.stamp(a.weight)
+    ob.step(); ob.step()
+    assert conv.stamp(a.weight) == sa1 and conv.stamp(b.weight) != sb0
+    conv.invalidate_packed_weights()
+    assert conv.stamp(a.weight) != sa1                                   # the manual switch reaches everybody
+    shared = torch.optim.SGD([a.weight], lr=0.1)                         # a second owner of a.weight
+    s2 = conv.stamp(a.weight)
+    shared.step()
+    s3 = conv.stamp(a.weight)
+    oa.step()
+    assert s3 != s2 and conv.stamp(a.weight) != s3                       # both owners' steps are seen

@@ -7,6 +7,7 @@
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r06
 cd $R
+python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/r06/gpu_tests_tail.txt; cat gpurun_out/r06/gpu_tests_tail.txt
 timeout 600 tools/bin/split_gemm_ceiling gpurun_out/r06/split_gemm_ceiling.json > gpurun_out/r06/split_gemm_ceiling.txt 2>&1
 cp gpurun_out/r06/split_gemm_ceiling.json profiles/r06_split_gemm_ceiling.json      # the box's copy: the bench line below reads it
 bash tools/gpu_pmc.sh > gpurun_out/r06/pmc.log 2>&1
