@@ -326,7 +326,17 @@ __global__ __launch_bounds__(kThreads) void maxpool2x2_fwd_kernel(const float* _
 //   mode 2 Dropout: keep from Philox(seed, off[0] + element/4), g * keep / (1-p) | 3 FeatureDropout: g * keep[b,h,w]
 //   mode 4 MaxPool2d(2) of the next encoder level: g is [B,C,H/2,W/2], routed to the arg-max position kept in `keep`
 // Summation order = input order, the same association the separate kernels + uaps_sum_tensors produced.
+// e = q * d + r for the flat element index of the fan kernels: a shift when d is a power of two (`sh` = log2 d, every level of the
+// 256 x 256 / 512 x 512 configurations), one 32-bit division when both fit (the 640 x 640 ResNet maps), the 64-bit division otherwise.
+// The 64-bit form alone cost the fan kernels a fifth of their time: they are VALU-co-limited by the two Philox calls per element.
+__device__ __forceinline__ void fan_divmod(long e, long d, int sh, long& q, long& r) {
+    if (sh >= 0) { q = e >> sh; r = e & (d - 1); }
+    else if (((unsigned long)e | (unsigned long)d) >> 32 == 0) { const uint32_t q32 = (uint32_t)e / (uint32_t)d; q = q32; r = (uint32_t)e - q32 * (uint32_t)d; }
+    else { q = e / d; r = e - q * d; }
+}
+inline int fan_log2(long d) { return d > 0 && (d & (d - 1)) == 0 ? __builtin_ctzl((unsigned long)d) : -1; }
 constexpr int kFanMax = 8, kFanGroups = 4;
+static_assert(kFanGroups == 4, "the fan kernels derive the statistics group of an image by three comparisons");
 struct FanInArgs {
     const float4* g[kFanMax];
     const uchar4* keep[kFanMax];
@@ -337,23 +347,28 @@ struct FanInArgs {
     int n, B, Bg;
     long chw4, hw4;
     int W;
+    int sh_chw4, sh_hw4, sh_w;      // log2 of chw4 / hw4 / W, or -1 (fan_divmod)
+    int Ho;                         // H / 2 (mode 4)
     const uint32_t* st;             // step state (philox.hpp) or NULL
 };
 __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, float4* __restrict__ out) {
     const long total = (long)a.B * a.chw4;
     const uint64_t seed = uaps::step_key(a.seed, a.st);
     for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
-        const long b = e / a.chw4, ce = e - b * a.chw4;
-        const int grp = (int)(b / a.Bg);
+        long b, ce;
+        fan_divmod(e, a.chw4, a.sh_chw4, b, ce);
+        const int ib = (int)b, grp = (ib >= a.Bg) + (ib >= 2 * a.Bg) + (ib >= 3 * a.Bg);      // b / Bg for <= kFanGroups = 4 groups
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < kFanMax; ++k) {
             if (k >= a.n) break;
             float4 v;
             if (a.mode[k] == 4) {               // 4 consecutive pixels of row h <- 2 pooled pixels of row h/2
-                const long pl = e / a.hw4, pe = (e - pl * a.hw4) * 4;
-                const int h = (int)(pe / a.W), w = (int)(pe - (long)h * a.W), Wo = a.W / 2;
-                const long po = (pl * (a.hw4 * 4 / a.W / 2) + h / 2) * (long)Wo + w / 2;
+                long pl, pe4, hh, ww;
+                fan_divmod(e, a.hw4, a.sh_hw4, pl, pe4);
+                fan_divmod(pe4 * 4, a.W, a.sh_w, hh, ww);
+                const int h = (int)hh, w = (int)ww, Wo = a.W / 2;
+                const long po = (pl * a.Ho + h / 2) * (long)Wo + w / 2;
                 const float2 gp = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(a.g[k]) + po);
                 const uchar2 ix = *reinterpret_cast<const uchar2*>(reinterpret_cast<const uint8_t*>(a.keep[k]) + po);
                 const int base = (h & 1) * 2;
@@ -373,7 +388,9 @@ __global__ __launch_bounds__(kThreads) void fanin_perturbed_kernel(FanInArgs a, 
                 v.x = u01(r.x) >= a.p ? v.x * a.scale : 0.f; v.y = u01(r.y) >= a.p ? v.y * a.scale : 0.f;
                 v.z = u01(r.z) >= a.p ? v.z * a.scale : 0.f; v.w = u01(r.w) >= a.p ? v.w * a.scale : 0.f;
             } else if (a.mode[k] == 3) {
-                const uchar4 m = a.keep[k][b * a.hw4 + ce % a.hw4];
+                long cc, pix;
+                fan_divmod(ce, a.hw4, a.sh_hw4, cc, pix);
+                const uchar4 m = a.keep[k][b * a.hw4 + pix];
                 v.x = m.x ? v.x : 0.f; v.y = m.y ? v.y : 0.f; v.z = m.z ? v.z : 0.f; v.w = m.w ? v.w : 0.f;
             }
             if (k == 0) acc = v;
@@ -399,14 +416,16 @@ struct FanOutArgs {
     float range, p, scale;
     int n, B, Bg;
     long chw4, hw4;
+    int sh_chw4, sh_hw4;            // log2 of chw4 / hw4, or -1 (fan_divmod)
     const uint32_t* st;             // step state (philox.hpp) or NULL
 };
 __global__ __launch_bounds__(kThreads) void fanout_perturbed_kernel(const float4* __restrict__ f, FanOutArgs a) {
     const long total = (long)a.B * a.chw4;
     const uint64_t seed = uaps::step_key(a.seed, a.st);
     for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
-        const long b = e / a.chw4, ce = e - b * a.chw4;
-        const int grp = (int)(b / a.Bg);
+        long b, ce;
+        fan_divmod(e, a.chw4, a.sh_chw4, b, ce);
+        const int ib = (int)b, grp = (ib >= a.Bg) + (ib >= 2 * a.Bg) + (ib >= 3 * a.Bg);      // b / Bg for <= kFanGroups = 4 groups
         const float4 x = f[e];
 #pragma unroll
         for (int k = 0; k < kFanMax; ++k) {
@@ -423,7 +442,8 @@ __global__ __launch_bounds__(kThreads) void fanout_perturbed_kernel(const float4
                 v.x = u01(r.x) >= a.p ? v.x * a.scale : 0.f; v.y = u01(r.y) >= a.p ? v.y * a.scale : 0.f;
                 v.z = u01(r.z) >= a.p ? v.z * a.scale : 0.f; v.w = u01(r.w) >= a.p ? v.w * a.scale : 0.f;
             } else if (a.mode[k] == 3) {
-                const long pix = ce % a.hw4;
+                long cc, pix;
+                fan_divmod(ce, a.hw4, a.sh_hw4, cc, pix);
                 // threshold factor U(0.7, 0.9) (UAPS_unet.py:164): the host's draw, or -- a negative value asks for it -- one
                 // Philox draw per (call, statistics group) on the device (captured steps cannot take a new host number)
                 const float uf = a.u[grp] >= 0.f ? a.u[grp] : 0.7f + 0.2f * u01(philox4x32_10(a.off[k][grp], seed).x);
@@ -599,6 +619,7 @@ extern "C" int uaps_fanout_perturbed(const float* f, float* const* out, const in
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
     a.st = (const uint32_t*)uaps_get_step_state();
     a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4;
+    a.sh_chw4 = fan_log2(a.chw4); a.sh_hw4 = fan_log2(a.hw4);
     {   // f once, every perturbed copy once (+ the FeatureDropout keep masks, one byte per pixel)
         double by = 4.0 * B * C * HW * (1.0 + n);
         for (int k = 0; k < n; ++k) if (mode[k] == 3) by += (double)B * HW;
@@ -642,7 +663,8 @@ extern "C" int uaps_fanin_perturbed(const float* const* g, const int* mode, cons
     }
     a.seed = seed; a.range = range; a.p = p; a.scale = 1.f / (1.f - p); a.n = n; a.B = B; a.Bg = B / groups;
     a.st = (const uint32_t*)uaps_get_step_state();
-    a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4; a.W = W;
+    a.chw4 = (long)C * HW / 4; a.hw4 = HW / 4; a.W = W; a.Ho = H / 2;
+    a.sh_chw4 = fan_log2(a.chw4); a.sh_hw4 = fan_log2(a.hw4); a.sh_w = fan_log2(W);
     {   // every incoming gradient once (mode 4: the pooled gradient and its index bytes), the keep masks, the sum once
         double by = 4.0 * B * C * HW;
         for (int k = 0; k < n; ++k) by += mode[k] == 4 ? 5.0 * B * C * HW / 4 : 4.0 * B * C * HW + (mode[k] == 3 ? (double)B * HW : 0.0);
