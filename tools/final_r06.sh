@@ -10,6 +10,8 @@ cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/r06/gpu_tests_tail.txt; cat gpurun_out/r06/gpu_tests_tail.txt
 timeout 600 tools/bin/split_gemm_ceiling gpurun_out/r06/split_gemm_ceiling.json > gpurun_out/r06/split_gemm_ceiling.txt 2>&1
 cp gpurun_out/r06/split_gemm_ceiling.json profiles/r06_split_gemm_ceiling.json      # the box's copy: the bench line below reads it
+timeout 600 tools/bin/split_wrw_ceiling gpurun_out/r06/split_wrw_ceiling.json > gpurun_out/r06/split_wrw_ceiling.txt 2>&1
+cp gpurun_out/r06/split_wrw_ceiling.json profiles/r06_split_wrw_ceiling.json      # (same: read by bench.py when a weight-gradient tile kernel leads)
 bash tools/gpu_pmc.sh > gpurun_out/r06/pmc.log 2>&1
 cp gpurun_out/pmc/summary.txt gpurun_out/r06/pmc_traffic_summary.txt
 cp gpurun_out/pmc/pmc_traffic.json gpurun_out/r06/pmc_traffic.json

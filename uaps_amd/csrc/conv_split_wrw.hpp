@@ -20,6 +20,15 @@
 
 namespace uaps {
 
+// Diagnostic builds only (make -C uaps_amd/csrc wrwabl; tools/diag/wrw_ablate.sh): bits of UAPS_WRW_ABLATE remove ONE cost of
+// conv_swrw_body each -- timing only, the results are meaningless.  1: the column taps use the aligned fragment (no v_perm / register
+// assembly of the two shifted ones); 2: no edge dwords (their two 4-byte fetches per unit, their split, their LDS traffic); 4: every
+// fetch unpredicated at clamped coordinates (no branch per staged unit); 8: the two halo rows of the input tile are neither fetched
+// nor staged.  0 = the shipped kernel.
+#ifndef UAPS_WRW_ABLATE
+#define UAPS_WRW_ABLATE 0
+#endif
+
 template <int TH, int WCO, int WCI, int DIL = 1> struct SWrwCfg {
     static constexpr int TW = 32, WR = 4 / (WCO * WCI), RPW = TH / WR;          // rows of the tile per wave
     static constexpr int BCO = 16 * WCO, BCI = 16 * WCI;
@@ -140,6 +149,16 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int n = 0; n < ND; ++n) {
             const int c = co0 + dC[n], gy = y0 + dR[n] * DIL, gx = x0 + dG[n] * 8;
+#if UAPS_WRW_ABLATE & 4
+            {
+                const int cc = c < 0 ? 0 : (c < a.Cout ? c : a.Cout - 1), yy = gy < a.H ? gy : a.H - 1, xx = gx + 8 <= a.W ? gx : a.W - 8;
+                const float* q = a.dout + ((size_t)b * a.Cout + cc) * HW + yy * a.W + xx;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(q), w1 = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rd[n][k] = w0[k]; rd[n][4 + k] = w1[k]; }
+                continue;
+            }
+#endif
             const bool ok = dC[n] >= 0 && c < a.Cout && gy < a.H && gx < a.W;             // W % 4 == 0: float4 pieces are all in or all out
             const float* p = a.dout + ((size_t)b * a.Cout + (ok ? c : 0)) * HW + (ok ? gy * a.W + gx : 0);
             const f32x4 v0 = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -150,6 +169,28 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
             const int c = ci0 + xC[n], gy = y0 + (xR[n] - 1) * DIL, gx = x0 + (xG[n] - XH) * 8;
+#if UAPS_WRW_ABLATE & 8
+            if (xR[n] == 0 || xR[n] == TH + 1) continue;
+#endif
+#if UAPS_WRW_ABLATE & 4
+            {
+                const int cc = c < 0 ? 0 : (c < a.Csplit ? c : a.Csplit - 1), yy = gy < 0 ? 0 : (gy < a.H ? gy : a.H - 1);
+                const int xx = gx < 0 ? 0 : (gx + 8 <= a.W ? gx : a.W - 8);              // (timing layers: W % 8 == 0)
+                const float* q = a.in + ((size_t)b * a.Csplit + cc) * HW + yy * a.W;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(q + xx), w1 = *reinterpret_cast<const f32x4*>(q + xx + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rx[n][k] = w0[k]; rx[n][4 + k] = w1[k]; }
+                if constexpr (DIL == 1) {
+#if !(UAPS_WRW_ABLATE & 2)
+                    rx[n][8] = q[xx > 0 ? xx - 1 : 0]; rx[n][9] = q[xx + 8 < a.W ? xx + 8 : a.W - 1];
+#else
+                    rx[n][8] = 0.f; rx[n][9] = 0.f;
+#endif
+                }
+                if constexpr (XF) xf_idx[n] = (b / a.xf_Bg) * BCI + (xC[n] < 0 ? 0 : xC[n]);
+                continue;
+            }
+#endif
             const bool second = c >= a.Csplit;
             const float* src = second ? a.in2 + ((size_t)b * (a.Cin - a.Csplit) + (c - a.Csplit)) * HW : a.in + ((size_t)b * a.Csplit + c) * HW;
             const bool okc = xC[n] >= 0 && c < a.Cin && gy >= 0 && gy < a.H;
@@ -160,8 +201,12 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { rx[n][k] = v0[k]; rx[n][4 + k] = v1[k]; }
             if constexpr (DIL == 1) {
+#if UAPS_WRW_ABLATE & 2
+                rx[n][8] = 0.f; rx[n][9] = 0.f;
+#else
                 rx[n][8] = (okc && gx - 1 >= 0 && gx - 1 < a.W) ? src[gy * a.W + gx - 1] : 0.f;
                 rx[n][9] = (okc && gx + 8 < a.W) ? src[gy * a.W + gx + 8] : 0.f;
+#endif
             }
             if constexpr (XF) xf_idx[n] = okc ? (b / a.xf_Bg) * BCI + xC[n] : XF_ZERO;     // padding rows / channels stay zero
         }
@@ -186,6 +231,9 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #pragma unroll
         for (int n = 0; n < NX; ++n) {
             if (xC[n] < 0) continue;
+#if UAPS_WRW_ABLATE & 8
+            if (xR[n] == 0 || xR[n] == TH + 1) continue;
+#endif
             if constexpr (XF) {                  // leaky_relu(fma(y, scale, shift)) of the raw conv output; columns outside the image stay zero
                 const f32x2 cf = sXf[xf_idx[n]];
                 const int gx = x0 + xG[n] * 8;
@@ -209,10 +257,14 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                 u32x4 p0, p1;
                 split8h(v8, sc_x, p0, p1);
                 sX[u] = p0; sX[BCI * XPLU + u] = p1;
+#if !(UAPS_WRW_ABLATE & 2)
                 unsigned e0, e1;                 // (right neighbour, left neighbour) -> low / high half of the edge dword
                 const f32x2 ev = f32x2{rx[n][9], rx[n][8]} * bcast_lo(sc_x);
                 conv_split2h(ev.x, ev.y, e0, e1);
                 sE[eu] = e0; sE[BCI * EPL + eu] = e1;
+#else
+                (void)eu;
+#endif
             } else {
                 u32x4 p0, p1, p2;
                 split8(v8, p0, p1, p2);
@@ -264,7 +316,15 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                     bf[1][p] = __builtin_bit_cast(bf16x8, c);
                     continue;
                 }
+#if UAPS_WRW_ABLATE & 1
+                bf[0][p] = __builtin_bit_cast(bf16x8, c); bf[1][p] = __builtin_bit_cast(bf16x8, c); bf[2][p] = __builtin_bit_cast(bf16x8, c);
+                continue;
+#endif
+#if UAPS_WRW_ABLATE & 2
+                const unsigned e = 0u;
+#else
                 const unsigned e = sE[p * BCI * EPL + eoff + r * 4];
+#endif
                 const unsigned t01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), t12 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
                 const unsigned t23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
                 const unsigned tE0 = __builtin_amdgcn_alignbit(c[0], e, 16), t3E = __builtin_amdgcn_alignbit(e, c[3], 16);
