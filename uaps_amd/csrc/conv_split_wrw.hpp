@@ -81,11 +81,21 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     constexpr int TW = 32, WR = Cfg::WR, RPW = Cfg::RPW, BCO = Cfg::BCO, BCI = Cfg::BCI;
     constexpr int DPLU = Cfg::DPLU, XPLU = Cfg::XPLU, EPL = Cfg::EPL, ND = Cfg::ND, NX = Cfg::NX;
     constexpr int RED_FLOATS = WR > 1 ? (WR / 2) * WCO * WCI * 10 * 256 : 0;
-    constexpr int STAGE_UNITS = NP * BCO * DPLU + NP * BCI * XPLU;
+    // EU (fp16 form, no dilation; round 6): the staged input rows carry a FIFTH unit per row that holds the two pixels outside the tile
+    // (left neighbour of column 0 in the high half of dword 3, right neighbour of column 31 in the low half of dword 0); a lane's
+    // shifted fragments then take their boundary dwords from the NEIGHBOURING units of the row already in LDS -- unit (kq + 4) % 5
+    // dword 3 and unit kq + 1 dword 0 -- instead of an edge dword fetched, split and stored per staged unit (two 4-byte fetches, a
+    // split and two LDS stores per unit: 9-10 % of the kernel, profiles/r06_wrw_ablation.txt).
+    constexpr bool EU = H16 && DIL == 1;
+    constexpr int XGS = EU ? 5 : XG;                                   // units per staged row in LDS
+    constexpr int XPLS = EU ? (TH + 2) * 5 + ((TH + 2) * 5 % 4 == 2 ? 0 : (6 - (TH + 2) * 5 % 4) % 4) : XPLU;      // plane stride == 2 (mod 4)
+    static_assert(XPLS % 4 == 2, "input plane stride");
+    constexpr int NE = EU ? (BCI * (TH + 2) + kConvThreads - 1) / kConvThreads : 0;      // edge items (channel, row) per thread
+    constexpr int STAGE_UNITS = NP * BCO * DPLU + NP * BCI * XPLS;
     constexpr int LDS_UNITS = STAGE_UNITS > RED_FLOATS / 4 ? STAGE_UNITS : RED_FLOATS / 4;
 
     __shared__ __attribute__((aligned(16))) u32x4 smem[LDS_UNITS];
-    __shared__ unsigned sE[DIL == 1 ? NP * BCI * EPL : 1];
+    __shared__ unsigned sE[(DIL == 1 && !EU) ? NP * BCI * EPL : 1];
     __shared__ f32x2 sXf[XF ? kWrwMaxGroups * BCI + 1 : 1];
     u32x4* sD = smem;                        // [piece][co][row][4 groups] (+ 2 pad units per plane)
     u32x4* sX = smem + NP * BCO * DPLU;      // [piece][ci][row][4 groups] (+ 2 pad units per plane)
@@ -139,8 +149,18 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     }
 
     float rd[ND][8];
-    float rx[NX][DIL == 1 ? 10 : 8];         // 8 pixels, then (DIL 1) the pixel left of the group and the pixel right of it
+    float rx[NX][(DIL == 1 && !EU) ? 10 : 8];     // 8 pixels, then (bf16 form) the pixel left of the group and the pixel right of it
+    float re[EU ? NE : 1][2];                     // EU: (left, right) outside pixels of this thread's edge items
+    int eC[EU ? NE : 1], eR[EU ? NE : 1];
+    if constexpr (EU) {
+#pragma unroll
+        for (int n = 0; n < NE; ++n) {
+            const int i = tid + n * kConvThreads;
+            eC[n] = i < BCI * (TH + 2) ? i / (TH + 2) : -1; eR[n] = i % (TH + 2);
+        }
+    }
     int xf_idx[XF ? NX : 1];
+    int exf_idx[(XF && EU) ? NE : 1];
 
     auto load_tile = [&](int t) {
         const int b = t / tiles_per_img, tt = t % tiles_per_img;
@@ -180,7 +200,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(q + xx), w1 = *reinterpret_cast<const f32x4*>(q + xx + 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { rx[n][k] = w0[k]; rx[n][4 + k] = w1[k]; }
-                if constexpr (DIL == 1) {
+                if constexpr (DIL == 1 && !EU) {
 #if !(UAPS_WRW_ABLATE & 2)
                     rx[n][8] = q[xx > 0 ? xx - 1 : 0]; rx[n][9] = q[xx + 8 < a.W ? xx + 8 : a.W - 1];
 #else
@@ -200,7 +220,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             const f32x4 v1 = (ok && gx + 4 < a.W) ? *reinterpret_cast<const f32x4*>(p + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 4; ++k) { rx[n][k] = v0[k]; rx[n][4 + k] = v1[k]; }
-            if constexpr (DIL == 1) {
+            if constexpr (DIL == 1 && !EU) {
 #if UAPS_WRW_ABLATE & 2
                 rx[n][8] = 0.f; rx[n][9] = 0.f;
 #else
@@ -209,6 +229,22 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
 #endif
             }
             if constexpr (XF) xf_idx[n] = okc ? (b / a.xf_Bg) * BCI + xC[n] : XF_ZERO;     // padding rows / channels stay zero
+        }
+        if constexpr (EU) {                      // the pixel left of the tile's first column and the pixel right of its last, per (channel, row)
+#pragma unroll
+            for (int n = 0; n < NE; ++n) {
+                const int c = ci0 + eC[n], gy = y0 + eR[n] - 1;
+                const bool second = c >= a.Csplit;
+                const float* src = second ? a.in2 + ((size_t)b * (a.Cin - a.Csplit) + (c - a.Csplit)) * HW : a.in + ((size_t)b * a.Csplit + c) * HW;
+                const bool okc = eC[n] >= 0 && c < a.Cin && gy >= 0 && gy < a.H;
+#if UAPS_WRW_ABLATE & 2
+                re[n][0] = 0.f; re[n][1] = 0.f;
+#else
+                re[n][0] = (okc && x0 - 1 >= 0) ? src[gy * a.W + x0 - 1] : 0.f;
+                re[n][1] = (okc && x0 + TW < a.W) ? src[gy * a.W + x0 + TW] : 0.f;
+#endif
+                if constexpr (XF) exf_idx[n] = okc ? (b / a.xf_Bg) * BCI + eC[n] : XF_ZERO;
+            }
         }
     };
     auto store_tile = [&](int t) {
@@ -238,7 +274,7 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                 const f32x2 cf = sXf[xf_idx[n]];
                 const int gx = x0 + xG[n] * 8;
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
+                for (int k = 0; k < ((DIL == 1 && !EU) ? 10 : 8); ++k) {
                     const int col = k < 8 ? gx + k : (k == 8 ? gx - 1 : gx + 8);
                     const float z = __builtin_fmaf(rx[n][k], cf.x, cf.y);
                     rx[n][k] = (col >= 0 && col < a.W) ? __builtin_fmaxf(z, z * a.xf_slope) : 0.f;
@@ -247,16 +283,21 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             float v8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) v8[k] = rx[n][k];
-            const int u = xC[n] * XPLU + xR[n] * XG + xG[n];
+            const int u = xC[n] * XPLS + xR[n] * XGS + xG[n];
             const int eu = xC[n] * EPL + xR[n] * 4 + xG[n];
             if constexpr (DIL > 1) {
                 u32x4 p0, p1;
                 split8h(v8, sc_x, p0, p1);
-                sX[u] = p0; sX[BCI * XPLU + u] = p1;
+                sX[u] = p0; sX[BCI * XPLS + u] = p1;
+            } else if constexpr (EU) {
+                u32x4 p0, p1;
+                split8h(v8, sc_x, p0, p1);
+                sX[u] = p0; sX[BCI * XPLS + u] = p1;
+                (void)eu;
             } else if constexpr (H16) {
                 u32x4 p0, p1;
                 split8h(v8, sc_x, p0, p1);
-                sX[u] = p0; sX[BCI * XPLU + u] = p1;
+                sX[u] = p0; sX[BCI * XPLS + u] = p1;
 #if !(UAPS_WRW_ABLATE & 2)
                 unsigned e0, e1;                 // (right neighbour, left neighbour) -> low / high half of the edge dword
                 const f32x2 ev = f32x2{rx[n][9], rx[n][8]} * bcast_lo(sc_x);
@@ -268,11 +309,31 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             } else {
                 u32x4 p0, p1, p2;
                 split8(v8, p0, p1, p2);
-                sX[u] = p0; sX[BCI * XPLU + u] = p1; sX[2 * BCI * XPLU + u] = p2;
+                sX[u] = p0; sX[BCI * XPLS + u] = p1; sX[2 * BCI * XPLS + u] = p2;
                 unsigned e0, e1, e2;             // (right neighbour, left neighbour) -> low / high half of the edge dword
                 conv_split3(rx[n][9], rx[n][8], e0, e1, e2);
                 sE[eu] = e0; sE[BCI * EPL + eu] = e1; sE[2 * BCI * EPL + eu] = e2;
             }
+        }
+        if constexpr (EU) {
+#if !(UAPS_WRW_ABLATE & 2)
+#pragma unroll
+            for (int n = 0; n < NE; ++n) {
+                if (eC[n] < 0) continue;
+                float l = re[n][0], r = re[n][1];
+                if constexpr (XF) {              // the same transform as the row's pixels; columns outside the image stay zero
+                    const f32x2 cf = sXf[exf_idx[n]];
+                    const float zl = __builtin_fmaf(l, cf.x, cf.y), zr = __builtin_fmaf(r, cf.x, cf.y);
+                    l = x0 - 1 >= 0 ? __builtin_fmaxf(zl, zl * a.xf_slope) : 0.f;
+                    r = x0 + TW < a.W ? __builtin_fmaxf(zr, zr * a.xf_slope) : 0.f;
+                }
+                unsigned e0, e1;                 // (right neighbour, left neighbour) -> low / high half: dword 0 serves the row's last unit, dword 3 its first
+                const f32x2 ev = f32x2{r, l} * bcast_lo(sc_x);
+                conv_split2h(ev.x, ev.y, e0, e1);
+                const int ue = eC[n] * XPLS + eR[n] * XGS + 4;
+                sX[ue] = u32x4{e0, e0, e0, e0}; sX[BCI * XPLS + ue] = u32x4{e1, e1, e1, e1};
+            }
+#endif
         }
     };
 
@@ -285,8 +346,10 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
     const int aoff = (wco * 16 + j) * DPLU + kq;         // + row * 4 (+ piece plane)
-    const int boff = (wci * 16 + j) * XPLU + kq + XH;    // + row * XG
+    const int boff = (wci * 16 + j) * XPLS + kq + XH;    // + row * XGS
     const int eoff = (wci * 16 + j) * EPL + kq;
+    // EU: dword indices (within a staged row of 5 units) of the dword left of this lane's k-group and of the dword right of it
+    const int elidx = ((kq + 4) % 5) * 4 + 3, eridx = (kq + 1) * 4;
 
     if (t_begin < t_end) { load_tile(t_begin); }
     if constexpr (XF) __syncthreads();                   // sXf visible
@@ -302,10 +365,10 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
             bf16x8 bf[3][NP];                             // [shift kx][piece]
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const u32x4 c = sX[p * BCI * XPLU + boff + r * XG];
+                const u32x4 c = sX[p * BCI * XPLS + boff + r * XGS];
                 if constexpr (DIL > 1) {                  // neighbours' dwords: pixels x - DIL .. x - 1 and x + 8 .. x + 7 + DIL
-                    const unsigned* cl = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLU + boff + r * XG - 1]);
-                    const unsigned* cr = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLU + boff + r * XG + 1]);
+                    const unsigned* cl = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLS + boff + r * XGS - 1]);
+                    const unsigned* cr = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLS + boff + r * XGS + 1]);
                     if constexpr (DIL == 2) {
                         bf[0][p] = __builtin_bit_cast(bf16x8, u32x4{cl[3], c[0], c[1], c[2]});
                         bf[2][p] = __builtin_bit_cast(bf16x8, u32x4{c[1], c[2], c[3], cr[0]});
@@ -320,14 +383,20 @@ __device__ __forceinline__ void conv_swrw_body(const ConvWrwArgs& a) {
                 bf[0][p] = __builtin_bit_cast(bf16x8, c); bf[1][p] = __builtin_bit_cast(bf16x8, c); bf[2][p] = __builtin_bit_cast(bf16x8, c);
                 continue;
 #endif
+                unsigned el, er;                          // high half of el = the pixel left of the group, low half of er = the pixel right of it
 #if UAPS_WRW_ABLATE & 2
-                const unsigned e = 0u;
+                el = er = 0u;
 #else
-                const unsigned e = sE[p * BCI * EPL + eoff + r * 4];
+                if constexpr (EU) {
+                    const unsigned* rowd = reinterpret_cast<const unsigned*>(&sX[p * BCI * XPLS + (wci * 16 + j) * XPLS + r * XGS]);
+                    el = rowd[elidx]; er = rowd[eridx];
+                } else {
+                    el = er = sE[p * BCI * EPL + eoff + r * 4];
+                }
 #endif
                 const unsigned t01 = __builtin_amdgcn_alignbit(c[1], c[0], 16), t12 = __builtin_amdgcn_alignbit(c[2], c[1], 16);
                 const unsigned t23 = __builtin_amdgcn_alignbit(c[3], c[2], 16);
-                const unsigned tE0 = __builtin_amdgcn_alignbit(c[0], e, 16), t3E = __builtin_amdgcn_alignbit(e, c[3], 16);
+                const unsigned tE0 = __builtin_amdgcn_alignbit(c[0], el, 16), t3E = __builtin_amdgcn_alignbit(er, c[3], 16);
                 bf[0][p] = __builtin_bit_cast(bf16x8, u32x4{tE0, t01, t12, t23});          // pixels x - 1
                 bf[1][p] = __builtin_bit_cast(bf16x8, c);
                 bf[2][p] = __builtin_bit_cast(bf16x8, u32x4{t01, t12, t23, t3E});          // pixels x + 1
