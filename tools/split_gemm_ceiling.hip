@@ -291,6 +291,19 @@ int main(int argc, char** argv) {
         if (js) fprintf(js, "], \"best_tflops\": %.1f, \"best_tflops_reread\": %.1f}", best, best_reread);
     }
     if (js) { fprintf(js, "]}\n"); fclose(js); }
+    // ---- the 32-output-channel layers of the 128 x 128 level (conv_h32t_kernel<32>: 11 launches per step at 165-222 TFLOP/s): not part
+    // of the JSON's four layers (roofline.practical_peak is defined on those), printed for DESIGN.md section 3.2
+    const Layer narrow[] = {{"32 -> 32 @128^2", 32, 128, 128, 32, 32}, {"64 -> 32 @128^2", 32, 128, 128, 64, 32}};
+    for (const Layer& L : narrow) {
+        printf("%s, B = %d: M = %d pixels, N = %d, K = %d x 9 taps, %.2f GFLOP\n", L.name, L.B, L.B * L.H * L.W, L.Cout, L.Cin,
+               2.0 * L.B * L.H * L.W * L.Cout * L.Cin * 9 / 1e9);
+        run<8, 2, 4, 1, 9, false, 1>(L, "128x32 per wave, 4 waves (1 / SIMD), A re-read per tap", true, nullptr, true);
+        run<8, 2, 4, 1, 9, false, 2>(L, "128x32 per wave, 4 waves, 2 wg / CU, A re-read", false, nullptr, true);
+        run<4, 2, 4, 1, 9, false, 2>(L, "64x32 per wave, 4 waves, 2 wg / CU, A re-read", false, nullptr, true);
+        run<4, 2, 4, 1, 9, false, 4>(L, "64x32 per wave, 4 waves, 4 wg / CU, A re-read", false, nullptr, true);
+        run<4, 2, 8, 1, 9, false, 2>(L, "64x32 per wave, 8 waves, 2 wg / CU, A re-read", false, nullptr, true);
+        run<8, 2, 4, 1, 9, true, 1>(L, "128x32 per wave, 4 waves (1 / SIMD), A frags kept", false, nullptr, true);
+    }
     // ---- the same kernel as a plain GEMM (R = 1): the ResNet-50 configuration's 1x1 bottleneck projections (utilities/resnet.py:
     // 55-95) at the configs[4] per-GPU batch, 8 + 8 images of 640 x 640 -> 80 x 80 maps.  Every staged activation element now serves
     // ONE tap: the split arithmetic of the staging is no longer amortised over nine.  Shipped conv_g1h256_kernel: 692-751 us on the
