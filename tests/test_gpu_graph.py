@@ -401,3 +401,35 @@ def test_a_parameter_with_a_foreign_gradient_hook_or_a_derived_weight_is_reduced
         conv.conv2d(x, v * 2.0, None).sum().backward()          # the weight is a non-leaf: its gradient feeds the multiplication's backward
         assert not step.deferred
     np.testing.assert_allclose(v.grad.cpu().numpy(), 2.0 * ref, rtol=2e-5, atol=4e-4)
+
+
+def test_a_replayed_step_launches_no_library_kernel():
+    """with the batch written into the graph's own input tensors (StepGraph.inputs()) and the live output scalars
+    (StepGraph.live_outputs), a replayed training step is hand-written kernels plus ONE 64-byte upload of the step state (the host-drawn
+    Dirichlet weights, ramp weights, Adam scalars and Philox key: graph.StepState.upload): no ATen elementwise / fill / reduction
+    kernel and no other runtime copy appears in a profiled replay.  (The default -- caller-owned inputs, cloned output scalars -- adds
+    three input copies and three scalar clones OUTSIDE the graph: tools/diag/replay_library_launches.py lists them.)"""
+    import uaps_amd
+    from torch.profiler import ProfilerActivity, profile
+    tr = uaps_amd.UAPSTrainer(_model(9).to(DEV), base_lr=1e-3, seed=0, use_graph=True, track_metrics=False)
+    data = _batches(1, 4, 64, 64)[0]
+    for _ in range(4):                           # warm-up steps, the capture, one replay
+        tr.train_step(*data)
+    g = tr.step_graph
+    assert g.graph is not None and g.inputs() is not None
+    g.live_outputs = True
+    xs = g.inputs()
+    for dst, src in zip(xs, data):               # the "data pipeline": writes the batch where the graph reads it
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        last = tr.train_step(*xs)
+        torch.cuda.synchronize()
+    dev_names = [str(e.name) for e in prof.events() if e.device_type.name == "CUDA"]
+    own = [n for n in dev_names if "uaps::" in n or "(anonymous namespace)::" in n]
+    other = [n for n in dev_names if n not in own]
+    assert len(own) > 100, len(own)              # the graph's kernels are in the trace
+    assert not [n for n in other if not n.startswith("Memcpy")], other
+    assert len(other) <= 1, other                # the step-state upload
+    assert last["loss"].data_ptr() == g.static["out"].loss.data_ptr()      # the live tensor, not a copy
+    assert bool(torch.isfinite(last["loss"]))

@@ -92,12 +92,19 @@ class StepGraph:
         self.graph_tail: Optional[torch.cuda.CUDAGraph] = None      # split form: Adam + confusion matrix
         self.calls = 0
         self.static = None
+        self.live_outputs = False                # True: train_step returns the graph's own scalar tensors (overwritten by the next replay)
         self._side = torch.cuda.Stream(device=trainer.device) if capture else None
         # data parallel + capture: every step of every rank, warm-up and fallback steps included, launches the bucket
         # all-reduces in ONE fixed order after the backward (exchange_all), never from the backward hooks -- a rank whose
         # capture failed, or that steps eagerly for another reason, still pairs the same buckets as the ranks that replay
         self.fixed_order = self.split and capture
         trainer.optimizer.from_step_state = True
+
+    def inputs(self):
+        """The graph's own input tensors (x_l, y_l, x_u) once the step is captured, else None: a data pipeline that writes a batch
+        straight into them (and passes them to train_step) spares the replay its three input copies."""
+        s = self.static
+        return None if s is None else (s["x_l"], s["y_l"], s["x_u"])
 
     def invalidate(self) -> None:
         """Forget the capture (checkpoint load, anything that replaced tensors the graph addresses): the next steps warm up
@@ -210,8 +217,9 @@ class StepGraph:
             tr._cms.append(cm.clone() if self.graph is not None else cm)
         tr.iter_num += 1
         # a replay overwrites the graph's static output tensors: hand out copies (as for the confusion matrix above), so that
-        # scalars a caller collects over an epoch keep their own step's values
-        sc = (lambda t: t.detach().clone()) if self.graph is not None else (lambda t: t.detach())
+        # scalars a caller collects over an epoch keep their own step's values -- unless the caller asked for the live tensors
+        # (`live_outputs`: a loop that reads the loss only now and then; three small library launches fewer per step)
+        sc = (lambda t: t.detach().clone()) if (self.graph is not None and not self.live_outputs) else (lambda t: t.detach())
         tr.last = {"loss": sc(out.loss), "sup": sc(out.sup), "unsup": sc(out.unsup), "cw1": cw1, "cw2": cw2, "w": w}
         return tr.last
 
