@@ -3,6 +3,7 @@ main-head prediction, the all-heads ensemble of the paper's decoder study, the t
 per-image score table.  Everything runs on the HIP kernels of this package; nothing here trains."""
 from __future__ import annotations
 
+import operator
 from typing import Dict, Iterable, Optional, Tuple
 
 import numpy as np
@@ -33,6 +34,9 @@ def predict_main(model: torch.nn.Module, images: torch.Tensor) -> torch.Tensor:
     return torch.argmax(logits, dim=1)
 
 
+_VERSION = operator.attrgetter("_version")
+
+
 class CapturedMainHead:
     """predict_main for ONE input shape as a replayed hipGraph: at batch 1 the eager call is ~90 launches of a few microseconds of
     work each and is bound by their issue; the replay hands the device the whole chain at once.  Same kernels and arithmetic as
@@ -48,6 +52,7 @@ class CapturedMainHead:
         if not example.is_cuda:
             raise ValueError("CapturedMainHead: a GPU tensor expected")
         self.model, self.x = model, example.detach().clone()
+        self._tensors = self._params = None
         model.eval()
         cur = torch.cuda.current_stream(example.device)
         side = torch.cuda.Stream(device=example.device)
@@ -72,9 +77,23 @@ class CapturedMainHead:
         self._stamp = self._weights_stamp()
 
     def _weights_stamp(self):
+        """(manual-invalidation generation, number of tensors, sum of the version counters of every parameter and buffer, sum of the
+        parameters' optimizer counters).  Every term only ever grows, so a sum changes exactly when one of its terms does.  This runs in
+        front of EVERY replay (the tuple-of-tuples form of the first version cost 0.5 ms per call, more than the graph): the versions
+        are summed by a C-level loop over a cached list, the optimizer counters are only walked when some optimizer of the process has
+        stepped since the last look (conv._shared_cell)."""
         from . import conv
-        return (tuple(conv.stamp(p) for p in self.model.parameters()), tuple(p._version for p in self.model.parameters()),
-                tuple(b._version for b in self.model.buffers()))
+        if self._tensors is None:
+            # a model with forward_main runs its encoder and main decoder only (unet.UNet_UAPS): watch those tensors, a third of the net
+            mods = [getattr(self.model, n, None) for n in ("encoder", "main_decoder")] if hasattr(self.model, "forward_main") else []
+            mods = mods if mods and all(isinstance(m, torch.nn.Module) for m in mods) else [self.model]
+            self._params = [p for m in mods for p in m.parameters()]
+            self._tensors = self._params + [b for m in mods for b in m.buffers()]
+            self._seen_steps, self._cell_sum = -1, 0
+        if conv._shared_cell[0] != self._seen_steps:
+            self._seen_steps = conv._shared_cell[0]
+            self._cell_sum = sum(c[0] for c in (getattr(p, "_uaps_cell", None) for p in self._params) if c is not None)
+        return (conv._generation, len(self._tensors), sum(map(_VERSION, self._tensors)), self._cell_sum)
 
     def stale(self) -> bool:
         """Have the model's parameters or buffers changed since the capture (an optimizer step, a checkpoint load, an in-place edit)?"""
