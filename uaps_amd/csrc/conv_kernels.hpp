@@ -746,21 +746,82 @@ constexpr int kReduceBatch = 28;
 struct ReduceDesc {
     const float* slab; const float* bslab; float* dw; float* db;
     int nsplit, taps, Cout, Cin, CoutS, CinS;
-    int el;                 // 16 or 64: elements per block, as the single launch chooses
+    int el;                 // 16 or 64: elements per block, as the single launch chooses; 256: a 64-element item in the 16-byte form
     unsigned first;         // first block of this item
 };
 struct ReduceBatch { ReduceDesc d[kReduceBatch]; int n; unsigned blocks; };
 
 static __global__ __launch_bounds__(256) void conv_wrw_reduce_batch_kernel(ReduceBatch rb) {
-    __shared__ float red[256];
+    __shared__ __attribute__((aligned(16))) float red[1024];
     if (blockIdx.x >= rb.blocks) return;
     int i = 0;
     while (i + 1 < rb.n && rb.d[i + 1].first <= blockIdx.x) ++i;      // uniform: <= kReduceBatch scalar compares
     const ReduceDesc& q = rb.d[i];
-    const int EL = q.el, SL = 256 / EL;
     const long n = (long)q.taps * q.CoutS * q.CinS;
+    const unsigned blk = blockIdx.x - q.first;
+    if (q.el == 256) {
+        // 64-element items, 16 bytes per lane (round 6): a block owns 256 consecutive slab elements, its 4 split lanes x 64 threads
+        // each sum 4 adjacent elements with EXACTLY the chains of the 4-byte form (per element: the same splits in the same order,
+        // the same (s0 + s1) + (s2 + s3), the same lane order) -- bit-identical, one KiB per wave-load instead of 256 bytes.  The
+        // bias partials follow in 64-element blocks of the 4-byte form below.
+        const unsigned wblocks = (unsigned)((n + 255) / 256);
+        if (blk < wblocks) {
+            constexpr int SL = 4;
+            const int el4 = threadIdx.x & 63, sl = threadIdx.x >> 6;
+            const long e = (long)blk * 256 + el4 * 4;
+            f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+            const bool in = e < n;                                      // n % 4 == 0: four elements are all inside or all outside
+            if (in) {
+                const float* src = q.slab + e;
+                int k = sl;
+                for (; k + 3 * SL < q.nsplit; k += 4 * SL) {
+                    s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * n); s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + SL) * n);
+                    s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 2 * SL) * n); s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(k + 3 * SL) * n);
+                }
+                for (; k < q.nsplit; k += SL) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)k * n);
+            }
+            const f32x4 t = (s0 + s1) + (s2 + s3);
+            *reinterpret_cast<f32x4*>(&red[(sl * 64 + el4) * 4]) = t;
+            __syncthreads();
+            if (sl != 0 || !in) return;
+            f32x4 s = t;
+#pragma unroll
+            for (int r = 1; r < SL; ++r) s += *reinterpret_cast<const f32x4*>(&red[(r * 64 + el4) * 4]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const long ev = e + v;
+                const int ci = (int)(ev % q.CinS); const long r = ev / q.CinS;
+                const int co = (int)(r % q.CoutS), tp = (int)(r / q.CoutS);
+                if (co < q.Cout && ci < q.Cin) q.dw[((long)co * q.Cin + ci) * q.taps + tp] = s[v];
+            }
+            return;
+        }
+        // bias partials: 64 elements per block, the 4-byte form
+        const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const long eb = (long)(blk - wblocks) * 64 + el;
+        const bool is_b = q.bslab != nullptr && eb < q.CoutS;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (is_b) {
+            const float* src = q.bslab + eb;
+            const size_t stride = (size_t)q.CoutS;
+            int k = sl;
+            for (; k + 3 * 4 < q.nsplit; k += 16) {
+                s0 += src[(size_t)k * stride]; s1 += src[(size_t)(k + 4) * stride];
+                s2 += src[(size_t)(k + 8) * stride]; s3 += src[(size_t)(k + 12) * stride];
+            }
+            for (; k < q.nsplit; k += 4) s0 += src[(size_t)k * stride];
+        }
+        red[sl * 64 + el] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl != 0) return;
+        float s = red[el];
+        for (int r = 1; r < 4; ++r) s += red[r * 64 + el];
+        if (is_b && q.db && eb < q.Cout) q.db[eb] = s;
+        return;
+    }
+    const int EL = q.el, SL = 256 / EL;
     const int el = threadIdx.x % EL, sl = threadIdx.x / EL;
-    const long e = (long)(blockIdx.x - q.first) * EL + el;
+    const long e = (long)blk * EL + el;
     const bool is_w = e < n, is_b = !is_w && q.bslab != nullptr && e - n < q.CoutS;
     const float* src = is_w ? q.slab + e : (is_b ? q.bslab + (e - n) : nullptr);
     const size_t stride = is_w ? (size_t)n : (size_t)q.CoutS;

@@ -415,7 +415,12 @@ extern "C" int uaps_conv_bwd_weight_reduce_batch(const uaps_wrw_reduce_item* ite
             const long ne = (long)taps * p.CoutS * p.CinS + (it.dbias ? p.CoutS : 0);
             q.el = ne < 32768 ? 16 : 64;
             q.first = blocks;
-            const long nb = (ne + q.el - 1) / q.el;
+            long nb = (ne + q.el - 1) / q.el;
+            const long nw = (long)taps * p.CoutS * p.CinS;
+            if (q.el == 64 && nw % 4 == 0 && (reinterpret_cast<uintptr_t>(q.slab) & 15) == 0) {      // the 16-byte form of conv_wrw_reduce_batch_kernel
+                q.el = 256;
+                nb = (nw + 255) / 256 + (it.dbias ? (p.CoutS + 63) / 64 : 0);
+            }
             if (nb + blocks > 0x7fffffffL) return UAPS_ERANGE;
             blocks += (unsigned)nb;
         }
